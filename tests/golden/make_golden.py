@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by running the REFERENCE (/root/reference) on CPU.
+
+Runs only in the build container (the reference tree never travels to the GPU box); the ``.npz`` files it
+writes are committed.  Usage:  python tests/golden/make_golden.py
+
+What is pinned (see oracle/l3ac_oracle.py docstring):
+  * ``*_conv.npz``   — reference ``Codec`` (encoder / quantizer / to_features / decoder) outputs, produced by
+                       reference code only.  Weights come from l3ac_amd.weights.synthetic_state_dicts and are
+                       loaded into the reference with ``load_state_dict(strict=True)`` (also pins the schema).
+  * ``*_e2e.npz``    — reference ``EnCodec`` wiring (l3ac/local_trans.py, en_codec.py) run end to end, with the
+                       absent PyPI dependency ``local_attention`` replaced by a stand-in built on the oracle's
+                       own restatement.  Pins the WIRING only; the attention arithmetic stays unpinned.
+  * ``fsq_kat.npz``  — known-answer vectors from the reference ``SuperFSQ`` (half-even ties, saturation, decode).
+"""
+import sys
+import types
+from pathlib import Path
+
+sys.dont_write_bytecode = True
+HERE = Path(__file__).resolve().parent
+REPO = HERE.parent.parent
+sys.path.insert(0, str(REPO))
+sys.path.insert(0, "/root/reference")
+
+import numpy as np
+import pydantic
+import torch
+import torch.nn as nn
+
+# --- harness stub: pydantic-settings is not installed here; l3ac/xtract/config.py only needs the names --------
+_ps = types.ModuleType("pydantic_settings")
+_ps.BaseSettings = type("BaseSettings", (pydantic.BaseModel,), {})
+_ps.SettingsConfigDict = dict
+_ps.PydanticBaseSettingsSource = object
+_ps.TomlConfigSettingsSource = object
+sys.modules["pydantic_settings"] = _ps
+
+from oracle import l3ac_oracle as O  # noqa: E402
+
+
+# --- harness stand-in for the absent `local_attention` package (wiring check only) ---------------------------
+def _install_local_attention_standin():
+    class DynamicPositionBias(nn.Module):
+        def __init__(self, dim, heads):
+            super().__init__()
+            self.mlp = nn.Sequential(nn.Linear(1, dim), nn.SiLU(), nn.Linear(dim, dim), nn.SiLU(), nn.Linear(dim, heads))
+
+        def forward(self, i, j):
+            w = {f"p.mlp.{k}": v for k, v in self.mlp.state_dict().items()}
+            return O.dynamic_position_bias(w, "p", i, j)
+
+    class LocalMHA(nn.Module):
+        def __init__(self, *, dim, window_size, dim_head, heads, dropout, causal, prenorm, qk_rmsnorm,
+                     use_xpos, xpos_scale_base, exact_windowsize, use_rotary_pos_emb):
+            super().__init__()
+            assert causal and prenorm and not qk_rmsnorm and not use_xpos and not exact_windowsize
+            assert not use_rotary_pos_emb and heads == O.HEADS and dropout == 0.
+            self.window_size = window_size
+            self.norm = nn.LayerNorm(dim)
+            self.to_qkv = nn.Linear(dim, dim_head * heads * 3, bias=False)
+            self.to_out = nn.Linear(dim_head * heads, dim, bias=False)
+
+        def forward(self, x, mask=None, attn_bias=None):
+            assert mask is None
+            w = {f"p.{k}": v for k, v in self.state_dict().items()}
+            return O.local_mha(w, "p", x, self.window_size, attn_bias)
+
+    class GEGLU(nn.Module):
+        def forward(self, x):
+            a, gate = x.chunk(2, dim=-1)
+            return a * torch.nn.functional.gelu(gate)
+
+    def FeedForward(dim, mult=4, dropout=0.):
+        inner = int(dim * mult * 2 / 3)
+        return nn.Sequential(nn.LayerNorm(dim), nn.Linear(dim, inner * 2, bias=False), GEGLU(), nn.Dropout(dropout),
+                             nn.Linear(inner, dim, bias=False))
+
+    pkg = types.ModuleType("local_attention")
+    tr = types.ModuleType("local_attention.transformer")
+    tr.DynamicPositionBias, tr.LocalMHA, tr.FeedForward = DynamicPositionBias, LocalMHA, FeedForward
+    pkg.transformer = tr
+    sys.modules["local_attention"] = pkg
+    sys.modules["local_attention.transformer"] = tr
+
+
+_install_local_attention_standin()
+
+import l3ac.codec  # noqa: E402  (reference)
+import l3ac.en_codec  # noqa: E402  (reference)
+
+from l3ac_amd.config import L3ACConfig, resolve_config_file  # noqa: E402
+from l3ac_amd import weights as W  # noqa: E402
+
+
+def seeded_audio(batch, samples, seed=1234):
+    """(rand * 2 - 1) * 0.5 from a CPU generator."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.rand(batch, samples, generator=g) * 2 - 1) * 0.5
+
+
+def build_reference(cfg_file, seed):
+    cfg = L3ACConfig(config_file=cfg_file)
+    mc = cfg.network_config
+    ref_mc = l3ac.en_codec.ModelConfig(**mc.model_dump(exclude={"hop_length"}))
+    assert ref_mc.hop_length == mc.hop_length
+    ref = l3ac.en_codec.EnCodec(ref_mc).eval()
+    sds = W.synthetic_state_dicts(mc, seed=seed)
+    for name, module in ref.trainable_modules.items():
+        want = {k: tuple(v.shape) for k, v in module.state_dict().items()}
+        have = dict(W.raw_keys(mc, name))
+        assert want == have, f"{name}: schema mismatch {set(want) ^ set(have)}"
+        module.load_state_dict(sds[name], strict=True)
+    return mc, ref, sds
+
+
+def strided(t, n=4096):
+    flat = t.reshape(-1)
+    step = max(1, flat.numel() // n)
+    return flat[::step][:n].numpy().copy()
+
+
+@torch.inference_mode()
+def make_model_fixtures(tag, cfg_file, seed, batch, samples, full_tensors):
+    mc, ref, _ = build_reference(cfg_file, seed)
+    audio = seeded_audio(batch, samples)
+    out = {"seed": np.int64(seed), "audio_seed": np.int64(1234), "batch": np.int64(batch), "samples": np.int64(samples)}
+
+    # ---- conv stacks + quantiser: reference code only ------------------------------------------------
+    x, length = ref.preprocess(audio)
+    hooks, taps = [], {}
+    for name, m in list(ref.encoder.blocks.named_children()) + []:
+        hooks.append(m.register_forward_hook(lambda _m, _i, o, n=name: taps.__setitem__(f"enc_block{n}", o)))
+    feature = ref.encoder(x.unsqueeze(1))
+    for h in hooks:
+        h.remove()
+    q_feat, ind, loss = ref.quantizer(feature.permute(0, 2, 1))  # Codec.forward order (codec.py:101-103)
+    feats_from_idx = ref.quantizer.to_features(ind["indices"])
+    lat = ref.quantizer.project_in(feature.permute(0, 2, 1))
+    hooks, dtaps = [], {}
+    for name, m in ref.decoder.blocks.named_children():
+        hooks.append(m.register_forward_hook(lambda _m, _i, o, n=name: dtaps.__setitem__(f"dec_block{n}", o)))
+    wave = ref.decoder(q_feat.permute(0, 2, 1)).squeeze(1)
+    for h in hooks:
+        h.remove()
+    conv = dict(out)
+    conv.update(padded_len=np.int64(x.shape[-1]), orig_len=np.int64(length),
+                indices=ind["indices"].numpy(), level_indices=ind["level_indices"].numpy(),
+                vq_loss=loss.numpy())
+    assert torch.equal(feats_from_idx, q_feat), "to_features(indices) != q_feat"
+    big = {"feature": feature, "latents": lat, "q_feat": q_feat, "wave": wave, **taps, **dtaps}
+    for k, v in big.items():
+        if full_tensors:
+            conv[k] = v.numpy()
+        else:
+            conv[k + "_strided"] = strided(v)
+            conv[k + "_sum"] = np.float64(v.double().sum().item())
+            conv[k + "_abssum"] = np.float64(v.double().abs().sum().item())
+            conv[k + "_shape"] = np.array(v.shape, dtype=np.int64)
+    np.savez_compressed(HERE / f"{tag}_conv.npz", **conv)
+
+    # ---- end to end through the reference's EnCodec wiring (stand-in attention) ----------------------
+    feature = ref.encoder(x.unsqueeze(1))  # l3ac/__init__.py:108-114
+    trans = ref.en_encoder(feature)
+    q_trans, ind2, _ = ref.quantizer(trans)
+    q_feature = ref.en_decoder(q_trans)  # l3ac/__init__.py:116-121
+    wave2 = ref.decoder(q_feature).squeeze(1)
+    wave_from_idx = ref.decoder(ref.en_decoder(ref.quantizer.to_features(ind2["indices"]))).squeeze(1)
+    fwd = ref(audio)  # EnCodec.forward (en_codec.py:53-72)
+    assert torch.equal(fwd["indices"], ind2["indices"])
+    assert torch.equal(fwd["generated_audio"], wave2[..., :length])
+    assert torch.equal(wave_from_idx, wave2)
+    e2e = dict(out)
+    e2e.update(indices=ind2["indices"].numpy(), level_indices=ind2["level_indices"].numpy())
+    big = {"trans": trans, "latents": ref.quantizer.project_in(trans), "q_trans": q_trans,
+           "q_feature": q_feature, "wave": wave2}
+    for k, v in big.items():
+        if full_tensors:
+            e2e[k] = v.numpy()
+        else:
+            e2e[k + "_strided"] = strided(v)
+            e2e[k + "_sum"] = np.float64(v.double().sum().item())
+            e2e[k + "_abssum"] = np.float64(v.double().abs().sum().item())
+            e2e[k + "_shape"] = np.array(v.shape, dtype=np.int64)
+    np.savez_compressed(HERE / f"{tag}_e2e.npz", **e2e)
+    hist = np.bincount(ind2["level_indices"].numpy().astype(np.int64).reshape(-1), minlength=max(mc.levels))
+    print(f"[{tag}] hop={mc.hop_length} tokens={ind2['indices'].shape} wave std={wave2.std():.4f} "
+          f"|wave|max={wave2.abs().max():.4f} level hist={hist.tolist()}")
+
+
+@torch.inference_mode()
+def make_fsq_kat():
+    from l3ac.vq.fsq import SuperFSQ  # reference
+    out = {}
+    for tag, levels in (("l7", [7] * 6), ("l9977", [9, 9, 9, 7, 7, 7]), ("even", [2, 4, 6, 8]), ("tiny", [5, 3, 4])):
+        fsq = SuperFSQ(levels=levels, noise_rate=0.5).eval()
+        d = len(levels)
+        g = torch.Generator().manual_seed(7)
+        rows = [torch.zeros(1, d), torch.full((1, d), 20.0), torch.full((1, d), -20.0),
+                torch.full((1, d), float("inf")), torch.full((1, d), -float("inf")),
+                torch.randn(4096, d, generator=g) * 1.5]
+        z = torch.cat(rows)
+        q, ind = fsq(z)
+        k = int(torch.prod(torch.tensor(levels)))
+        all_idx = torch.arange(k, dtype=torch.int32)
+        sel = all_idx if k <= 4096 else all_idx[:: k // 4096]
+        out[f"{tag}_levels"] = np.array(levels, dtype=np.int32)
+        out[f"{tag}_z"] = z.numpy()
+        out[f"{tag}_q"] = q.numpy()
+        out[f"{tag}_indices"] = ind["indices"].numpy()
+        out[f"{tag}_level_indices"] = ind["level_indices"].numpy()
+        out[f"{tag}_dec_idx"] = sel.numpy()
+        out[f"{tag}_dec_codes"] = fsq.indices_to_codes(sel).numpy()
+        # closed form == nearest neighbour over the explicit codebook: record reference answers
+        codes = fsq.indices_to_codes(all_idx)
+        zq = torch.tanh(z[5:5 + 512])
+        nn_idx = torch.cdist(zq, codes).argmin(dim=1).to(torch.int32)
+        out[f"{tag}_nn_query"] = zq.numpy()
+        out[f"{tag}_nn_idx"] = nn_idx.numpy()
+    np.savez_compressed(HERE / "fsq_kat.npz", **out)
+    print("[fsq_kat] written")
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    make_fsq_kat()
+    make_model_fixtures("tiny", HERE / "tiny.toml", seed=3, batch=2, samples=250, full_tensors=True)
+    make_model_fixtures("1kbps", resolve_config_file("1kbps"), seed=0, batch=2, samples=16000, full_tensors=False)
+    make_model_fixtures("3kbps", resolve_config_file("3kbps"), seed=0, batch=2, samples=16000, full_tensors=False)

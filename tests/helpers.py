@@ -1,0 +1,56 @@
+"""Shared helpers for the parity tests (test infrastructure)."""
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from l3ac_amd import weights as W
+from l3ac_amd.config import L3ACConfig, resolve_config_file
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+
+
+def seeded_audio(batch, samples, seed=1234):
+    """(rand * 2 - 1) * 0.5 from a CPU generator."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.rand(batch, samples, generator=g) * 2 - 1) * 0.5
+
+
+def load_case(tag):
+    """(mc, folded weights, conv fixture, e2e fixture) for a golden case; weights regenerate from the seed."""
+    cfg_file = GOLDEN / "tiny.toml" if tag == "tiny" else resolve_config_file(tag)
+    mc = L3ACConfig(config_file=cfg_file).network_config
+    conv = np.load(GOLDEN / f"{tag}_conv.npz")
+    e2e = np.load(GOLDEN / f"{tag}_e2e.npz")
+    sds = W.synthetic_state_dicts(mc, seed=int(conv["seed"]))
+    return mc, W.folded_weights(sds), conv, e2e
+
+
+def strided(t, n=4096):
+    flat = t.reshape(-1)
+    step = max(1, flat.numel() // n)
+    return flat[::step][:n]
+
+
+def index_mismatch_report(idx, idx_ref, latents_ref, levels, tau):
+    """Compare quantiser indices.  Every mismatch must be a +-1 step in level space caused by a latent whose
+    act*(L-1) lies within `tau` of a rounding boundary (SURVEY §7 'hard parts').  Returns (n_mismatch, ok)."""
+    idx = np.asarray(idx).reshape(-1).astype(np.int64)
+    idx_ref = np.asarray(idx_ref).reshape(-1).astype(np.int64)
+    bad = np.nonzero(idx != idx_ref)[0]
+    if bad.size == 0:
+        return 0, True
+    lv = np.asarray(levels, dtype=np.int64)
+    basis = np.concatenate([[1], np.cumprod(lv[:-1])])
+    lat = np.asarray(latents_ref, dtype=np.float64).reshape(-1, len(lv))
+    ok = True
+    for r in bad:
+        li = (idx[r] // basis) % lv
+        li_ref = (idx_ref[r] // basis) % lv
+        diff = np.nonzero(li != li_ref)[0]
+        scaled = (np.tanh(lat[r]) + 1) / 2 * (lv - 1)
+        margin = np.abs(np.abs(scaled - np.floor(scaled)) - 0.5)
+        for d in diff:
+            if abs(li[d] - li_ref[d]) != 1 or margin[d] > tau:
+                ok = False
+    return int(bad.size), ok
