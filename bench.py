@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""Headline benchmark: audio samples/s, encode_audio + decode_audio, 1kbps @ 16 kHz, batch 256 x 1 s per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over one batch of synthetic clips already resident in HBM.  With N > 1 every
+rank (one process per GPU) runs its own 256 clips (weak scaling, clips are independent) and the quantiser indices
+and waveforms are all-gathered over RCCL at the end of the step.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+import torch
+
+PEAK_F32_TFLOPS = 157.3  # MI355X fp32 MFMA = fp32 vector peak (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_HBM_GBS = 8000.0    # HBM3E spec
+
+
+def algorithmic_gflop_per_clip_second(mc):
+    """MACs of every conv / linear / attention product of the path for a 1 s clip, as GFLOP."""
+    from l3ac_amd.weights import HEADS, en_decoder_layout, en_encoder_layout, trans_geometry
+    hop, sr = mc.hop_length, 16000
+    t0 = -(-sr // hop) * hop
+    macs = 0.0
+    unit = lambda c, t: t * (7 * c + 8 * c * c)
+    t = t0
+    macs += t * (140 + 1600 + 81 * mc.encoder_dims[0])
+    for i, c in enumerate(mc.encoder_dims):
+        macs += mc.encoder_depths[i] * unit(c, t)
+        if i + 1 < len(mc.encoder_dims):
+            s = mc.compress_rates[i]
+            t //= s
+            macs += t * s * c * mc.encoder_dims[i + 1]
+    macs += t * 3 * mc.encoder_dims[-1] * mc.feature_dim
+    dim = mc.feature_dim
+    dh, inner, ffi = trans_geometry(dim)
+    layer = lambda n: n * (3 * inner * dim + inner * dim + 2 * ffi * dim + ffi * dim) + HEADS * dh * n * (n + 1)
+    frames = t
+    n = frames
+    for prefix, _, depth in en_encoder_layout(mc):
+        macs += depth * layer(n)
+        if prefix == "down_trans.trans":
+            n //= mc.en_coder_compress_rate
+            macs += n * mc.en_coder_compress_rate * dim * dim
+    macs += n * 2 * len(mc.levels) * dim
+    for prefix, _, depth in en_decoder_layout(mc):
+        if prefix == "up_trans.trans":
+            n *= mc.en_coder_compress_rate
+        macs += depth * layer(n)
+    t = frames
+    macs += t * 3 * dim * mc.decoder_dims[0]
+    for i, s in enumerate(mc.decode_rates):
+        c = mc.decoder_dims[i]
+        macs += mc.decoder_depths[i] * unit(c, t) + t * c * mc.decoder_dims[i + 1] + t * (28 + 4 * c)
+        t *= s
+    c = mc.decoder_dims[-1]
+    macs += t * (3 * (7 * c * c + c * c) + 7 * c)
+    return 2.0 * macs / 1e9
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="1kbps")
+    ap.add_argument("--batch", type=int, default=256, help="clips per GPU")
+    ap.add_argument("--seconds", type=float, default=1.0)
+    ap.add_argument("--no-gather", action="store_true", help="skip the RCCL all-gather of outputs (N > 1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    import torch.distributed as dist
+
+    import l3ac_amd
+    from l3ac_amd import _capi
+
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+
+    codec = l3ac_amd.get_model(args.config, synthetic_seed=0)  # identical weights on every rank
+    codec.network.to(device=dev).eval()
+    mc = codec.network.mc
+    samples = int(round(args.seconds * codec.config.sample_rate))
+    b = args.batch
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    audio = ((torch.rand(b, samples, generator=g) * 2 - 1) * 0.5).to(dev)
+    codec.network.context().reserve(b, samples)
+    n_tok = -(-samples // mc.hop_length)
+    gather = world > 1 and not args.no_gather
+    if gather:
+        all_idx = torch.empty((world * b, n_tok), dtype=torch.int32, device=dev)
+        all_wave = torch.empty((world * b, n_tok * mc.hop_length), dtype=torch.float32, device=dev)
+
+    def step():
+        q, ind = codec.encode_audio(audio)
+        wave = codec.decode_audio(q)
+        if gather:  # the only exchange step of the path: outputs to every rank over xGMI
+            dist.all_gather_into_tensor(all_idx, ind["indices"])
+            dist.all_gather_into_tensor(all_wave, wave)
+        return ind, wave
+
+    run = step
+    if args.graph:
+        assert not gather, "--graph is a single-GPU mode"
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            step()
+        torch.cuda.current_stream().wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            captured = step()
+        run = lambda: (graph.replay(), captured)[1]
+
+    for _ in range(args.warmup):
+        run()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ind, wave = run()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * b * samples * args.steps / elapsed
+        gflop_clip = algorithmic_gflop_per_clip_second(mc) * args.seconds
+        # ---- per-kernel roofline: one extra, untimed step with HIP events around every launch ----------
+        with _capi.profile() as prof:
+            codec.decode_audio(codec.encode_audio(audio)[0])
+        kernels = sorted(prof.entries, key=lambda e: -e["ms_total"])
+        total_ms = sum(e["ms_total"] for e in kernels)
+        dom = kernels[0]
+        dom_ms = dom["ms_total"] / dom["launches"]
+        ai = dom["flops"] / max(dom["bytes"], 1.0)
+        if ai > PEAK_F32_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9):
+            roof = dict(bound="mfma", achieved=dom["flops"] / dom["ms_total"] / 1e9, peak=PEAK_F32_TFLOPS, unit="TFLOP/s")
+        else:
+            roof = dict(bound="hbm", achieved=dom["bytes"] / dom["ms_total"] / 1e6, peak=PEAK_HBM_GBS, unit="GB/s")
+        roof.update(frac=roof["achieved"] / roof["peak"], traffic=None, kernel=dom["name"], launches_per_step=dom["launches"],
+                    avg_launch_ms=dom_ms, share_of_step=dom["ms_total"] / total_ms)
+        out = {
+            "metric": "audio samples/sec encode+decode, 1kbps@16kHz, batch 256; indices bit-exact",
+            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config} config, {b} x {args.seconds:g} s 16 kHz clips per GPU, "
+                                   "encode_audio + decode_audio(q_feature)" + (", RCCL all-gather of indices+waveforms" if gather else ""),
+                       "batch_per_gpu": b, "samples_per_clip": samples, "weights": "seeded synthetic (seed 0)",
+                       "hipgraph": bool(args.graph)},
+            "roofline": roof,
+            "e2e": {"algorithmic_gflop_per_step": gflop_clip * b,
+                    "achieved_tflops": gflop_clip * b * world / (ms_per_step * 1e-3) / 1e3,
+                    "frac_of_f32_mfma_peak": gflop_clip * b / (ms_per_step * 1e-3) / 1e3 / PEAK_F32_TFLOPS,
+                    "kernel_ms_sum_profiled": total_ms},
+            "kernels": [{"name": e["name"], "launches": e["launches"], "ms": round(e["ms_total"], 4),
+                         "tflops": round(e["flops"] / e["ms_total"] / 1e9, 2), "gbs": round(e["bytes"] / e["ms_total"] / 1e6, 1)}
+                        for e in kernels],
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(codec, audio, args.cpu_batch, ind)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(codec, audio, cpu_batch, gpu_ind):
+    """The oracle (PyTorch-CPU restatement of the reference path) timed on this box's host cores, rank 0 only,
+    on a bounded sample of the same workload; also reports index agreement of the GPU run on those clips."""
+    import numpy as np
+
+    from l3ac_amd import weights as W
+    from oracle import l3ac_oracle as O
+    from tests.helpers import index_mismatch_report
+
+    mc = codec.network.mc
+    w = W.folded_weights(codec.network.state_dicts())
+    x = audio[:cpu_batch].cpu()
+    taps = {}
+    O.decode_audio(w, mc, O.encode_audio(w, mc, x, taps=taps)[0])  # warm-up
+    iters, t0 = 0, time.perf_counter()
+    while True:
+        q, ind = O.encode_audio(w, mc, x)
+        O.decode_audio(w, mc, q)
+        iters += 1
+        if time.perf_counter() - t0 > 10.0 or iters >= 8:
+            break
+    dt = (time.perf_counter() - t0) / iters
+    n_bad, ok = index_mismatch_report(gpu_ind["indices"][:cpu_batch].cpu().numpy(), ind["indices"].numpy(),
+                                      taps["latents"].numpy(), mc.levels, tau=2e-3)
+    return {"value": cpu_batch * x.shape[1] / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{cpu_batch} of the batch's clips x {iters} iterations of encode_audio+decode_audio "
+                      f"({dt:.2f} s each), torch {torch.__version__} CPU, nproc={os.cpu_count()}",
+            "gpu_index_mismatches_on_sample": int(n_bad), "sample_tokens": int(np.prod(ind["indices"].shape)),
+            "mismatches_are_boundary_flips": bool(ok)}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,172 @@
+/*
+ * l3ac_hip.h — C ABI of the MI355X-native L3AC encode -> quantize -> decode path (libl3ac_hip.so).
+ *
+ * The reference (zhai-lw/L3AC) is pure Python and exposes no FFI; its boundary for this path is the method
+ * surface of l3ac/__init__.py.  Each entry point below names the reference interface it replaces:
+ *
+ *   l3ac_create / l3ac_destroy   <- l3ac.get_model + network.load_model   (l3ac/__init__.py:21-25, :104-106,
+ *                                                                          l3ac/xtract/nn/module.py:43-54)
+ *   l3ac_encode                  <- L3AC.encode_audio                      (l3ac/__init__.py:108-114)
+ *   l3ac_decode                  <- L3AC.decode_audio                      (l3ac/__init__.py:116-121)
+ *   l3ac_fsq_* / l3ac_vq_argmin  <- VQEmbed.forward / to_features          (l3ac/vq/__init__.py:20-30, vq/fsq.py:30-81)
+ *   l3ac_op_*                    <- the individual blocks of modules.py / tconv / local_trans.py, exported so
+ *                                   that every kernel can be parity-tested alone.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative L3AC_E* code otherwise; nothing throws across the ABI;
+ *     l3ac_last_error() returns a human-readable message for the calling thread's last failure.
+ *   - all data pointers are DEVICE pointers (e.g. torch tensor.data_ptr()), contiguous, 16-byte aligned,
+ *     fp32 / int32.  Activations are frame-major: [batch][frame][channel], channel fastest.
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); calls only enqueue
+ *     work on it: no host synchronisation, and no allocation once l3ac_reserve() has sized the workspace,
+ *     so a call sequence can be captured into a hipGraph.
+ *   - one context per device; a context is not thread-safe.
+ */
+#ifndef L3AC_HIP_H
+#define L3AC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define L3AC_ABI_VERSION 1
+#define L3AC_MAX_STAGES 8
+#define L3AC_MAX_LEVELS 8
+
+enum {
+    L3AC_OK = 0,
+    L3AC_EINVAL = -1,    /* bad argument / unsupported geometry */
+    L3AC_EWEIGHT = -2,   /* missing / mis-shaped weight tensor */
+    L3AC_EHIP = -3,      /* HIP runtime error */
+    L3AC_ENOMEM = -4,    /* workspace too small while stream capture forbids growing it */
+};
+
+/* Network geometry: the [network_config] table of the reference's TOML files
+ * (l3ac/codec.py:13-36, l3ac/en_codec.py:9-19). */
+typedef struct l3ac_config {
+    int32_t abi_version;                     /* = L3AC_ABI_VERSION */
+    int32_t feature_dim;
+    int32_t n_enc;                           /* len(encoder_dims) */
+    int32_t enc_dims[L3AC_MAX_STAGES];
+    int32_t enc_depths[L3AC_MAX_STAGES];
+    int32_t compress_rates[L3AC_MAX_STAGES]; /* n_enc - 1 entries */
+    int32_t n_dec;                           /* len(decoder_dims) */
+    int32_t dec_dims[L3AC_MAX_STAGES];
+    int32_t dec_depths[L3AC_MAX_STAGES];
+    int32_t decode_rates[L3AC_MAX_STAGES];   /* n_dec - 1 entries */
+    int32_t n_levels;
+    int32_t levels[L3AC_MAX_LEVELS];         /* vq_config.levels */
+    int32_t en_coder_depth;
+    int32_t en_coder_window_size;
+    int32_t en_coder_compress_rate;
+    int32_t grn_exact;                       /* 0: GRN normaliser taken as exactly 1.0f (true for ||x|| >= 0.25);
+                                                1: evaluate g / (g + eps) per clip (layers.py:112-115) */
+} l3ac_config;
+
+/* One named fp32 host tensor.  Names are the reference's state-dict keys prefixed with the module file name,
+ * weight-norm already folded (".parametrizations.weight.original{0,1}" -> ".weight"), e.g.
+ * "encoder.blocks.1.0.module.pw_conv1.weight". */
+typedef struct l3ac_tensor {
+    const char* name;
+    const float* data;
+    int64_t numel;
+} l3ac_tensor;
+
+typedef struct l3ac_ctx l3ac_ctx;
+
+const char* l3ac_last_error(void);
+int l3ac_abi_version(void);
+
+int l3ac_create(const l3ac_config* cfg, const l3ac_tensor* tensors, int32_t n_tensors, int32_t device,
+                l3ac_ctx** out);
+void l3ac_destroy(l3ac_ctx* ctx);
+
+/* Size the workspace for clips of up to `samples` samples in batches of up to `batch` (allocates; call it
+ * before stream capture).  encode/decode grow the workspace themselves when not capturing. */
+int l3ac_reserve(l3ac_ctx* ctx, int32_t batch, int32_t samples);
+int64_t l3ac_workspace_bytes(const l3ac_ctx* ctx);
+int32_t l3ac_hop_length(const l3ac_ctx* ctx);
+
+/* encode_audio: audio [batch][samples] (row stride `audio_stride` floats) is right-padded with zeros to a
+ * multiple of hop_length (codec.py:79-84); n_tok = ceil(samples / hop).
+ *   q_feature      [batch][n_tok][feature_dim] fp32
+ *   indices        [batch][n_tok]              int32
+ *   level_indices  [batch][n_tok][n_levels]    fp32   (may be NULL) */
+int l3ac_encode(l3ac_ctx* ctx, const float* audio, int32_t batch, int32_t samples, int64_t audio_stride,
+                float* q_feature, int32_t* indices, float* level_indices, void* stream);
+
+/* decode_audio: from q_feature, or — when q_feature is NULL — from indices (vq/__init__.py:20-23).
+ *   audio_out [batch][n_tok * hop_length] fp32, NOT trimmed (the caller slices, example.py:28). */
+int l3ac_decode(l3ac_ctx* ctx, const float* q_feature, const int32_t* indices, int32_t batch, int32_t n_tok,
+                float* audio_out, void* stream);
+
+/* ---- quantiser kernels, context-free --------------------------------------------------------------- */
+
+/* Fused FSQ (vq/__init__.py:25-30 + vq/fsq.py:30-68, eval): x [n][feat] -> q_feature [n][feat], indices [n],
+ * level_indices [n][n_levels] (NULL to skip), latents [n][n_levels] (NULL to skip; test hook).
+ * w_in [n_levels][feat], b_in [n_levels], w_out [feat][n_levels], b_out [feat] are device pointers.
+ * With x == NULL the `latents` buffer is an INPUT (project_in skipped). */
+int l3ac_fsq_forward(const float* x, int64_t n, int32_t feat, const int32_t* levels, int32_t n_levels,
+                     const float* w_in, const float* b_in, const float* w_out, const float* b_out,
+                     float* q_feature, int32_t* indices, float* level_indices, float* latents, void* stream);
+
+/* VQEmbed.to_features (vq/__init__.py:20-23): indices [n] -> q_feature [n][feat]. */
+int l3ac_fsq_decode(const int32_t* indices, int64_t n, int32_t feat, const int32_t* levels, int32_t n_levels,
+                    const float* w_out, const float* b_out, float* q_feature, void* stream);
+
+/* Explicit-codebook nearest neighbour (the search FSQ is the closed form of):
+ * queries [n][dim] (= tanh(latents)), codebook [k][dim] (= indices_to_codes(arange(k)), vq/fsq.py:80-81);
+ * out_idx[i] = argmin_k ||q_i - c_k||^2, lowest k on exact ties.  dim <= 8. */
+int l3ac_vq_argmin(const float* queries, int64_t n, const float* codebook, int32_t k, int32_t dim,
+                   int32_t* out_idx, void* stream);
+
+/* ---- single blocks of a context's network, for per-kernel parity tests ------------------------------ */
+/* `block` is the reference state-dict prefix of the block inside its module file, e.g. "encoder.blocks.1.0.module".
+ * Shapes: x / y are [batch][frames][channels] frame-major. */
+int l3ac_op_first_block(l3ac_ctx* ctx, const float* audio, int32_t batch, int32_t samples, float* y, void* stream);
+int l3ac_op_conv_unit(l3ac_ctx* ctx, const char* block, const float* x, int32_t batch, int32_t frames, float* y,
+                      void* stream);
+int l3ac_op_down_layer(l3ac_ctx* ctx, const char* block, const float* x, int32_t batch, int32_t frames, float* y,
+                       void* stream);
+int l3ac_op_conv_k3(l3ac_ctx* ctx, const char* block, const float* x, int32_t batch, int32_t frames, float* y,
+                    void* stream);
+int l3ac_op_enhance(l3ac_ctx* ctx, const char* block, const float* x, int32_t batch, int32_t frames, float* y,
+                    void* stream);
+int l3ac_op_up_layer(l3ac_ctx* ctx, const char* block, const float* x, int32_t batch, int32_t frames, float* y,
+                     void* stream);
+int l3ac_op_last_block(l3ac_ctx* ctx, const float* x, int32_t batch, int32_t frames, float* audio, void* stream);
+int l3ac_op_local_trans(l3ac_ctx* ctx, const char* block, const float* x, int32_t batch, int32_t frames, float* y,
+                        void* stream);
+/* whole sub-modules */
+int l3ac_op_encoder(l3ac_ctx* ctx, const float* audio, int32_t batch, int32_t samples, float* feature, void* stream);
+int l3ac_op_en_encoder(l3ac_ctx* ctx, const float* feature, int32_t batch, int32_t frames, float* tokens, void* stream);
+int l3ac_op_en_decoder(l3ac_ctx* ctx, const float* tokens, int32_t batch, int32_t n_tok, float* feature, void* stream);
+int l3ac_op_decoder(l3ac_ctx* ctx, const float* feature, int32_t batch, int32_t frames, float* audio, void* stream);
+
+/* ---- per-launch profile (measurement aid; reference has no counterpart) -------------------------------
+ * Between l3ac_profile_begin() and l3ac_profile_end() every kernel launched by the calling thread is bracketed
+ * by HIP events on its own stream.  l3ac_profile_end() synchronises, aggregates per kernel name (launch count,
+ * summed device time, summed algorithmic FLOPs and bytes) and writes at most `cap` entries. */
+typedef struct l3ac_profile_entry {
+    char name[64];
+    int32_t launches;
+    int32_t reserved;
+    double ms_total;
+    double flops;   /* algorithmic floating-point operations of those launches */
+    double bytes;   /* algorithmic HBM bytes of those launches */
+} l3ac_profile_entry;
+int l3ac_profile_begin(void);
+int l3ac_profile_end(l3ac_profile_entry* out, int32_t cap, int32_t* n_out);
+
+/* Generic fp32 MFMA GEMM used by every channel contraction: c[m][n] = a[m][:] . w[n][:] + bias[n].
+ * a [m][k] (row stride lda), w [n][k], k % 4 == 0.  Exported for the kernel micro-benchmark and tests. */
+int l3ac_gemm_f32(const float* a, int64_t lda, const float* w, const float* bias, float* c, int64_t ldc,
+                  int64_t m, int32_t n, int32_t k, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* L3AC_HIP_H */

@@ -1,0 +1,233 @@
+"""l3ac_amd — MI355X-native encode -> quantize -> decode path behind L3AC's Python surface.
+
+Drop-in for the reference package on this path (``import l3ac_amd as l3ac``):
+
+    l3ac.list_models()                      reference l3ac/__init__.py:17-18
+    codec = l3ac.get_model("1kbps")         reference l3ac/__init__.py:21-25
+    codec.config.sample_rate                reference l3ac/__init__.py:54-81
+    codec.network.to(device="cuda"); codec.network.eval()
+    q_feature, indices = codec.encode_audio(audio)          reference l3ac/__init__.py:108-114
+    audio = codec.decode_audio(q_feature)                   reference l3ac/__init__.py:116-121
+    audio = codec.decode_audio(indices=indices["indices"])
+
+All arithmetic runs in hand-written HIP kernels inside libl3ac_hip.so (include/l3ac_hip.h) on gfx950; torch
+supplies device memory and streams only.  There is no CPU path: calling encode/decode with CPU tensors, or
+without the built extension, raises.
+"""
+from __future__ import annotations
+
+import logging
+import math
+from pathlib import Path
+from typing import Optional
+
+import torch
+
+from . import _capi
+from . import weights as _weights
+from .config import CONFIG_DIR, L3ACConfig, ModelConfig, list_models, resolve_config_file
+
+__all__ = ["list_models", "get_model", "get_model_info", "L3AC", "L3ACConfig", "ModelConfig", "Network"]
+__version__ = "0.1.0"
+
+log = logging.getLogger("L3AC")
+
+
+class Network:
+    """Stands where the reference's ``EnCodec`` nn.Module stands (``codec.network``): holds the weights and the
+    per-device HIP context.  Callers only move it (``.to`` / ``.cuda``) and switch it to eval mode."""
+
+    def __init__(self, mc: ModelConfig):
+        mc.check_supported()
+        self.mc = mc
+        self.training = True  # nn.Module default; the reference needs .eval() before inference (vq/fsq.py:31)
+        self.grn_exact = False
+        self._state_dicts = None
+        self._folded = None
+        self._ctx: Optional[_capi.Context] = None
+        self.device = torch.device("cpu")
+
+    # ---- weights ------------------------------------------------------------------------------------
+    def load_state_dicts(self, state_dicts) -> "Network":
+        _weights.check_state_dicts(state_dicts, self.mc)
+        self._state_dicts = state_dicts
+        self._folded = _weights.folded_weights(state_dicts)  # weight-norm folded once
+        if self._ctx is not None:
+            self._drop_ctx()
+            self._make_ctx()
+        return self
+
+    def load_model(self, model_dir=None, model_path=None) -> "Network":
+        """reference xtract/nn/module.py:43-54, but a missing file raises instead of keeping random weights."""
+        model_path = Path(model_path) if model_path is not None else Path(model_dir)
+        return self.load_state_dicts(_weights.load_state_dicts(model_path, self.mc))
+
+    def state_dicts(self):
+        return self._state_dicts
+
+    @property
+    def trainable_modules(self):
+        return {name: self._state_dicts[name] for name in _weights.MODULE_NAMES} if self._state_dicts else {}
+
+    # ---- nn.Module-like surface -----------------------------------------------------------------------
+    def eval(self) -> "Network":
+        self.training = False
+        return self
+
+    def train(self, mode: bool = True) -> "Network":
+        if mode:
+            raise NotImplementedError("l3ac_amd implements the inference path only (FSQ noise / drop-path are training-side)")
+        return self.eval()
+
+    def to(self, device=None, dtype=None, **_ignored) -> "Network":
+        if dtype is not None and dtype != torch.float32:
+            raise NotImplementedError("the path computes in fp32, like the reference")
+        if device is None:
+            return self
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        if device != self.device:
+            self._drop_ctx()
+            self.device = device
+            if device.type == "cuda":
+                self._make_ctx()
+        return self
+
+    def cuda(self, device=None) -> "Network":
+        return self.to(device="cuda" if device is None else device)
+
+    def cpu(self) -> "Network":
+        return self.to(device="cpu")
+
+    def _make_ctx(self):
+        if self._folded is None:
+            raise RuntimeError("no weights loaded (get_model / load_state_dicts first)")
+        self._ctx = _capi.Context(self.mc, self._folded, self.device.index, grn_exact=self.grn_exact)
+
+    def _drop_ctx(self):
+        if self._ctx is not None:
+            self._ctx.close()
+            self._ctx = None
+
+    def context(self) -> _capi.Context:
+        if self._ctx is None:
+            raise RuntimeError(
+                "network is not on a GPU: call codec.network.to(device='cuda') first "
+                "(l3ac_amd has no CPU path; the reference's PyTorch-CPU path is not part of this package)")
+        return self._ctx
+
+    # ---- reference Codec.preprocess (codec.py:79-84): kept for callers that use it -----------------
+    def preprocess(self, audio_data: torch.Tensor):
+        length = audio_data.shape[-1]
+        hop = self.mc.hop_length
+        pad_len = math.ceil(length / hop) * hop - length
+        return torch.nn.functional.pad(audio_data, (0, pad_len)), length
+
+
+class L3AC:
+    """reference l3ac/__init__.py:84-121."""
+
+    def __init__(self, config: L3ACConfig):
+        self.config = config
+        self.network = Network(config.network_config)
+
+    def load_pretrained(self):
+        """reference :104-106 minus the HTTP download (no network here): weights must already be on disk."""
+        if not self.config.model_path.exists():
+            raise FileNotFoundError(
+                f"no weights at {self.config.model_path}: download "
+                f"{self.config.weight_url.format('{encoder,quantizer,decoder,en_encoder,en_decoder}')} there, "
+                "pass model_dir=..., or use get_model(..., synthetic_seed=N)")
+        self.network.load_model(model_path=self.config.model_path)
+
+    # ---- hot path -------------------------------------------------------------------------------------
+    def _check_input(self, t: torch.Tensor, what: str):
+        if self.network.training:
+            raise RuntimeError("call codec.network.eval() first: the training-mode quantiser injects noise "
+                               "(reference vq/fsq.py:31,40-43), which this inference path does not implement")
+        ctx = self.network.context()
+        if not t.is_cuda or t.device != self.network.device:
+            raise RuntimeError(f"{what} is on {t.device} but the network is on {self.network.device}")
+        return ctx
+
+    @torch.no_grad()
+    def encode_audio(self, audio_data: torch.Tensor):
+        """audio (B, T) fp32 -> (q_feature (B, T_tok, C) fp32, {"indices": int32 (B, T_tok),
+        "level_indices": fp32 (B, T_tok, D)}); the zero right-padding to a hop multiple happens in-kernel."""
+        ctx = self._check_input(audio_data, "audio_data")
+        if audio_data.dim() != 2:
+            raise ValueError(f"audio_data must be (batch, samples), got {tuple(audio_data.shape)}")
+        audio = audio_data.to(torch.float32)
+        if audio.stride(-1) != 1 or audio.stride(0) % 4 != 0 or audio.data_ptr() % 16 != 0:
+            audio = audio.contiguous()
+        b, t = audio.shape
+        if t == 0 or b == 0:
+            raise ValueError("empty audio")
+        mc = self.network.mc
+        n_tok = math.ceil(t / mc.hop_length)
+        dev = audio.device
+        q_feature = torch.empty((b, n_tok, mc.feature_dim), dtype=torch.float32, device=dev)
+        indices = torch.empty((b, n_tok), dtype=torch.int32, device=dev)
+        level_indices = torch.empty((b, n_tok, len(mc.levels)), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _capi.check(ctx.lib.l3ac_encode(ctx.handle, audio.data_ptr(), b, t, audio.stride(0) if b > 1 else t,
+                                            q_feature.data_ptr(), indices.data_ptr(), level_indices.data_ptr(), stream))
+        return q_feature, {"indices": indices, "level_indices": level_indices}
+
+    @torch.no_grad()
+    def decode_audio(self, audio_feature: torch.Tensor = None, indices: torch.Tensor = None) -> torch.Tensor:
+        """(B, T_tok, C) features, or int indices (B, T_tok) -> audio (B, T_tok * hop), not trimmed."""
+        src = audio_feature if audio_feature is not None else indices
+        if src is None:
+            raise ValueError("decode_audio needs audio_feature or indices")
+        ctx = self._check_input(src, "decode input")
+        mc = self.network.mc
+        if audio_feature is not None:
+            if audio_feature.dim() != 3 or audio_feature.shape[-1] != mc.feature_dim:
+                raise ValueError(f"audio_feature must be (batch, tokens, {mc.feature_dim})")
+            feat = audio_feature.to(torch.float32).contiguous()
+            b, n_tok = feat.shape[:2]
+            f_ptr, i_ptr, keep = feat.data_ptr(), None, feat
+        else:
+            if indices.dim() != 2:
+                raise ValueError("indices must be (batch, tokens)")
+            idx = indices.to(torch.int32).contiguous()
+            b, n_tok = idx.shape
+            f_ptr, i_ptr, keep = None, idx.data_ptr(), idx
+        audio = torch.empty((b, n_tok * mc.hop_length), dtype=torch.float32, device=src.device)
+        with torch.cuda.device(src.device):
+            stream = torch.cuda.current_stream(src.device).cuda_stream
+            _capi.check(ctx.lib.l3ac_decode(ctx.handle, f_ptr, i_ptr, b, n_tok, audio.data_ptr(), stream))
+        del keep
+        return audio
+
+
+def get_model(config_name, model_dir=None, synthetic_seed: Optional[int] = None) -> L3AC:
+    """reference l3ac/__init__.py:21-25.  ``config_name`` is a shipped model name (``list_models()``) or a path
+    to a TOML file of the same schema.  Weights come from ``{model_dir}/{name}.{version}/*.pt`` (default
+    ``~/.cache/l3ac``, the reference's cache), or — with ``synthetic_seed`` — from the seeded generator."""
+    overrides = {} if model_dir is None else {"model_dir": Path(model_dir)}
+    codec = L3AC(L3ACConfig(config_file=resolve_config_file(config_name), **overrides))
+    if synthetic_seed is not None:
+        codec.network.load_state_dicts(_weights.synthetic_state_dicts(codec.config.network_config, seed=synthetic_seed))
+    else:
+        codec.load_pretrained()
+    return codec
+
+
+def get_model_info(model, sample_rate: int = 16000) -> dict:
+    """Geometry facts of reference l3ac/__init__.py:28-51 (the ptflops MAC count is out of scope)."""
+    mc = model.mc if hasattr(model, "mc") else model.network.mc
+    compress_rate = mc.hop_length
+    codebook_size = mc.codebook_size
+    frame_rate = sample_rate / compress_rate
+    params = sum(int(math.prod(shape)) for m in _weights.MODULE_NAMES for _, shape in _weights.raw_keys(mc, m))
+    return {
+        "params": params,
+        "codebook_size": codebook_size,
+        "frame_rate": frame_rate,
+        "bps": frame_rate * math.log2(codebook_size),
+        "receptive_field": mc.en_coder_window_size / frame_rate,
+    }

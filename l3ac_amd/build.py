@@ -1,0 +1,79 @@
+"""Builds libl3ac_hip.so (the C-ABI extension, include/l3ac_hip.h) in-tree with hipcc for gfx950.
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the resulting ``.so`` is git-ignored
+but ships to the GPU box with the repo snapshot.  Usage: ``python -m l3ac_amd.build [--force]``.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+REPO = PKG.parent
+CSRC = PKG / "csrc"
+OBJ_DIR = CSRC / "build"
+LIB_PATH = PKG / "libl3ac_hip.so"
+ARCH = "gfx950"
+
+SOURCES = [
+    "capi.hip",
+    "network.hip",
+    "kernels/gemm_f32.hip",
+    "kernels/rows.hip",
+    "kernels/first_block.hip",
+    "kernels/enhance.hip",
+    "kernels/attention.hip",
+    "kernels/fsq.hip",
+]
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(exe).exists():
+        raise RuntimeError("hipcc not found: the HIP extension cannot be built")
+    return exe
+
+
+def _newest_header() -> float:
+    hdrs = list(CSRC.glob("*.hpp")) + list((REPO / "include").glob("*.h"))
+    return max(h.stat().st_mtime for h in hdrs)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> Path:
+    OBJ_DIR.mkdir(parents=True, exist_ok=True)
+    hipcc = _hipcc()
+    flags = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-Wall", "-Wno-unused-function",
+             f"-I{REPO / 'include'}", f"-I{CSRC}"]
+    hdr_time = _newest_header()
+    jobs = []
+    objs = []
+    for src in SOURCES:
+        s = CSRC / src
+        o = OBJ_DIR / (src.replace("/", "_") + ".o")
+        objs.append(o)
+        if force or not o.exists() or o.stat().st_mtime < max(s.stat().st_mtime, hdr_time):
+            jobs.append([hipcc, *flags, "-c", str(s), "-o", str(o)])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+        if verbose and r.stderr.strip():
+            print(r.stderr, file=sys.stderr)
+
+    with ThreadPoolExecutor(max_workers=min(4, os.cpu_count() or 1)) as pool:
+        list(pool.map(run, jobs))
+    if jobs or not LIB_PATH.exists():
+        run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(LIB_PATH), *map(str, objs)])
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    path = build_library(force="--force" in sys.argv, verbose=True)
+    print(f"built {path} ({path.stat().st_size / 1e6:.1f} MB)")

@@ -1,0 +1,369 @@
+// extern "C" entry points of libl3ac_hip.so (include/l3ac_hip.h).
+#include <cstdarg>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "network.hpp"
+
+static thread_local std::string g_last_error;
+
+void l3ac_set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+static thread_local Profiler* g_profiler = nullptr;
+Profiler* l3ac_current_profiler() { return g_profiler; }
+void l3ac_set_current_profiler(Profiler* p) { g_profiler = p; }
+
+namespace {
+
+struct DeviceGuard {  // make the context's device current for the duration of a call
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+        if (prev == dev) prev = -1;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+#define L3AC_ENTER(ctx)                                     \
+    L3AC_REQUIRE((ctx) != nullptr, "null context");         \
+    DeviceGuard guard_((ctx)->device);                      \
+    L3AC_REQUIRE(guard_.ok, "cannot select device %d", (ctx)->device)
+
+template <class Map>
+auto lookup(const Map& m, const char* name, const char* kind) -> decltype(m.begin()->second) {
+    if (!name) {
+        l3ac_set_error("null block name");
+        return nullptr;
+    }
+    auto it = m.find(name);
+    if (it == m.end()) {
+        l3ac_set_error("no %s block named '%s'", kind, name);
+        return nullptr;
+    }
+    return it->second;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* l3ac_last_error(void) { return g_last_error.c_str(); }
+int l3ac_abi_version(void) { return L3AC_ABI_VERSION; }
+
+int l3ac_create(const l3ac_config* cfg, const l3ac_tensor* tensors, int32_t n_tensors, int32_t device, l3ac_ctx** out) {
+    L3AC_REQUIRE(cfg && tensors && out && n_tensors > 0, "l3ac_create: null argument");
+    *out = nullptr;
+    int n_dev = 0;
+    L3AC_HIP_CHECK(hipGetDeviceCount(&n_dev));
+    L3AC_REQUIRE(device >= 0 && device < n_dev, "l3ac_create: device %d out of range (%d visible)", device, n_dev);
+    l3ac_ctx* ctx = new (std::nothrow) l3ac_ctx();
+    L3AC_REQUIRE(ctx, "out of host memory");
+    ctx->cfg = *cfg;
+    ctx->device = device;
+    DeviceGuard guard(device);
+    int rc = guard.ok ? network_build(ctx, tensors, n_tensors) : L3AC_EHIP;
+    if (rc != L3AC_OK) {
+        network_free(ctx);
+        delete ctx;
+        return rc;
+    }
+    *out = ctx;
+    return L3AC_OK;
+}
+
+void l3ac_destroy(l3ac_ctx* ctx) {
+    if (!ctx) return;
+    DeviceGuard guard(ctx->device);
+    (void)hipDeviceSynchronize();
+    network_free(ctx);
+    delete ctx;
+}
+
+int l3ac_reserve(l3ac_ctx* ctx, int32_t batch, int32_t samples) {
+    L3AC_ENTER(ctx);
+    L3AC_REQUIRE(batch > 0 && samples > 0, "l3ac_reserve: bad shape");
+    return workspace_ensure_clip(ctx, batch, samples, nullptr);
+}
+
+int64_t l3ac_workspace_bytes(const l3ac_ctx* ctx) { return ctx ? (int64_t)ctx->ws.bytes() : 0; }
+int32_t l3ac_hop_length(const l3ac_ctx* ctx) { return ctx ? ctx->hop : 0; }
+
+int l3ac_encode(l3ac_ctx* ctx, const float* audio, int32_t batch, int32_t samples, int64_t audio_stride,
+                float* q_feature, int32_t* indices, float* level_indices, void* stream) {
+    L3AC_ENTER(ctx);
+    L3AC_REQUIRE(audio && q_feature && indices, "l3ac_encode: null buffer");
+    L3AC_REQUIRE(batch > 0 && batch <= 65535 && samples > 0 && audio_stride >= samples, "l3ac_encode: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    L3AC_TRY(workspace_ensure_clip(ctx, batch, samples, s));
+    const int frames = (int)round_up64(samples, ctx->hop);  // Codec.preprocess (codec.py:79-84)
+    float* cur = ctx->ws.x0;
+    float* alt = ctx->ws.x1;
+    L3AC_TRY(run_encoder(ctx, s, audio, audio_stride, batch, samples, frames, &cur, &alt));
+    int n_tok = 0;
+    L3AC_TRY(run_en_encoder(ctx, s, batch, frames / ctx->enc_rate, &cur, &alt, &n_tok));
+    FsqArgs f{};
+    f.x = cur; f.n = (int64_t)batch * n_tok; f.feat = ctx->cfg.feature_dim; f.n_levels = ctx->cfg.n_levels;
+    for (int d = 0; d < f.n_levels; ++d) f.levels[d] = ctx->cfg.levels[d];
+    f.w_in = ctx->q_win; f.b_in = ctx->q_bin; f.w_out = ctx->q_wout; f.b_out = ctx->q_bout;
+    f.q_feature = q_feature; f.indices = indices; f.level_indices = level_indices;
+    return launch_fsq(s, f);
+}
+
+int l3ac_decode(l3ac_ctx* ctx, const float* q_feature, const int32_t* indices, int32_t batch, int32_t n_tok,
+                float* audio_out, void* stream) {
+    L3AC_ENTER(ctx);
+    L3AC_REQUIRE((q_feature || indices) && audio_out, "l3ac_decode: null buffer");
+    L3AC_REQUIRE(batch > 0 && batch <= 65535 && n_tok > 0, "l3ac_decode: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    L3AC_TRY(workspace_ensure_clip(ctx, batch, n_tok * ctx->hop, s));
+    float* cur = ctx->ws.x0;
+    float* alt = ctx->ws.x1;
+    const int64_t n = (int64_t)batch * n_tok;
+    if (q_feature) {
+        L3AC_HIP_CHECK(hipMemcpyAsync(cur, q_feature, (size_t)n * ctx->cfg.feature_dim * sizeof(float), hipMemcpyDeviceToDevice, s));
+    } else {  // VQEmbed.to_features (vq/__init__.py:20-23)
+        FsqArgs f{};
+        f.idx_in = indices; f.n = n; f.feat = ctx->cfg.feature_dim; f.n_levels = ctx->cfg.n_levels;
+        for (int d = 0; d < f.n_levels; ++d) f.levels[d] = ctx->cfg.levels[d];
+        f.w_out = ctx->q_wout; f.b_out = ctx->q_bout; f.q_feature = cur;
+        L3AC_TRY(launch_fsq(s, f));
+    }
+    int frames = 0;
+    L3AC_TRY(run_en_decoder(ctx, s, batch, n_tok, &cur, &alt, &frames));
+    return run_decoder(ctx, s, batch, frames, &cur, &alt, audio_out);
+}
+
+// ---- quantiser kernels --------------------------------------------------------------------------------
+int l3ac_fsq_forward(const float* x, int64_t n, int32_t feat, const int32_t* levels, int32_t n_levels,
+                     const float* w_in, const float* b_in, const float* w_out, const float* b_out, float* q_feature,
+                     int32_t* indices, float* level_indices, float* latents, void* stream) {
+    L3AC_REQUIRE(levels && n_levels >= 1 && n_levels <= L3AC_MAX_LEVELS, "fsq: bad levels");
+    FsqArgs f{};
+    f.x = x; f.n = n; f.feat = feat; f.n_levels = n_levels;
+    for (int d = 0; d < n_levels; ++d) f.levels[d] = levels[d];
+    f.w_in = w_in; f.b_in = b_in; f.w_out = w_out; f.b_out = b_out;
+    f.q_feature = q_feature; f.indices = indices; f.level_indices = level_indices; f.latents = latents;
+    return launch_fsq((hipStream_t)stream, f);
+}
+
+int l3ac_fsq_decode(const int32_t* indices, int64_t n, int32_t feat, const int32_t* levels, int32_t n_levels,
+                    const float* w_out, const float* b_out, float* q_feature, void* stream) {
+    L3AC_REQUIRE(indices && levels && n_levels >= 1 && n_levels <= L3AC_MAX_LEVELS, "fsq_decode: bad arguments");
+    FsqArgs f{};
+    f.idx_in = indices; f.n = n; f.feat = feat; f.n_levels = n_levels;
+    for (int d = 0; d < n_levels; ++d) f.levels[d] = levels[d];
+    f.w_out = w_out; f.b_out = b_out; f.q_feature = q_feature;
+    return launch_fsq((hipStream_t)stream, f);
+}
+
+int l3ac_vq_argmin(const float* queries, int64_t n, const float* codebook, int32_t k, int32_t dim, int32_t* out_idx,
+                   void* stream) {
+    L3AC_REQUIRE(queries && codebook && out_idx, "vq_argmin: null buffer");
+    if (n == 0) return L3AC_OK;
+    // enough codebook slices to fill the chip: blocks = ceil(n / 256) * parts >= ~1024
+    const int64_t qblocks = ceil_div64(n, 256);
+    int parts = (int)ceil_div64(1024, qblocks);
+    const int shards = (int)ceil_div64(k, 2048);
+    if (parts > shards) parts = shards;
+    if (parts < 1) parts = 1;
+    hipStream_t s = (hipStream_t)stream;
+    float* part_dist = nullptr;
+    L3AC_HIP_CHECK(hipMallocAsync((void**)&part_dist, (size_t)parts * n * 2 * sizeof(float), s));
+    int32_t* part_idx = reinterpret_cast<int32_t*>(part_dist + (size_t)parts * n);
+    int rc = launch_vq_argmin_parts(s, queries, n, codebook, k, dim, parts, part_dist, part_idx, out_idx);
+    (void)hipFreeAsync(part_dist, s);
+    return rc;
+}
+
+// ---- per-block parity entry points --------------------------------------------------------------------
+int l3ac_op_first_block(l3ac_ctx* ctx, const float* audio, int32_t batch, int32_t samples, float* y, void* stream) {
+    L3AC_ENTER(ctx);
+    return launch_first_block((hipStream_t)stream, ctx->first, audio, samples, batch, samples, samples, y);
+}
+
+#define L3AC_OP_SCRATCH(c_max)                                                                                    \
+    L3AC_TRY(workspace_ensure(ctx, (size_t)batch * frames * (c_max), (size_t)batch * frames * (c_max),           \
+                              (size_t)batch * frames * 4 * (c_max), (size_t)batch * frames * 4, (size_t)batch,   \
+                              (hipStream_t)stream))
+
+int l3ac_op_conv_unit(l3ac_ctx* ctx, const char* block, const float* x, int32_t batch, int32_t frames, float* y,
+                      void* stream) {
+    L3AC_ENTER(ctx);
+    const ConvUnitW* w = lookup(ctx->by_unit, block, "ConvUnit");
+    if (!w) return L3AC_EINVAL;
+    L3AC_OP_SCRATCH(w->c);
+    return run_conv_unit(ctx, (hipStream_t)stream, *w, x, y, batch, frames);
+}
+
+int l3ac_op_down_layer(l3ac_ctx* ctx, const char* block, const float* x, int32_t batch, int32_t frames, float* y,
+                       void* stream) {
+    L3AC_ENTER(ctx);
+    const DownW* w = lookup(ctx->by_down, block, "down-layer");
+    if (!w) return L3AC_EINVAL;
+    return run_down(ctx, (hipStream_t)stream, *w, x, y, batch, frames);
+}
+
+int l3ac_op_conv_k3(l3ac_ctx* ctx, const char* block, const float* x, int32_t batch, int32_t frames, float* y,
+                    void* stream) {
+    L3AC_ENTER(ctx);
+    const ConvK3W* w = lookup(ctx->by_k3, block, "Conv1d(k3)");
+    if (!w) return L3AC_EINVAL;
+    return run_conv_k3(ctx, (hipStream_t)stream, *w, x, y, batch, frames);
+}
+
+int l3ac_op_enhance(l3ac_ctx* ctx, const char* block, const float* x, int32_t batch, int32_t frames, float* y,
+                    void* stream) {
+    L3AC_ENTER(ctx);
+    const EnhW* w = lookup(ctx->by_enh, block, "EnhanceBlock");
+    if (!w) return L3AC_EINVAL;
+    L3AC_OP_SCRATCH(w->c);
+    return run_enhance(ctx, (hipStream_t)stream, *w, x, y, batch, frames);
+}
+
+int l3ac_op_up_layer(l3ac_ctx* ctx, const char* block, const float* x, int32_t batch, int32_t frames, float* y,
+                     void* stream) {
+    L3AC_ENTER(ctx);
+    const UpW* w = lookup(ctx->by_up, block, "up-layer");
+    if (!w) return L3AC_EINVAL;
+    L3AC_OP_SCRATCH(w->cout);
+    return run_up(ctx, (hipStream_t)stream, *w, x, ctx->ws.a, y, batch, frames);
+}
+
+int l3ac_op_last_block(l3ac_ctx* ctx, const float* x, int32_t batch, int32_t frames, float* audio, void* stream) {
+    L3AC_ENTER(ctx);
+    const int c = ctx->head.c;
+    L3AC_OP_SCRATCH(c);
+    hipStream_t s = (hipStream_t)stream;
+    L3AC_HIP_CHECK(hipMemcpyAsync(ctx->ws.x0, x, (size_t)batch * frames * c * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return run_last_block(ctx, s, ctx->ws.x0, audio, batch, frames);
+}
+
+int l3ac_op_local_trans(l3ac_ctx* ctx, const char* block, const float* x, int32_t batch, int32_t frames, float* y,
+                        void* stream) {
+    L3AC_ENTER(ctx);
+    const LocalTransW* w = lookup(ctx->by_trans, block, "LocalTrans");
+    if (!w) return L3AC_EINVAL;
+    const int dim = ctx->cfg.feature_dim;
+    const size_t rows = (size_t)batch * frames;
+    const size_t cols = (size_t)std::max(std::max(3 * ctx->inner, ctx->ff_n), 4 * dim);
+    hipStream_t s = (hipStream_t)stream;
+    L3AC_TRY(workspace_ensure(ctx, rows * dim, rows * std::max(ctx->inner, dim), rows * cols, 0, (size_t)batch, s));
+    if (y != x) L3AC_HIP_CHECK(hipMemcpyAsync(y, x, rows * dim * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return run_local_trans(ctx, s, *w, y, batch, frames);
+}
+
+int l3ac_op_encoder(l3ac_ctx* ctx, const float* audio, int32_t batch, int32_t samples, float* feature, void* stream) {
+    L3AC_ENTER(ctx);
+    L3AC_REQUIRE(samples % ctx->enc_rate == 0, "op_encoder: samples must be a multiple of prod(compress_rates)");
+    hipStream_t s = (hipStream_t)stream;
+    L3AC_TRY(workspace_ensure_clip(ctx, batch, samples, s));
+    float* cur = ctx->ws.x0;
+    float* alt = ctx->ws.x1;
+    L3AC_TRY(run_encoder(ctx, s, audio, samples, batch, samples, samples, &cur, &alt));
+    const size_t n = (size_t)batch * (samples / ctx->enc_rate) * ctx->cfg.feature_dim;
+    L3AC_HIP_CHECK(hipMemcpyAsync(feature, cur, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return L3AC_OK;
+}
+
+int l3ac_op_en_encoder(l3ac_ctx* ctx, const float* feature, int32_t batch, int32_t frames, float* tokens, void* stream) {
+    L3AC_ENTER(ctx);
+    hipStream_t s = (hipStream_t)stream;
+    L3AC_TRY(workspace_ensure_clip(ctx, batch, frames * ctx->enc_rate, s));
+    float* cur = ctx->ws.x0;
+    float* alt = ctx->ws.x1;
+    const size_t n_in = (size_t)batch * frames * ctx->cfg.feature_dim;
+    L3AC_HIP_CHECK(hipMemcpyAsync(cur, feature, n_in * sizeof(float), hipMemcpyDeviceToDevice, s));
+    int n_tok = 0;
+    L3AC_TRY(run_en_encoder(ctx, s, batch, frames, &cur, &alt, &n_tok));
+    L3AC_HIP_CHECK(hipMemcpyAsync(tokens, cur, (size_t)batch * n_tok * ctx->cfg.feature_dim * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return L3AC_OK;
+}
+
+int l3ac_op_en_decoder(l3ac_ctx* ctx, const float* tokens, int32_t batch, int32_t n_tok, float* feature, void* stream) {
+    L3AC_ENTER(ctx);
+    hipStream_t s = (hipStream_t)stream;
+    L3AC_TRY(workspace_ensure_clip(ctx, batch, n_tok * ctx->hop, s));
+    float* cur = ctx->ws.x0;
+    float* alt = ctx->ws.x1;
+    L3AC_HIP_CHECK(hipMemcpyAsync(cur, tokens, (size_t)batch * n_tok * ctx->cfg.feature_dim * sizeof(float), hipMemcpyDeviceToDevice, s));
+    int frames = 0;
+    L3AC_TRY(run_en_decoder(ctx, s, batch, n_tok, &cur, &alt, &frames));
+    L3AC_HIP_CHECK(hipMemcpyAsync(feature, cur, (size_t)batch * frames * ctx->cfg.feature_dim * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return L3AC_OK;
+}
+
+int l3ac_op_decoder(l3ac_ctx* ctx, const float* feature, int32_t batch, int32_t frames, float* audio, void* stream) {
+    L3AC_ENTER(ctx);
+    hipStream_t s = (hipStream_t)stream;
+    L3AC_TRY(workspace_ensure_clip(ctx, batch, frames * ctx->enc_rate, s));
+    float* cur = ctx->ws.x0;
+    float* alt = ctx->ws.x1;
+    L3AC_HIP_CHECK(hipMemcpyAsync(cur, feature, (size_t)batch * frames * ctx->cfg.feature_dim * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return run_decoder(ctx, s, batch, frames, &cur, &alt, audio);
+}
+
+int l3ac_profile_begin(void) {
+    L3AC_REQUIRE(g_profiler == nullptr, "profile already active on this thread");
+    g_profiler = new (std::nothrow) Profiler();
+    L3AC_REQUIRE(g_profiler, "out of host memory");
+    return L3AC_OK;
+}
+
+int l3ac_profile_end(l3ac_profile_entry* out, int32_t cap, int32_t* n_out) {
+    L3AC_REQUIRE(g_profiler != nullptr, "no active profile on this thread");
+    Profiler* p = g_profiler;
+    g_profiler = nullptr;
+    int n = 0;
+    int rc = L3AC_OK;
+    for (ProfRecord& r : p->records) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.stop) != hipSuccess || hipEventElapsedTime(&ms, r.start, r.stop) != hipSuccess) {
+            l3ac_set_error("profile: event query failed for %s", r.name);
+            rc = L3AC_EHIP;
+        }
+        (void)hipEventDestroy(r.start);
+        (void)hipEventDestroy(r.stop);
+        if (!out || rc != L3AC_OK) continue;
+        int slot = -1;
+        for (int i = 0; i < n; ++i)
+            if (std::strncmp(out[i].name, r.name, sizeof(out[i].name)) == 0) slot = i;
+        if (slot < 0) {
+            if (n >= cap) continue;
+            slot = n++;
+            std::memset(&out[slot], 0, sizeof(out[slot]));
+            std::strncpy(out[slot].name, r.name, sizeof(out[slot].name) - 1);
+        }
+        out[slot].launches += 1;
+        out[slot].ms_total += ms;
+        out[slot].flops += r.flops;
+        out[slot].bytes += r.bytes;
+    }
+    if (p->failed && rc == L3AC_OK) {
+        l3ac_set_error("profile: event creation failed");
+        rc = L3AC_EHIP;
+    }
+    delete p;
+    if (n_out) *n_out = n;
+    return rc;
+}
+
+int l3ac_gemm_f32(const float* a, int64_t lda, const float* w, const float* bias, float* c, int64_t ldc, int64_t m,
+                  int32_t n, int32_t k, void* stream) {
+    GemmArgs g{};
+    g.a = a; g.lda = lda; g.w = w; g.ldw = k; g.c = c; g.ldc = ldc; g.m = m; g.n = n; g.k = k; g.bias = bias; g.epi = EPI_BIAS;
+    return launch_gemm((hipStream_t)stream, g);
+}
+
+}  // extern "C"

@@ -1,0 +1,81 @@
+// Shared host-side helpers of libl3ac_hip.so (error plumbing, launch checks).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "l3ac_hip.h"
+
+void l3ac_set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+
+#define L3AC_HIP_CHECK(expr)                                                                             \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess) {                                                                          \
+            l3ac_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);   \
+            return L3AC_EHIP;                                                                            \
+        }                                                                                                \
+    } while (0)
+
+#define L3AC_LAUNCH_CHECK() L3AC_HIP_CHECK(hipGetLastError())
+
+#define L3AC_REQUIRE(cond, ...)            \
+    do {                                   \
+        if (!(cond)) {                     \
+            l3ac_set_error(__VA_ARGS__);   \
+            return L3AC_EINVAL;            \
+        }                                  \
+    } while (0)
+
+#define L3AC_TRY(expr)             \
+    do {                           \
+        int rc_ = (expr);          \
+        if (rc_ != L3AC_OK) return rc_; \
+    } while (0)
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int64_t round_up64(int64_t a, int64_t b) { return ceil_div64(a, b) * b; }
+
+// ---------------------------------------------------------------------------------------------------------
+// Per-launch profiler: when a thread has an active Profiler, every kernel launch made through L3AC_PROFILED is
+// bracketed by HIP events recorded on the launch stream (so the durations are the kernels' own, measured where
+// they run), tagged with the algorithmic FLOPs / bytes of that launch.  Off by default: zero overhead.
+// ---------------------------------------------------------------------------------------------------------
+#include <string>
+#include <vector>
+
+struct ProfRecord {
+    const char* name;
+    hipEvent_t start, stop;
+    double flops, bytes;
+};
+struct Profiler {
+    std::vector<ProfRecord> records;
+    bool failed = false;
+};
+Profiler* l3ac_current_profiler();
+void l3ac_set_current_profiler(Profiler* p);
+
+struct ProfScope {
+    Profiler* prof;
+    hipStream_t stream;
+    size_t slot = 0;
+    ProfScope(hipStream_t s, const char* name, double flops, double bytes) : prof(l3ac_current_profiler()), stream(s) {
+        if (!prof) return;
+        ProfRecord r{name, nullptr, nullptr, flops, bytes};
+        if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) {
+            prof->failed = true;
+            prof = nullptr;
+            return;
+        }
+        (void)hipEventRecord(r.start, stream);
+        slot = prof->records.size();
+        prof->records.push_back(r);
+    }
+    ~ProfScope() {
+        if (prof) (void)hipEventRecord(prof->records[slot].stop, stream);
+    }
+};

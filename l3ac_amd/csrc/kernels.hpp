@@ -1,0 +1,136 @@
+// Launch API of the HIP kernels (one .hip file per kernel family under kernels/).
+// All pointers are device pointers; activations are frame-major [batch][frame][channel].
+#pragma once
+
+#include "common.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// fp32 MFMA GEMM:  c[m][n] = epilogue( sum_k A(m,k) * w[n][k] )
+// ------------------------------------------------------------------------------------------------
+enum GemmEpilogue : int {
+    EPI_BIAS = 0,       // acc + bias[n]                               (bias may be null)
+    EPI_BIAS_RES = 1,   // res[m][n] + (acc + bias[n])                 ConvUnit / LegacyUnit residual, attention/ff residual
+    EPI_SNAKE = 2,      // snake(acc + bias[n], alpha[n])              LegacyUnit inner activation
+    EPI_SNAKE_GRN = 3,  // s = snake(acc + bias); gamma*s + beta + s   ConvUnit pw_conv1 -> snake -> GRN (normaliser == 1)
+    EPI_GEGLU = 4,      // value/gate column tiles interleaved: out[m][j] = v * gelu(g)   (FeedForward)
+};
+
+struct GemmArgs {
+    // A operand.  taps == 1: plain rows, a[m * lda + k].  taps > 1: implicit 1-D convolution over the frames of
+    // one clip: k = tap * cin + c reads a[(b*frames + t + (tap - taps/2) * dil) * lda + c], zero outside the clip.
+    const float* a = nullptr;
+    int64_t lda = 0;
+    int taps = 1, dil = 1, cin = 0;
+    int64_t frames = 0;
+    // W operand [n][k] (row stride ldw), output c [m][ldc]
+    const float* w = nullptr;
+    int64_t ldw = 0;
+    float* c = nullptr;
+    int64_t ldc = 0;
+    int64_t m = 0;
+    int n = 0, k = 0;
+    // epilogue
+    int epi = EPI_BIAS;
+    const float* bias = nullptr;
+    const float* res = nullptr;
+    int64_t ldres = 0;
+    const float* alpha = nullptr;      // snake alpha[n]
+    const float* inv_alpha = nullptr;  // 1 / (alpha[n] + 1e-8)
+    const float* gamma = nullptr;      // GRN
+    const float* beta = nullptr;
+    int n_out = 0;                     // EPI_GEGLU: number of valid output columns (ff inner)
+};
+int launch_gemm(hipStream_t s, const GemmArgs& g);
+
+// ------------------------------------------------------------------------------------------------
+// row kernels: one output row = one frame (all channels), optional per-row normalisation
+// ------------------------------------------------------------------------------------------------
+enum RowSource : int {
+    SRC_PLAIN = 0,    // y = x
+    SRC_DWCONV7 = 1,  // depth-wise conv k7 pad 3 along frames (ConvUnit.dw_conv)
+    SRC_LERP = 2,     // linear upsample x scale, align_corners=False (nn.Upsample)
+    SRC_GATE = 3,     // EnhanceBlock: x + (merge(instnorm(yi))) * x
+};
+enum RowNorm : int {
+    NORM_NONE = 0,
+    NORM_LN = 1,  // F.layer_norm over channels: (x - mu) * rsqrt(var + eps) * w + b
+    NORM_CN = 2,  // channel_norm channels_first: (x - mu) / sqrt(var + eps) * w + b
+};
+struct RowArgs {
+    const float* x = nullptr;
+    float* y = nullptr;
+    int64_t batch = 0, frames_in = 0, frames_out = 0;
+    int c = 0;
+    int src = SRC_PLAIN, norm = NORM_NONE;
+    const float* dw_w = nullptr;  // [7][c]
+    const float* dw_b = nullptr;  // [c]
+    int scale = 1;                // SRC_LERP
+    const float* yi = nullptr;    // SRC_GATE: raw branch signals [batch][frames][4]
+    const float* stats = nullptr; // [batch][8] = mean[4], invstd[4]
+    const float* in_w = nullptr;  // InstanceNorm affine [4]
+    const float* in_b = nullptr;
+    const float* gate_w = nullptr;  // merge conv [c][4]
+    const float* gate_b = nullptr;  // [c]
+    const float* nw = nullptr;      // norm affine [c]
+    const float* nb = nullptr;
+    float eps = 0.f;
+};
+int launch_rows(hipStream_t s, const RowArgs& r);
+
+// elementwise
+int launch_snake(hipStream_t s, const float* x, float* y, int64_t rows, int c, const float* alpha,
+                 const float* inv_alpha);
+int launch_geglu(hipStream_t s, const float* h, int64_t ldh, float* y, int64_t ldy, int64_t rows, int inner);
+int launch_grn_sumsq(hipStream_t s, const float* h, int64_t batch, int64_t per_clip, float* sumsq);
+int launch_grn_apply(hipStream_t s, float* h, int64_t batch, int64_t frames, int c, const float* sumsq,
+                     const float* gamma, const float* beta);
+
+// FirstBlock (tconv/__init__.py:8-27): audio [batch][samples] -> y [batch][frames][d0], frames >= samples (zero tail)
+struct FirstBlockW {
+    const float* tw;   // trend convs [5][4][7]
+    const float* tb;   // [5][4]
+    const float* w1;   // conv_1 [80][20]
+    const float* b1;   // [80]
+    const float* w2;   // conv_2 [d0][81]
+    const float* b2;   // [d0]
+    int d0;
+};
+int launch_first_block(hipStream_t s, const FirstBlockW& w, const float* audio, int64_t audio_stride, int batch,
+                       int samples, int frames, float* y);
+
+// EnhanceBlock helpers (tconv/__init__.py:30-44)
+struct EnhanceW {
+    const float* tw;  // trend convs [4][7]
+    const float* tb;  // [4]
+};
+int launch_enhance_branches(hipStream_t s, const EnhanceW& w, const float* x, int batch, int frames, int c, float* yi);
+int launch_enhance_stats(hipStream_t s, const float* yi, int batch, int frames, float* stats);
+
+// output head (modules.py:190-195 after the Snake1d): conv 24 -> 1 k7 pad 3, tanh
+int launch_head(hipStream_t s, const float* x, int batch, int frames, int c, const float* w /*[7][c]*/,
+                const float* b, float* audio);
+
+// causal local attention, look-back one window (local_attention.LocalAttention); qkv [rows][3*heads*dh]
+int launch_attention(hipStream_t s, const float* qkv, float* out, const float* bias_table /*[heads][2*window]*/,
+                     int batch, int frames, int heads, int dh, int window);
+
+// FSQ
+struct FsqArgs {
+    const float* x = nullptr;   // [n][feat] or null (latents is then the input)
+    int64_t n = 0;
+    int feat = 0, n_levels = 0;
+    int levels[L3AC_MAX_LEVELS] = {0};
+    const float* w_in = nullptr;
+    const float* b_in = nullptr;
+    const float* w_out = nullptr;
+    const float* b_out = nullptr;
+    const int32_t* idx_in = nullptr;  // decode path: indices are the input
+    float* q_feature = nullptr;
+    int32_t* indices = nullptr;
+    float* level_indices = nullptr;
+    float* latents = nullptr;
+};
+int launch_fsq(hipStream_t s, const FsqArgs& a);
+// `parts` codebook slices are searched by separate blocks; part_dist / part_idx are [parts][n] scratch
+int launch_vq_argmin_parts(hipStream_t s, const float* queries, int64_t n, const float* codebook, int k, int dim,
+                           int parts, float* part_dist, int32_t* part_idx, int32_t* out_idx);

@@ -1,0 +1,140 @@
+// Encoder stem "FirstBlock" (reference l3ac/tconv/__init__.py:8-27, tconv/base.py:8-45):
+//   5 trend branches  p_k = avg_pool(max_pool(|x|, k), k), k in {1 (identity, no abs), 5, 11, 21, 45}
+//   -> weight-normed Conv1d(1 -> 4, k7, pad 3) each -> concat 20 ch -> 1x1 conv 20 -> 80 -> exact GELU
+//   -> concat the raw sample (81 ch) -> 1x1 conv 81 -> d0.
+// audio [batch][samples] -> y [batch][frames][d0]; frames >= samples, the tail is the zero right-padding of
+// Codec.preprocess (l3ac/codec.py:79-84), folded into the load.
+//
+// One block = 256 consecutive frames of one clip.  The pooled signals are built in LDS (halo 3 + 2*(k/2) per
+// side); pooling semantics follow ATen: max_pool pads -inf, avg_pool pads 0 and always divides by k
+// (count_include_pad), its window summed left to right.  The 1x1 convs run on the VALU with wave-uniform
+// (scalar-loaded) weights: ~3.7 kFMA per frame against 4 B read + 4*d0 B written — compute-bound on fp32 VALU.
+#include "../kernels.hpp"
+
+namespace {
+
+constexpr int TILE = 256;
+constexpr int HALO = 47;  // 3 (conv) + 22 (avg 45) + 22 (max 45)
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+template <int D0>
+__global__ __launch_bounds__(TILE) void first_block_kernel(const FirstBlockW w, const float* __restrict__ audio,
+                                                          int64_t audio_stride, int samples, int frames,
+                                                          float* __restrict__ y) {
+    __shared__ float xs[TILE + 2 * HALO];
+    __shared__ float mbuf[TILE + 6 + 44];
+    __shared__ float pbuf[TILE + 6];
+
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * TILE;
+    const float* clip = audio + (int64_t)b * audio_stride;
+
+    for (int i = tid; i < TILE + 2 * HALO; i += TILE) {
+        const int u = t0 - HALO + i;
+        xs[i] = (u >= 0 && u < samples) ? clip[u] : 0.f;
+    }
+    __syncthreads();
+
+    float h[20];
+    // branch 0: identity pool (tconv/base.py:13), conv over the raw samples
+    {
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            float acc = w.tb[o];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) acc = fmaf(w.tw[o * 7 + j], xs[HALO + tid + j - 3], acc);
+            h[o] = acc;
+        }
+    }
+    const int pool_k[4] = {5, 11, 21, 45};
+#pragma unroll
+    for (int br = 0; br < 4; ++br) {
+        const int k = pool_k[br];
+        const int hk = k >> 1;
+        // m[v] for v in [t0 - 3 - hk, t0 + TILE + 3 + hk): max over the in-clip part of the window; 0 outside the clip
+        const int m_len = TILE + 6 + 2 * hk;
+        for (int i = tid; i < m_len; i += TILE) {
+            const int v = t0 - 3 - hk + i;
+            float m = 0.f;
+            if (v >= 0 && v < frames) {
+                const int base = v - hk - (t0 - HALO);  // xs index of sample v - hk
+                for (int s = 0; s < k; ++s) m = fmaxf(m, fabsf(xs[base + s]));
+            }
+            mbuf[i] = m;
+        }
+        __syncthreads();
+        // p[u] for u in [t0 - 3, t0 + TILE + 3): left-to-right window sum / k; 0 outside the clip (conv zero pad)
+        for (int i = tid; i < TILE + 6; i += TILE) {
+            const int u = t0 - 3 + i;
+            float pv = 0.f;
+            if (u >= 0 && u < frames) {
+                float sum = 0.f;
+                for (int s = 0; s < k; ++s) {
+                    const int v = u - hk + s;
+                    if (v >= 0 && v < frames) sum += mbuf[i + s];
+                }
+                pv = sum / (float)k;
+            }
+            pbuf[i] = pv;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const int ch = (br + 1) * 4 + o;
+            float acc = w.tb[ch];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) acc = fmaf(w.tw[ch * 7 + j], pbuf[tid + j], acc);
+            h[ch] = acc;
+        }
+        __syncthreads();
+    }
+
+    const int t = t0 + tid;
+    if (t >= frames) return;
+
+    float out[D0];
+#pragma unroll
+    for (int d = 0; d < D0; ++d) out[d] = w.b2[d];
+    for (int o = 0; o < 80; ++o) {
+        float s = w.b1[o];
+#pragma unroll
+        for (int i = 0; i < 20; ++i) s = fmaf(w.w1[o * 20 + i], h[i], s);
+        const float g = gelu_erf(s);
+#pragma unroll
+        for (int d = 0; d < D0; ++d) out[d] = fmaf(w.w2[o * D0 + d], g, out[d]);
+    }
+    const float xv = xs[HALO + tid];
+#pragma unroll
+    for (int d = 0; d < D0; ++d) out[d] = fmaf(w.w2[80 * D0 + d], xv, out[d]);
+
+    float* dst = y + ((int64_t)b * frames + t) * D0;
+#pragma unroll
+    for (int d = 0; d < D0; d += 4) *reinterpret_cast<float4*>(dst + d) = make_float4(out[d], out[d + 1], out[d + 2], out[d + 3]);
+}
+
+}  // namespace
+
+// w.w2 is expected TRANSPOSED: [81][d0] (done once at weight upload).
+int launch_first_block(hipStream_t s, const FirstBlockW& w, const float* audio, int64_t audio_stride, int batch,
+                       int samples, int frames, float* y) {
+    L3AC_REQUIRE(batch > 0 && batch <= 65535 && frames >= samples && samples > 0, "first_block: bad shape");
+    const dim3 grid((unsigned)ceil_div64(frames, TILE), (unsigned)batch);
+    ProfScope prof(s, "first_block_kernel", 2.0 * (140.0 + 1600.0 + 81.0 * w.d0 + 164.0) * batch * frames,
+                   4.0 * ((double)batch * samples + (double)batch * frames * w.d0));
+    switch (w.d0) {
+#define L3AC_FB_CASE(D) \
+    case D: hipLaunchKernelGGL((first_block_kernel<D>), grid, dim3(TILE), 0, s, w, audio, audio_stride, samples, frames, y); break
+        L3AC_FB_CASE(8);
+        L3AC_FB_CASE(16);
+        L3AC_FB_CASE(24);
+        L3AC_FB_CASE(32);
+#undef L3AC_FB_CASE
+        default:
+            l3ac_set_error("first_block: encoder_dims[0]=%d not in {8,16,24,32}", w.d0);
+            return L3AC_EINVAL;
+    }
+    L3AC_LAUNCH_CHECK();
+    return L3AC_OK;
+}

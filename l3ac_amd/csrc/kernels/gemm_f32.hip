@@ -1,0 +1,264 @@
+// fp32 MFMA GEMM for every channel contraction of the L3AC conv stacks and transformer blocks
+// (reference: nn.Linear / nn.Conv1d calls in l3ac/modules.py:19-36,96-99,110,150,161 and local_attention's
+// to_qkv / to_out / FeedForward linears).
+//
+//   c[m][n] = epilogue( sum_k A(m, k) * w[n][k] )
+//
+// gfx950 design
+//   * v_mfma_f32_32x32x2_f32: exact fp32 (a k-ordered fmaf chain), 64 FLOP/clk/SIMD = the fp32 peak.
+//   * block = 4 waves, tile 128 (m) x 32*NT (n) x 32 (k); wave w owns rows [32w, 32w+32) across all NT column
+//     tiles, so a whole output row lives in one wave (row-wise epilogues need no cross-wave traffic).
+//   * both operands are k-contiguous in HBM; tiles are staged global -> registers -> LDS (16 B per lane,
+//     full 128-B lines per 8 lanes) and double-buffered, the next tile's global loads in flight during the MFMAs.
+//   * LDS rows are 128 B; the 16-B chunk index is XOR-swizzled with (row >> 1) & 7 so that the ds_read_b128
+//     fragment reads (one row per lane, same k chunk) are bank-conflict free.
+//   * one ds_read_b128 per operand feeds FOUR MFMAs: lane (i, h) holds k = 8q + 4h + {0..3}; MFMA r consumes
+//     element r from A and B alike, i.e. the k order inside a group of 8 is permuted identically on both sides.
+//   * A can be an implicit 1-D convolution (taps > 1): row m = (clip b, frame t) gathers frames
+//     t + (tap - taps/2) * dil of the same clip, zero outside it — no im2col buffer.
+#include "../kernels.hpp"
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int BK = 32;
+constexpr int THREADS = 256;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int lds_off(int row, int chunk) {  // float index of 16-B chunk `chunk` of row `row`
+    return row * BK + ((chunk ^ ((row >> 1) & 7)) << 2);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float snake_f(float h, float alpha, float inv_alpha) {
+    const float s = sinf(alpha * h);
+    return h + inv_alpha * (s * s);
+}
+
+template <int NT, bool CONV>
+__global__ __launch_bounds__(THREADS, 2) void gemm_f32_kernel(const GemmArgs p) {
+    constexpr int BN = 32 * NT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                 // [2][BM * BK]
+    float* Ws = smem + 2 * BM * BK;   // [2][BN * BK]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_blocks = (p.n + BN - 1) / BN;
+    const int64_t m0 = (int64_t)(blockIdx.x / n_blocks) * BM;
+    const int n0 = (int)(blockIdx.x % n_blocks) * BN;
+
+    // ---- staging roles: thread -> (chunk column cc, rows r0 + 32 i) ---------------------------------
+    const int cc = tid & 7;
+    const int r0 = tid >> 3;
+    const float* a_row[4];
+    int a_t[4];
+    bool a_ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t m = m0 + r0 + 32 * i;
+        a_ok[i] = m < p.m;
+        const int64_t mm = a_ok[i] ? m : 0;
+        if (CONV) {
+            a_t[i] = (int)(mm % p.frames);
+            a_row[i] = p.a + mm * p.lda;
+        } else {
+            a_t[i] = 0;
+            a_row[i] = p.a + mm * p.lda;
+        }
+    }
+    const float* w_row[NT];
+    bool w_ok[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int n = n0 + r0 + 32 * i;
+        w_ok[i] = n < p.n;
+        w_row[i] = p.w + (int64_t)(w_ok[i] ? n : 0) * p.ldw;
+    }
+    // conv bookkeeping for this thread's chunk: k = k_tile + 4 cc = tap * cin + c
+    int tap = 0, ch = 4 * cc;
+    if (CONV) {
+        while (ch >= p.cin) { ch -= p.cin; ++tap; }
+    }
+    const int half = p.taps >> 1;
+
+    float4 a_reg[4], w_reg[NT];
+    auto load_tile = [&](int k_tile) {
+        const int k = k_tile + 4 * cc;
+        const bool k_ok = k < p.k;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (CONV) {
+                const int ts = a_t[i] + (tap - half) * p.dil;
+                if (a_ok[i] && k_ok && ts >= 0 && ts < p.frames)
+                    v = *reinterpret_cast<const float4*>(a_row[i] + (int64_t)(tap - half) * p.dil * p.lda + ch);
+            } else {
+                if (a_ok[i] && k_ok) v = *reinterpret_cast<const float4*>(a_row[i] + k);
+            }
+            a_reg[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (w_ok[i] && k_ok) v = *reinterpret_cast<const float4*>(w_row[i] + k);
+            w_reg[i] = v;
+        }
+        if (CONV) {  // advance (tap, ch) by BK for the next tile
+            ch += BK;
+            while (ch >= p.cin) { ch -= p.cin; ++tap; }
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float* as = As + buf * BM * BK;
+        float* ws = Ws + buf * BN * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(as + lds_off(r0 + 32 * i, cc)) = a_reg[i];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) *reinterpret_cast<float4*>(ws + lds_off(r0 + 32 * i, cc)) = w_reg[i];
+    };
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    const int li = lane & 31;
+    const int lh = lane >> 5;
+    const int n_tiles = (p.k + BK - 1) / BK;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < n_tiles; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < n_tiles) load_tile((kt + 1) * BK);
+        const float* as = As + buf * BM * BK;
+        const float* ws = Ws + buf * BN * BK;
+#pragma unroll
+        for (int q = 0; q < BK / 8; ++q) {
+            const int chunk = 2 * q + lh;
+            const float4 af = *reinterpret_cast<const float4*>(as + lds_off(32 * wave + li, chunk));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float4 bf = *reinterpret_cast<const float4*>(ws + lds_off(32 * nt + li, chunk));
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc[nt], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < n_tiles) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds column n = n0 + 32 nt + li, rows m0 + 32 wave + (r&3) + 8 (r>>2) + 4 lh ----
+    const int64_t mw = m0 + 32 * wave + 4 * lh;
+    if (p.epi == EPI_GEGLU) {
+        // column tiles come in (value, gate) pairs; output column j = n0/2 + 32 (nt/2) + li
+#pragma unroll
+        for (int nt = 0; nt + 1 < NT; nt += 2) {
+            const int j = (n0 >> 1) + 16 * nt + li;
+            if (j < (int)p.ldc) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t m = mw + (r & 3) + 8 * (r >> 2);
+                    if (m < p.m) p.c[m * p.ldc + j] = acc[nt][r] * gelu_erf(acc[nt + 1][r]);
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = n0 + 32 * nt + li;
+        if (n >= p.n) continue;
+        const float bias = p.bias ? p.bias[n] : 0.f;
+        float alpha = 0.f, inv_alpha = 0.f, gamma = 0.f, beta = 0.f;
+        if (p.epi == EPI_SNAKE || p.epi == EPI_SNAKE_GRN) {
+            alpha = p.alpha[n];
+            inv_alpha = p.inv_alpha[n];
+        }
+        if (p.epi == EPI_SNAKE_GRN) {
+            gamma = p.gamma[n];
+            beta = p.beta[n];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t m = mw + (r & 3) + 8 * (r >> 2);
+            if (m >= p.m) continue;
+            float v = acc[nt][r] + bias;
+            if (p.epi == EPI_BIAS_RES) {
+                v = p.res[m * p.ldres + n] + v;
+            } else if (p.epi == EPI_SNAKE) {
+                v = snake_f(v, alpha, inv_alpha);
+            } else if (p.epi == EPI_SNAKE_GRN) {
+                const float s = snake_f(v, alpha, inv_alpha);
+                v = (gamma * s + beta) + s;  // layers.py:115 with the normaliser n_x == 1.0f
+            }
+            p.c[m * p.ldc + n] = v;
+        }
+    }
+}
+
+template <int NT, bool CONV>
+int launch_one(hipStream_t s, const GemmArgs& g) {
+    constexpr int BN = 32 * NT;
+    const int64_t blocks = ceil_div64(g.m, BM) * ceil_div64(g.n, BN);
+    if (blocks <= 0) return L3AC_OK;
+    L3AC_REQUIRE(blocks < (int64_t)1 << 31, "gemm: grid too large (m=%lld n=%d)", (long long)g.m, g.n);
+    const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
+    static const char* const names[2][4] = {
+        {"gemm_f32_kernel<1,false>", "gemm_f32_kernel<2,false>", "gemm_f32_kernel<3,false>", "gemm_f32_kernel<4,false>"},
+        {"gemm_f32_kernel<1,true>", "gemm_f32_kernel<2,true>", "gemm_f32_kernel<3,true>", "gemm_f32_kernel<4,true>"}};
+    const double a_elems = CONV ? (double)g.m * g.cin : (double)g.m * g.k;
+    const double c_cols = g.epi == EPI_GEGLU ? (double)g.ldc : (double)g.n;
+    ProfScope prof(s, names[CONV ? 1 : 0][NT - 1], 2.0 * (double)g.m * g.n * g.k,
+                   4.0 * (a_elems + (double)g.n * g.k + (double)g.m * c_cols * (g.epi == EPI_BIAS_RES ? 2.0 : 1.0)));
+    hipLaunchKernelGGL((gemm_f32_kernel<NT, CONV>), dim3((unsigned)blocks), dim3(THREADS), lds, s, g);
+    L3AC_LAUNCH_CHECK();
+    return L3AC_OK;
+}
+
+}  // namespace
+
+int launch_gemm(hipStream_t s, const GemmArgs& g) {
+    L3AC_REQUIRE(g.a && g.w && g.c, "gemm: null operand");
+    L3AC_REQUIRE(g.k > 0 && g.k % 4 == 0, "gemm: k=%d must be a positive multiple of 4", g.k);
+    L3AC_REQUIRE(g.lda % 4 == 0 && g.ldw % 4 == 0, "gemm: lda=%lld ldw=%lld must be multiples of 4", (long long)g.lda,
+                 (long long)g.ldw);
+    L3AC_REQUIRE(((uintptr_t)g.a & 15) == 0 && ((uintptr_t)g.w & 15) == 0, "gemm: operands must be 16-byte aligned");
+    const bool conv = g.taps > 1;
+    if (conv) {
+        L3AC_REQUIRE(g.cin > 0 && g.cin % 4 == 0 && g.k == g.taps * g.cin && g.frames > 0 && g.m % g.frames == 0,
+                     "gemm: bad implicit-conv geometry (taps=%d cin=%d k=%d frames=%lld m=%lld)", g.taps, g.cin, g.k,
+                     (long long)g.frames, (long long)g.m);
+    }
+    if (g.epi == EPI_GEGLU) {
+        L3AC_REQUIRE(g.n % 64 == 0 && !conv, "gemm: GEGLU epilogue needs interleaved 64-column tiles");
+        return launch_one<4, false>(s, g);
+    }
+    if (g.epi == EPI_BIAS_RES) L3AC_REQUIRE(g.res, "gemm: residual epilogue without residual");
+    if (g.epi == EPI_SNAKE || g.epi == EPI_SNAKE_GRN) L3AC_REQUIRE(g.alpha && g.inv_alpha, "gemm: snake without alpha");
+    if (g.epi == EPI_SNAKE_GRN) L3AC_REQUIRE(g.gamma && g.beta, "gemm: GRN without gamma/beta");
+    // widest column tile that does not over-pad n
+    const int nt = g.n <= 32 ? 1 : (g.n <= 64 ? 2 : (g.n <= 96 ? 3 : 4));
+    if (conv) {
+        switch (nt) {
+            case 1: return launch_one<1, true>(s, g);
+            case 2: return launch_one<2, true>(s, g);
+            case 3: return launch_one<3, true>(s, g);
+            default: return launch_one<4, true>(s, g);
+        }
+    }
+    switch (nt) {
+        case 1: return launch_one<1, false>(s, g);
+        case 2: return launch_one<2, false>(s, g);
+        case 3: return launch_one<3, false>(s, g);
+        default: return launch_one<4, false>(s, g);
+    }
+}

@@ -1,0 +1,294 @@
+// Row kernels: every op whose unit of work is one frame (all channels of one time step), HBM-bound.
+//
+//   source                      reference
+//   SRC_PLAIN                   identity (feeds the norms below)
+//   SRC_DWCONV7                 ConvUnit.dw_conv: depth-wise Conv1d k7 pad 3        l3ac/modules.py:19-20
+//   SRC_LERP                    nn.Upsample(scale, 'linear', align_corners=False)  l3ac/modules.py:162, local_trans.py:121
+//   SRC_GATE                    EnhanceBlock: x + merge(InstanceNorm(yi)) * x      l3ac/tconv/__init__.py:35-44
+//   norm
+//   NORM_LN                     F.layer_norm over channels                         l3ac/layers.py:79-80, local_attention LayerNorm
+//   NORM_CN                     channel_norm channels_first (divide by sqrt)       l3ac/layers.py:50-56
+//
+// Layout: a group of LPR lanes (power of two, <= 64) owns one row; lane j holds the 16-byte chunks j, j + LPR
+// (so c <= 8 * LPR), loads are 16 B per lane and contiguous across the group; mean / variance are two-pass in
+// registers with a butterfly over the group.
+#include "../kernels.hpp"
+
+namespace {
+
+constexpr int THREADS = 256;
+constexpr int MAX_CH = 2;  // chunks per lane
+
+__device__ __forceinline__ float group_sum(float v, int lpr) {
+    for (int mask = lpr >> 1; mask > 0; mask >>= 1) v += __shfl_xor(v, mask, 64);
+    return v;
+}
+
+__device__ __forceinline__ float4 f4_fma(float4 a, float4 b, float4 c) {
+    return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
+}
+
+template <int SRC, int NORM>
+__global__ __launch_bounds__(THREADS) void row_kernel(const RowArgs p, const int lpr) {
+    const int groups_per_block = THREADS / lpr;
+    const int64_t row = (int64_t)blockIdx.x * groups_per_block + threadIdx.x / lpr;
+    const int j = threadIdx.x % lpr;
+    const int64_t rows = p.batch * p.frames_out;
+    const bool row_ok = row < rows;
+    const int64_t rr = row_ok ? row : 0;
+    const int64_t b = rr / p.frames_out;
+    const int64_t t = rr % p.frames_out;
+    const int nchunk = p.c >> 2;
+
+    float4 v[MAX_CH];
+    bool ok[MAX_CH];
+#pragma unroll
+    for (int i = 0; i < MAX_CH; ++i) {
+        const int chunk = j + i * lpr;
+        ok[i] = row_ok && chunk < nchunk;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!ok[i]) continue;
+        const int c0 = chunk << 2;
+        if (SRC == SRC_PLAIN) {
+            v[i] = *reinterpret_cast<const float4*>(p.x + (b * p.frames_in + t) * p.c + c0);
+        } else if (SRC == SRC_DWCONV7) {
+            float4 acc = *reinterpret_cast<const float4*>(p.dw_b + c0);
+#pragma unroll
+            for (int tap = 0; tap < 7; ++tap) {
+                const int64_t ts = t + tap - 3;
+                if (ts >= 0 && ts < p.frames_in) {
+                    const float4 xv = *reinterpret_cast<const float4*>(p.x + (b * p.frames_in + ts) * p.c + c0);
+                    const float4 wv = *reinterpret_cast<const float4*>(p.dw_w + tap * p.c + c0);
+                    acc = f4_fma(xv, wv, acc);
+                }
+            }
+            v[i] = acc;
+        } else if (SRC == SRC_LERP) {
+            // ATen upsample_linear1d (align_corners=False): src = scale * (dst + 0.5) - 0.5 clamped at 0
+            const float rscale = (float)(1.0 / (double)p.scale);
+            float src = __fsub_rn(__fmul_rn(rscale, (float)t + 0.5f), 0.5f);
+            src = src < 0.f ? 0.f : src;
+            const int64_t i0 = (int64_t)src;
+            const int64_t i1 = i0 + (i0 < p.frames_in - 1 ? 1 : 0);
+            float l1 = src - (float)i0;
+            l1 = fminf(fmaxf(l1, 0.f), 1.f);
+            const float l0 = 1.f - l1;
+            const float4 x0 = *reinterpret_cast<const float4*>(p.x + (b * p.frames_in + i0) * p.c + c0);
+            const float4 x1 = *reinterpret_cast<const float4*>(p.x + (b * p.frames_in + i1) * p.c + c0);
+            v[i] = make_float4(__fadd_rn(__fmul_rn(l0, x0.x), __fmul_rn(l1, x1.x)),
+                               __fadd_rn(__fmul_rn(l0, x0.y), __fmul_rn(l1, x1.y)),
+                               __fadd_rn(__fmul_rn(l0, x0.z), __fmul_rn(l1, x1.z)),
+                               __fadd_rn(__fmul_rn(l0, x0.w), __fmul_rn(l1, x1.w)));
+        } else {  // SRC_GATE
+            const float4 yraw = *reinterpret_cast<const float4*>(p.yi + (b * p.frames_in + t) * 4);
+            const float4 mean = *reinterpret_cast<const float4*>(p.stats + b * 8);
+            const float4 istd = *reinterpret_cast<const float4*>(p.stats + b * 8 + 4);
+            const float4 iw = *reinterpret_cast<const float4*>(p.in_w);
+            const float4 ib = *reinterpret_cast<const float4*>(p.in_b);
+            const float y0 = (yraw.x - mean.x) * istd.x * iw.x + ib.x;
+            const float y1 = (yraw.y - mean.y) * istd.y * iw.y + ib.y;
+            const float y2 = (yraw.z - mean.z) * istd.z * iw.z + ib.z;
+            const float y3 = (yraw.w - mean.w) * istd.w * iw.w + ib.w;
+            const float4 xv = *reinterpret_cast<const float4*>(p.x + (b * p.frames_in + t) * p.c + c0);
+            const float4 gb = *reinterpret_cast<const float4*>(p.gate_b + c0);
+            const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+            const float gbs[4] = {gb.x, gb.y, gb.z, gb.w};
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float4 gw = *reinterpret_cast<const float4*>(p.gate_w + (int64_t)(c0 + e) * 4);
+                const float g = gbs[e] + gw.x * y0 + gw.y * y1 + gw.z * y2 + gw.w * y3;
+                o[e] = xs[e] + g * xs[e];
+            }
+            v[i] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+
+    if (NORM != NORM_NONE) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAX_CH; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);  // masked chunks hold zeros
+        const float mean = group_sum(s, lpr) / (float)p.c;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAX_CH; ++i) {
+            if (ok[i]) {
+                const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+                q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+            }
+        }
+        const float var = group_sum(q, lpr) / (float)p.c;
+        const float rstd = NORM == NORM_LN ? 1.0f / sqrtf(var + p.eps) : 0.f;
+        const float sd = NORM == NORM_CN ? sqrtf(var + p.eps) : 1.f;
+#pragma unroll
+        for (int i = 0; i < MAX_CH; ++i) {
+            if (!ok[i]) continue;
+            const int c0 = (j + i * lpr) << 2;
+            const float4 w = *reinterpret_cast<const float4*>(p.nw + c0);
+            const float4 bb = *reinterpret_cast<const float4*>(p.nb + c0);
+            if (NORM == NORM_LN) {
+                v[i] = make_float4((v[i].x - mean) * rstd * w.x + bb.x, (v[i].y - mean) * rstd * w.y + bb.y,
+                                   (v[i].z - mean) * rstd * w.z + bb.z, (v[i].w - mean) * rstd * w.w + bb.w);
+            } else {
+                v[i] = make_float4(w.x * ((v[i].x - mean) / sd) + bb.x, w.y * ((v[i].y - mean) / sd) + bb.y,
+                                   w.z * ((v[i].z - mean) / sd) + bb.z, w.w * ((v[i].w - mean) / sd) + bb.w);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAX_CH; ++i) {
+        if (ok[i]) *reinterpret_cast<float4*>(p.y + row * p.c + ((j + i * lpr) << 2)) = v[i];
+    }
+}
+
+template <int SRC, int NORM>
+int launch_rows_t(hipStream_t s, const RowArgs& r, int lpr) {
+    const int64_t rows = r.batch * r.frames_out;
+    const int64_t blocks = ceil_div64(rows, THREADS / lpr);
+    if (blocks <= 0) return L3AC_OK;
+    L3AC_REQUIRE(blocks < (int64_t)1 << 31, "rows: grid too large");
+    static const char* const names[4][3] = {{"row_kernel<PLAIN,NONE>", "row_kernel<PLAIN,LN>", "row_kernel<PLAIN,CN>"},
+                                            {"row_kernel<DWCONV7,NONE>", "row_kernel<DWCONV7,LN>", "row_kernel<DWCONV7,CN>"},
+                                            {"row_kernel<LERP,NONE>", "row_kernel<LERP,LN>", "row_kernel<LERP,CN>"},
+                                            {"row_kernel<GATE,NONE>", "row_kernel<GATE,LN>", "row_kernel<GATE,CN>"}};
+    const double in_elems = (double)r.batch * r.frames_in * r.c, out_elems = (double)rows * r.c;
+    ProfScope prof(s, names[SRC][NORM], (SRC == SRC_DWCONV7 ? 14.0 : 2.0) * out_elems + (NORM != NORM_NONE ? 8.0 * out_elems : 0.0),
+                   4.0 * (in_elems + out_elems));
+    hipLaunchKernelGGL((row_kernel<SRC, NORM>), dim3((unsigned)blocks), dim3(THREADS), 0, s, r, lpr);
+    L3AC_LAUNCH_CHECK();
+    return L3AC_OK;
+}
+
+// ---- elementwise -------------------------------------------------------------------------------
+__global__ __launch_bounds__(THREADS) void snake_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                       int64_t n4, int c4, const float* __restrict__ alpha,
+                                                       const float* __restrict__ inv_alpha) {
+    for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * THREADS) {
+        const int c0 = (int)(i % c4) << 2;
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        const float4 a = *reinterpret_cast<const float4*>(alpha + c0);
+        const float4 ia = *reinterpret_cast<const float4*>(inv_alpha + c0);
+        float4 o;
+        float s;
+        s = sinf(a.x * v.x); o.x = v.x + ia.x * (s * s);
+        s = sinf(a.y * v.y); o.y = v.y + ia.y * (s * s);
+        s = sinf(a.z * v.z); o.z = v.z + ia.z * (s * s);
+        s = sinf(a.w * v.w); o.w = v.w + ia.w * (s * s);
+        reinterpret_cast<float4*>(y)[i] = o;
+    }
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__global__ __launch_bounds__(THREADS) void geglu_kernel(const float* __restrict__ h, int64_t ldh, float* __restrict__ y,
+                                                       int64_t ldy, int64_t rows, int inner) {
+    const int64_t total = rows * ldy;
+    for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * THREADS) {
+        const int64_t r = i / ldy;
+        const int j = (int)(i % ldy);
+        float o = 0.f;
+        if (j < inner) o = h[r * ldh + j] * gelu_erf(h[r * ldh + inner + j]);
+        y[i] = o;
+    }
+}
+
+// per-clip sum of squares (GRN exact mode, layers.py:113): one block per (clip, slice), atomics into sumsq[batch]
+__global__ __launch_bounds__(THREADS) void grn_sumsq_kernel(const float* __restrict__ h, int64_t per_clip4,
+                                                           float* __restrict__ sumsq) {
+    const int64_t b = blockIdx.y;
+    const float4* base = reinterpret_cast<const float4*>(h) + b * per_clip4;
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < per_clip4; i += (int64_t)gridDim.x * THREADS) {
+        const float4 v = base[i];
+        acc += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    for (int mask = 32; mask > 0; mask >>= 1) acc += __shfl_xor(acc, mask, 64);
+    __shared__ float part[THREADS / 64];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(sumsq + b, (part[0] + part[1]) + (part[2] + part[3]));
+}
+
+__global__ __launch_bounds__(THREADS) void grn_apply_kernel(float* __restrict__ h, int64_t per_clip4, int c4,
+                                                           const float* __restrict__ sumsq,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta) {
+    const int64_t b = blockIdx.y;
+    const float g = sqrtf(sumsq[b]);
+    const float nx = g / (g + 1e-8f);  // layers.py:114 (the mean over a size-1 dim is the value itself)
+    float4* base = reinterpret_cast<float4*>(h) + b * per_clip4;
+    for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < per_clip4; i += (int64_t)gridDim.x * THREADS) {
+        const int c0 = (int)(i % c4) << 2;
+        const float4 v = base[i];
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + c0);
+        const float4 be = *reinterpret_cast<const float4*>(beta + c0);
+        base[i] = make_float4((ga.x * (v.x * nx) + be.x) + v.x, (ga.y * (v.y * nx) + be.y) + v.y,
+                              (ga.z * (v.z * nx) + be.z) + v.z, (ga.w * (v.w * nx) + be.w) + v.w);
+    }
+}
+
+inline unsigned stream_grid(int64_t work_items) {
+    const int64_t blocks = ceil_div64(work_items, THREADS);
+    return (unsigned)(blocks < 1 ? 1 : (blocks > 256 * 16 ? 256 * 16 : blocks));
+}
+
+}  // namespace
+
+int launch_rows(hipStream_t s, const RowArgs& r) {
+    L3AC_REQUIRE(r.x && r.y && r.c > 0 && r.c % 4 == 0, "rows: bad arguments (c=%d)", r.c);
+    int lpr = 1;
+    while (lpr * 4 < r.c && lpr < 64) lpr <<= 1;
+    L3AC_REQUIRE(r.c <= 4 * lpr * MAX_CH, "rows: c=%d too wide for the row kernel", r.c);
+    if (r.norm != NORM_NONE) L3AC_REQUIRE(r.nw && r.nb, "rows: norm without affine parameters");
+#define L3AC_ROWS_CASE(S, N) \
+    if (r.src == S && r.norm == N) return launch_rows_t<S, N>(s, r, lpr)
+    L3AC_ROWS_CASE(SRC_PLAIN, NORM_LN);
+    L3AC_ROWS_CASE(SRC_PLAIN, NORM_CN);
+    L3AC_ROWS_CASE(SRC_DWCONV7, NORM_LN);
+    L3AC_ROWS_CASE(SRC_LERP, NORM_NONE);
+    L3AC_ROWS_CASE(SRC_LERP, NORM_CN);
+    L3AC_ROWS_CASE(SRC_GATE, NORM_NONE);
+#undef L3AC_ROWS_CASE
+    l3ac_set_error("rows: unsupported (src=%d, norm=%d)", r.src, r.norm);
+    return L3AC_EINVAL;
+}
+
+int launch_snake(hipStream_t s, const float* x, float* y, int64_t rows, int c, const float* alpha,
+                 const float* inv_alpha) {
+    L3AC_REQUIRE(c % 4 == 0, "snake: c=%d must be a multiple of 4", c);
+    const int64_t n4 = rows * (c / 4);
+    if (n4 == 0) return L3AC_OK;
+    ProfScope prof(s, "snake_kernel", 16.0 * n4, 32.0 * n4);
+    hipLaunchKernelGGL(snake_kernel, dim3(stream_grid(n4)), dim3(THREADS), 0, s, x, y, n4, c / 4, alpha, inv_alpha);
+    L3AC_LAUNCH_CHECK();
+    return L3AC_OK;
+}
+
+int launch_geglu(hipStream_t s, const float* h, int64_t ldh, float* y, int64_t ldy, int64_t rows, int inner) {
+    if (rows == 0) return L3AC_OK;
+    ProfScope prof(s, "geglu_kernel", 10.0 * rows * inner, 12.0 * rows * inner);
+    hipLaunchKernelGGL(geglu_kernel, dim3(stream_grid(rows * ldy)), dim3(THREADS), 0, s, h, ldh, y, ldy, rows, inner);
+    L3AC_LAUNCH_CHECK();
+    return L3AC_OK;
+}
+
+int launch_grn_sumsq(hipStream_t s, const float* h, int64_t batch, int64_t per_clip, float* sumsq) {
+    L3AC_REQUIRE(per_clip % 4 == 0, "grn: per-clip size must be a multiple of 4");
+    L3AC_HIP_CHECK(hipMemsetAsync(sumsq, 0, (size_t)batch * sizeof(float), s));
+    const unsigned gx = (unsigned)(ceil_div64(per_clip / 4, THREADS * 8) < 1 ? 1 : ceil_div64(per_clip / 4, THREADS * 8));
+    ProfScope prof(s, "grn_sumsq_kernel", 2.0 * batch * per_clip, 4.0 * batch * per_clip);
+    hipLaunchKernelGGL(grn_sumsq_kernel, dim3(gx, (unsigned)batch), dim3(THREADS), 0, s, h, per_clip / 4, sumsq);
+    L3AC_LAUNCH_CHECK();
+    return L3AC_OK;
+}
+
+int launch_grn_apply(hipStream_t s, float* h, int64_t batch, int64_t frames, int c, const float* sumsq,
+                     const float* gamma, const float* beta) {
+    const int64_t per_clip4 = frames * c / 4;
+    const unsigned gx = (unsigned)(ceil_div64(per_clip4, THREADS * 8) < 1 ? 1 : ceil_div64(per_clip4, THREADS * 8));
+    ProfScope prof(s, "grn_apply_kernel", 4.0 * batch * frames * c, 8.0 * batch * frames * c);
+    hipLaunchKernelGGL(grn_apply_kernel, dim3(gx, (unsigned)batch), dim3(THREADS), 0, s, h, per_clip4, c / 4, sumsq, gamma,
+                       beta);
+    L3AC_LAUNCH_CHECK();
+    return L3AC_OK;
+}

@@ -1,0 +1,109 @@
+// Host-side model of the L3AC network: device-resident weights laid out for the kernels, the workspace,
+// and the encode / decode pipelines (reference call stacks: SURVEY.md §3.2, §3.3).
+#pragma once
+
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "kernels.hpp"
+
+struct ConvUnitW {  // modules.py:10-41
+    int c = 0;
+    const float *dw_w, *dw_b, *ln_w, *ln_b, *w1, *b1, *alpha, *inv_alpha, *gamma, *beta, *w2, *b2;
+};
+struct DownW {  // modules.py:96-99 and local_trans.py:136: Conv1d(k = stride) [+ ChannelNorm]
+    int cin = 0, cout = 0, stride = 1;
+    const float *w, *b, *nw = nullptr, *nb = nullptr;
+};
+struct ConvK3W {  // modules.py:110, :150
+    int cin = 0, cout = 0;
+    const float *w, *b;
+};
+struct EnhW {  // tconv/__init__.py:30-44
+    int c = 0;
+    EnhanceW t;
+    const float *in_w, *in_b, *gate_w, *gate_b;
+};
+struct UpW {  // modules.py:160-164
+    int cin = 0, cout = 0, scale = 1;
+    const float *w, *b, *nw, *nb;
+};
+struct LegacyW {  // modules.py:47-64
+    int c = 0, dil = 1;
+    const float *a0, *ia0, *w1, *b1, *a1, *ia1, *w2, *b2;
+};
+struct HeadW {  // modules.py:192-194
+    int c = 0;
+    const float *alpha, *inv_alpha, *w, *b;
+};
+struct TransLayerW {  // local_attention LocalMHA + FeedForward
+    const float *ln1w, *ln1b, *wqkv, *wout, *ln2w, *ln2b, *wff1, *wff2;
+};
+struct LocalTransW {  // local_trans.py:7-53
+    int window = 0;
+    std::vector<TransLayerW> layers;
+    const float* bias_table = nullptr;  // [heads][2 * window]
+};
+
+struct Workspace {
+    float *x0 = nullptr, *x1 = nullptr, *a = nullptr, *h = nullptr, *yi = nullptr, *stats = nullptr, *sumsq = nullptr;
+    size_t x_cap = 0, a_cap = 0, h_cap = 0, yi_cap = 0, b_cap = 0;  // capacities in floats
+    size_t bytes() const { return (2 * x_cap + a_cap + h_cap + yi_cap + 9 * b_cap) * sizeof(float); }
+};
+
+struct l3ac_ctx {
+    l3ac_config cfg{};
+    int device = 0;
+    int hop = 0, enc_rate = 1, dim_head = 0, inner = 0, ff_inner = 0, ff_pad = 0, ff_n = 0;
+    float* arena = nullptr;
+    size_t arena_floats = 0;
+
+    FirstBlockW first{};
+    std::vector<std::vector<ConvUnitW>> enc_units;  // per encoder stage (incl. the tail stage)
+    std::vector<DownW> enc_down;
+    ConvK3W enc_out{};
+    std::vector<LocalTransW> en_enc;   // execution order
+    DownW en_down{};                   // DownTrans.down_layer (compressed configs)
+    std::vector<LocalTransW> en_dec;
+    const float *q_win = nullptr, *q_bin = nullptr, *q_wout = nullptr, *q_bout = nullptr;
+    ConvK3W dec_in{};
+    std::vector<std::vector<ConvUnitW>> dec_units;
+    std::vector<EnhW> dec_enh;
+    std::vector<UpW> dec_up;
+    std::vector<LegacyW> legacy;
+    HeadW head{};
+
+    // name -> block, for the l3ac_op_* parity entry points
+    std::map<std::string, const ConvUnitW*> by_unit;
+    std::map<std::string, const DownW*> by_down;
+    std::map<std::string, const ConvK3W*> by_k3;
+    std::map<std::string, const EnhW*> by_enh;
+    std::map<std::string, const UpW*> by_up;
+    std::map<std::string, const LocalTransW*> by_trans;
+
+    Workspace ws;
+};
+
+int network_build(l3ac_ctx* ctx, const l3ac_tensor* tensors, int n_tensors);
+void network_free(l3ac_ctx* ctx);
+int workspace_ensure(l3ac_ctx* ctx, size_t x_floats, size_t a_floats, size_t h_floats, size_t yi_floats, size_t batch,
+                     hipStream_t s);
+int workspace_ensure_clip(l3ac_ctx* ctx, int batch, int samples, hipStream_t s);
+
+// blocks (x may alias y where noted)
+int run_conv_unit(l3ac_ctx* ctx, hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames);  // x == y ok
+int run_down(l3ac_ctx* ctx, hipStream_t s, const DownW& w, const float* x, float* y, int batch, int frames);
+int run_conv_k3(l3ac_ctx* ctx, hipStream_t s, const ConvK3W& w, const float* x, float* y, int batch, int frames);
+int run_enhance(l3ac_ctx* ctx, hipStream_t s, const EnhW& w, const float* x, float* y, int batch, int frames);  // x == y ok
+int run_up(l3ac_ctx* ctx, hipStream_t s, const UpW& w, const float* x, float* tmp, float* y, int batch, int frames);
+int run_last_block(l3ac_ctx* ctx, hipStream_t s, float* x, float* audio, int batch, int frames);  // x is clobbered
+int run_local_trans(l3ac_ctx* ctx, hipStream_t s, const LocalTransW& w, float* x, int batch, int frames);  // in place
+
+// sub-modules; `cur`/`alt` are the ping-pong activation buffers, on return *cur holds the result
+int run_encoder(l3ac_ctx* ctx, hipStream_t s, const float* audio, int64_t audio_stride, int batch, int samples,
+                int frames, float** cur, float** alt);
+int run_en_encoder(l3ac_ctx* ctx, hipStream_t s, int batch, int frames, float** cur, float** alt, int* n_tok);
+int run_en_decoder(l3ac_ctx* ctx, hipStream_t s, int batch, int n_tok, float** cur, float** alt, int* frames);
+int run_decoder(l3ac_ctx* ctx, hipStream_t s, int batch, int frames, float** cur, float** alt, float* audio);

@@ -1,0 +1,231 @@
+"""HIP kernels vs the CPU oracle, block by block, through the C ABI (needs an MI355X: `pytest -m gpu`)."""
+import numpy as np
+import pytest
+import torch
+
+import l3ac_amd
+from l3ac_amd import weights as W
+from oracle import l3ac_oracle as O
+from tests import gpu_ops as G
+from tests.helpers import GOLDEN, index_mismatch_report, load_case, seeded_audio
+
+pytestmark = pytest.mark.gpu
+
+ATOL_BLOCK = 2e-5   # one block, activations O(1), fp32 with a different summation order
+RTOL_BLOCK = 2e-5
+
+
+def _close(name, got, ref, atol=ATOL_BLOCK, rtol=RTOL_BLOCK):
+    got = got.detach().cpu().double()
+    ref = ref.detach().cpu().double()
+    assert got.shape == ref.shape, f"{name}: shape {tuple(got.shape)} != {tuple(ref.shape)}"
+    err = (got - ref).abs()
+    bound = atol + rtol * ref.abs()
+    print(f"[{name}] max|err|={err.max().item():.3e} max|ref|={ref.abs().max().item():.3e}")
+    assert torch.isfinite(got).all(), f"{name}: non-finite output"
+    assert (err <= bound).all(), f"{name}: max err {err.max().item():.3e} (worst excess {(err - bound).max().item():.3e})"
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    codec = l3ac_amd.get_model(GOLDEN / "tiny.toml", synthetic_seed=3)
+    codec.network.to(device="cuda").eval()
+    mc = codec.network.mc
+    w = W.folded_weights(codec.network.state_dicts())
+    return codec, mc, w
+
+
+@pytest.fixture(scope="module")
+def full():
+    codec = l3ac_amd.get_model("1kbps", synthetic_seed=0)
+    codec.network.to(device="cuda").eval()
+    mc = codec.network.mc
+    w = W.folded_weights(codec.network.state_dicts())
+    return codec, mc, w
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+# ---------------------------------------------------------------------------------------------------
+def test_gemm_against_fp64():
+    for (m, n, k) in [(300, 24, 96), (257, 96, 24), (1000, 130, 344), (129, 512, 2048), (64, 48, 144)]:
+        a, w, b = _rand((m, k), 1), _rand((n, k), 2, 0.1), _rand((n,), 3)
+        got = G.gemm(a.cuda(), w.cuda(), b.cuda()).cpu()
+        ref = (a.double() @ w.double().T + b.double())
+        scale = (a.abs().double() @ w.abs().double().T).max().item()
+        err = (got.double() - ref).abs().max().item()
+        print(f"[gemm {m}x{n}x{k}] max err {err:.3e} (sum|a||w| {scale:.3e})")
+        assert err <= 4e-7 * scale + 1e-6
+
+
+def test_first_block(tiny, full):
+    for codec, mc, w in (tiny, full):
+        x = seeded_audio(2, 1000)
+        ref = O.first_block(w, "encoder.blocks.0", x.unsqueeze(1))
+        got = G.op_plain(codec.network.context(), "l3ac_op_first_block", x.cuda(), 2, 1000, (2, 1000, mc.encoder_dims[0]))
+        _close("first_block", G.from_frames(got), ref)
+
+
+def test_conv_units(tiny, full):
+    codec, mc, w = tiny
+    for block, c in (("encoder.blocks.1.0.module", 8), ("encoder.blocks.5.1.module", 24), ("decoder.blocks.1.1.module", 32)):
+        x = _rand((2, c, 70), 10 + c)
+        ref = O.conv_unit(w, block, x)
+        got = G.op_block(codec.network.context(), "l3ac_op_conv_unit", block, G.to_frames(x), (2, 70, c))
+        _close(block, G.from_frames(got), ref)
+    codec, mc, w = full
+    for block, c, t in (("encoder.blocks.1.0.module", 24, 400), ("encoder.blocks.7.1.module", 192, 60),
+                        ("decoder.blocks.1.2.module", 512, 40), ("decoder.blocks.4.0.module", 256, 50),
+                        ("decoder.blocks.10.0.module", 48, 300)):
+        x = _rand((2, c, t), 20 + c)
+        ref = O.conv_unit(w, block, x)
+        got = G.op_block(codec.network.context(), "l3ac_op_conv_unit", block, G.to_frames(x), (2, t, c))
+        _close(block, G.from_frames(got), ref, atol=5e-5, rtol=5e-5)
+
+
+def test_down_and_k3_layers(tiny, full):
+    import torch.nn.functional as F
+    for (codec, mc, w), cases in ((tiny, [("encoder.blocks.2", 8, 16, 2, 66), ("encoder.blocks.4", 16, 24, 3, 66)]),
+                                  (full, [("encoder.blocks.2", 24, 48, 6, 600), ("encoder.blocks.6", 96, 192, 3, 90)])):
+        for block, ci, co, s, t in cases:
+            x = _rand((2, ci, t), 30 + ci)
+            ref = F.conv1d(x, w[f"{block}.0.weight"], w[f"{block}.0.bias"], stride=s)
+            ref = O.channel_norm_first(ref, w[f"{block}.1.weight"], w[f"{block}.1.bias"])
+            got = G.op_block(codec.network.context(), "l3ac_op_down_layer", block, G.to_frames(x), (2, t // s, co))
+            _close(block, G.from_frames(got), ref)
+    for (codec, mc, w), cases in ((tiny, [("encoder.blocks.6", 24, 16, 50), ("decoder.blocks.0", 16, 32, 50)]),
+                                  (full, [("encoder.blocks.8", 192, 128, 180), ("decoder.blocks.0", 128, 512, 180)])):
+        for block, ci, co, t in cases:
+            x = _rand((3, ci, t), 40 + ci)
+            ref = F.conv1d(x, w[f"{block}.weight"], w[f"{block}.bias"], padding=1)
+            got = G.op_block(codec.network.context(), "l3ac_op_conv_k3", block, G.to_frames(x), (3, t, co))
+            _close(block, G.from_frames(got), ref)
+
+
+def test_enhance_and_up_layers(tiny, full):
+    import torch.nn.functional as F
+    for (codec, mc, w), cases in ((tiny, [("decoder.blocks.2", "decoder.blocks.3", 32, 16, 3, 41)]),
+                                  (full, [("decoder.blocks.2", "decoder.blocks.3", 512, 256, 5, 180),
+                                          ("decoder.blocks.11", "decoder.blocks.12", 48, 24, 2, 700)])):
+        for eb, ub, ci, co, s, t in cases:
+            x = _rand((2, ci, t), 50 + ci)
+            ref = O.enhance_block(w, eb, x)
+            got = G.op_block(codec.network.context(), "l3ac_op_enhance", eb, G.to_frames(x), (2, t, ci))
+            _close(eb, G.from_frames(got), ref)
+            r = F.conv1d(x, w[f"{ub}.0.weight"], w[f"{ub}.0.bias"])
+            r = F.interpolate(r, scale_factor=s, mode="linear", align_corners=False)
+            r = O.channel_norm_first(r, w[f"{ub}.2.weight"], w[f"{ub}.2.bias"])
+            got = G.op_block(codec.network.context(), "l3ac_op_up_layer", ub, G.to_frames(x), (2, t * s, co))
+            _close(ub, G.from_frames(got), r)
+
+
+def test_last_block(tiny, full):
+    for (codec, mc, w), blk, t in ((tiny, "decoder.blocks.7.block", 300), (full, "decoder.blocks.13.block", 1500)):
+        c = mc.decoder_dims[-1]
+        x = _rand((2, c, t), 60)
+        r = x
+        for u, d in enumerate((1, 3, 9)):
+            r = O.legacy_unit(w, f"{blk}.0.{u}.module", r, d)
+        r = O.snake(r, w[f"{blk}.1.alpha"])
+        r = torch.tanh(torch.nn.functional.conv1d(r, w[f"{blk}.2.weight"], w[f"{blk}.2.bias"], padding=3)).squeeze(1)
+        got = G.op_plain(codec.network.context(), "l3ac_op_last_block", G.to_frames(x), 2, t, (2, t))
+        _close("last_block", got.cpu(), r, atol=5e-5, rtol=5e-5)
+
+
+def test_local_trans_single_and_multi_window(tiny, full):
+    codec, mc, w = tiny
+    for block, window, depth, t in (("en_encoder.down_trans.trans", 16, 1, 42), ("en_decoder.local_trans", 8, 2, 21),
+                                    ("en_decoder.up_trans.trans", 16, 2, 70), ("en_encoder.local_trans", 8, 2, 5)):
+        x = _rand((3, t, mc.feature_dim), 70 + t)
+        ref = O.local_trans(w, block, x, window, depth)
+        got = G.op_block(codec.network.context(), "l3ac_op_local_trans", block, x.cuda(), (3, t, mc.feature_dim))
+        _close(f"{block} T={t} W={window}", got.cpu(), ref, atol=5e-5, rtol=5e-5)
+    codec, mc, w = full
+    for block, window, depth, t in (("en_encoder.down_trans.trans", 750, 1, 180), ("en_decoder.local_trans", 250, 3, 60),
+                                    ("en_decoder.local_trans", 250, 3, 600)):
+        x = _rand((2, t, 128), 80 + t)
+        ref = O.local_trans(w, block, x, window, depth)
+        got = G.op_block(codec.network.context(), "l3ac_op_local_trans", block, x.cuda(), (2, t, 128))
+        _close(f"{block} T={t} W={window}", got.cpu(), ref, atol=1e-4, rtol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------------
+def test_fsq_known_answers_and_exactness():
+    kat = np.load(GOLDEN / "fsq_kat.npz")
+    for tag, feat in (("l7", 128), ("l9977", 128), ("even", 16), ("tiny", 16)):
+        levels = kat[f"{tag}_levels"].tolist()
+        d = len(levels)
+        g = torch.Generator().manual_seed(5)
+        w_out = (torch.rand(feat, d, generator=g) - 0.5).cuda()
+        b_out = (torch.rand(feat, generator=g) - 0.5).cuda()
+        z = torch.from_numpy(kat[f"{tag}_z"])
+        q, idx, li, _ = G.fsq_forward(None, levels, None, None, w_out, b_out, latents_in=z.cuda())
+        n_bad, ok = index_mismatch_report(idx.cpu().numpy(), kat[f"{tag}_indices"], z.numpy(), levels, tau=1e-6)
+        print(f"[fsq {tag}] {n_bad} of {z.shape[0]} indices differ from the reference (1-ulp tanh boundary cases)")
+        assert ok and n_bad <= 1
+        if n_bad == 0:
+            np.testing.assert_array_equal(li.cpu().numpy(), kat[f"{tag}_level_indices"])
+        # decode path == reference indices_to_codes followed by project_out
+        sel = torch.from_numpy(kat[f"{tag}_dec_idx"])
+        codes = torch.from_numpy(kat[f"{tag}_dec_codes"])
+        ref = codes @ w_out.cpu().T + b_out.cpu()
+        got = G.fsq_decode(sel.cuda(), levels, w_out, b_out)
+        _close(f"fsq_decode {tag}", got.cpu(), ref, atol=1e-6, rtol=1e-6)
+    # exact ties: tanh(0) = 0 -> 0.5, 1.5, 2.5, 3.5 round half-to-even to 0, 2, 2, 4 (torch.round semantics)
+    w_out = torch.zeros(8, 4).cuda()
+    b_out = torch.zeros(8).cuda()
+    _, idx, li, _ = G.fsq_forward(None, [2, 4, 6, 8], None, None, w_out, b_out, latents_in=torch.zeros(3, 4).cuda())
+    assert li.cpu().tolist() == [[0.0, 2.0, 2.0, 4.0]] * 3
+    assert idx.cpu().tolist() == [0 + 2 * 2 + 2 * 8 + 4 * 48] * 3
+
+
+def test_fsq_fused_forward_and_roundtrip(full):
+    codec, mc, w = full
+    for tag in ("1kbps", "3kbps"):
+        mc2, w2, _, _ = load_case(tag)
+        x = _rand((4096, 128), 90, 2.0)
+        q_ref, ind_ref, lat_ref = O.quantizer(w2, mc2, x)
+        dev = {k: w2[f"quantizer.{k}"].cuda() for k in ("project_in.weight", "project_in.bias", "project_out.weight", "project_out.bias")}
+        q, idx, li, lat = G.fsq_forward(x.cuda(), list(mc2.levels), dev["project_in.weight"], dev["project_in.bias"],
+                                        dev["project_out.weight"], dev["project_out.bias"], want_latents=True)
+        _close(f"latents {tag}", lat.cpu(), lat_ref, atol=2e-6, rtol=2e-6)
+        n_bad, ok = index_mismatch_report(idx.cpu().numpy(), ind_ref["indices"].numpy(), lat_ref.numpy(), mc2.levels, tau=1e-4)
+        print(f"[fsq fused {tag}] {n_bad}/4096 tokens differ (project_in summation order)")
+        assert ok and n_bad <= 4
+        # from the SAME latents the indices are bit-exact
+        q2, idx2, li2, _ = G.fsq_forward(None, list(mc2.levels), None, None, dev["project_out.weight"], dev["project_out.bias"],
+                                         latents_in=lat_ref.cuda())
+        n_bad2, ok2 = index_mismatch_report(idx2.cpu().numpy(), ind_ref["indices"].numpy(), lat_ref.numpy(), mc2.levels, tau=1e-6)
+        assert ok2 and n_bad2 <= 1
+        # to_features(indices) == q_feature, bit for bit (reference property)
+        back = G.fsq_decode(idx, list(mc2.levels), dev["project_out.weight"], dev["project_out.bias"])
+        assert torch.equal(back, q)
+        # level indices consistent with indices
+        lv = torch.tensor(mc2.levels)
+        basis = torch.cumprod(torch.tensor([1] + list(mc2.levels)[:-1]), 0)
+        assert torch.equal((li.cpu().long() * basis).sum(-1).int(), idx.cpu())
+        assert (li.cpu() >= 0).all() and (li.cpu() <= (lv - 1)).all()
+
+
+def test_vq_argmin_matches_closed_form():
+    """The explicit-codebook search reproduces the closed-form FSQ indices, near-ties excluded."""
+    for levels in ([7] * 6, [9, 9, 9, 7, 7, 7], [5, 3, 4]):
+        g = torch.Generator().manual_seed(11)
+        z = torch.randn(3000, len(levels), generator=g) * 1.2
+        _, idx_ref, _ = O.fsq_quantize(z, levels)
+        cb = O.codebook(levels)
+        got = G.vq_argmin(torch.tanh(z).cuda(), cb.cuda()).cpu()
+        lv = torch.tensor(levels, dtype=torch.float32)
+        scaled = (torch.tanh(z) + 1) / 2 * (lv - 1)
+        margin = ((scaled - scaled.floor()) - 0.5).abs().min(dim=1).values
+        clear = margin > 1e-4
+        assert clear.float().mean() > 0.99
+        assert torch.equal(got[clear], idx_ref[clear]), f"levels={levels}"
+        # brute force agrees with a CPU brute force everywhere except exact fp32 distance ties
+        d = torch.cdist(torch.tanh(z).double(), cb.double())
+        best = d.argmin(1)
+        gap = d.gather(1, got.long().unsqueeze(1)).squeeze(1) - d.gather(1, best.unsqueeze(1)).squeeze(1)
+        assert (gap.abs() < 1e-6).all()

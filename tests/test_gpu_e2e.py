@@ -1,0 +1,232 @@
+"""End-to-end parity of the drop-in surface (encode_audio / decode_audio) against the oracle and the committed
+reference vectors, plus size-independent properties at the BASELINE batch size (`pytest -m gpu`)."""
+import numpy as np
+import pytest
+import torch
+
+import l3ac_amd
+from l3ac_amd import weights as W
+from oracle import l3ac_oracle as O
+from tests import gpu_ops as G
+from tests.helpers import GOLDEN, index_mismatch_report, load_case, seeded_audio, strided
+
+pytestmark = pytest.mark.gpu
+
+TAU = 2e-3        # a flipped index must come from a latent within TAU of a rounding boundary (in level units)
+WAVE_ATOL = 2e-3  # waveform tolerance (tanh output in [-1, 1]) for the decoder given identical indices
+FEAT_ATOL = 5e-4  # encoder / transformer feature tolerance, activations O(1)
+
+
+def _codec(tag, seed):
+    cfg = GOLDEN / "tiny.toml" if tag == "tiny" else tag
+    codec = l3ac_amd.get_model(cfg, synthetic_seed=seed)
+    codec.network.to(device="cuda").eval()
+    return codec
+
+
+def _err(name, got, ref):
+    e = (got.detach().cpu().double() - ref.detach().cpu().double()).abs()
+    print(f"[{name}] max|err|={e.max().item():.3e} rms={e.pow(2).mean().sqrt().item():.3e} max|ref|={ref.abs().max().item():.3e}")
+    return e.max().item()
+
+
+@pytest.mark.parametrize("tag,seed,batch,samples", [("tiny", 3, 3, 250), ("tiny", 3, 2, 1201), ("1kbps", 0, 2, 16000),
+                                                    ("3kbps", 0, 2, 16000), ("1kbps", 0, 1, 5000)])
+def test_submodules_against_oracle(tag, seed, batch, samples):
+    codec = _codec(tag, seed)
+    ctx = codec.network.context()
+    mc = codec.network.mc
+    w = W.folded_weights(codec.network.state_dicts())
+    audio = seeded_audio(batch, samples)
+    x, _ = O.preprocess(mc, audio)
+    frames = x.shape[-1]
+    enc_rate = mc.hop_length // mc.en_coder_compress_rate
+    with torch.inference_mode():
+        feat_ref = O.encoder(w, mc, x.unsqueeze(1))
+        tok_ref = O.en_encoder(w, mc, feat_ref)
+        q_ref, ind_ref, lat_ref = O.quantizer(w, mc, tok_ref)
+        dec_in_ref = O.en_decoder(w, mc, q_ref)
+        wave_ref = O.decoder(w, mc, dec_in_ref).squeeze(1)
+    feat = G.op_plain(ctx, "l3ac_op_encoder", x.cuda(), batch, frames, (batch, frames // enc_rate, mc.feature_dim))
+    assert _err(f"{tag} encoder", G.from_frames(feat), feat_ref) < FEAT_ATOL
+    tok = G.op_plain(ctx, "l3ac_op_en_encoder", G.to_frames(feat_ref), batch, frames // enc_rate,
+                     (batch, frames // mc.hop_length, mc.feature_dim))
+    assert _err(f"{tag} en_encoder", tok.cpu(), tok_ref) < FEAT_ATOL
+    dec_in = G.op_plain(ctx, "l3ac_op_en_decoder", q_ref.cuda(), batch, frames // mc.hop_length,
+                        (batch, frames // enc_rate, mc.feature_dim))
+    assert _err(f"{tag} en_decoder", G.from_frames(dec_in), dec_in_ref) < FEAT_ATOL
+    wave = G.op_plain(ctx, "l3ac_op_decoder", G.to_frames(dec_in_ref), batch, frames // enc_rate, (batch, frames))
+    assert _err(f"{tag} decoder", wave.cpu(), wave_ref) < WAVE_ATOL
+
+
+@pytest.mark.parametrize("tag,seed,batch,samples", [("tiny", 3, 4, 250), ("1kbps", 0, 4, 16000), ("3kbps", 0, 3, 16000),
+                                                    ("1kbps", 0, 2, 16001), ("1kbps", 0, 3, 100), ("0k75bps", 1, 2, 8000),
+                                                    ("1k5bps", 1, 2, 8000)])
+def test_encode_decode_against_oracle(tag, seed, batch, samples):
+    codec = _codec(tag, seed)
+    mc = codec.network.mc
+    w = W.folded_weights(codec.network.state_dicts())
+    audio = seeded_audio(batch, samples)
+    taps = {}
+    q_ref, ind_ref = O.encode_audio(w, mc, audio, taps=taps)
+    q, ind = codec.encode_audio(audio.cuda())
+    n_tok = -(-samples // mc.hop_length)
+    assert q.shape == (batch, n_tok, mc.feature_dim) and q.dtype == torch.float32
+    assert ind["indices"].shape == (batch, n_tok) and ind["indices"].dtype == torch.int32
+    assert ind["level_indices"].shape == (batch, n_tok, len(mc.levels)) and ind["level_indices"].dtype == torch.float32
+    n_bad, ok = index_mismatch_report(ind["indices"].cpu().numpy(), ind_ref["indices"].numpy(), taps["latents"].numpy(),
+                                      mc.levels, TAU)
+    total = batch * n_tok
+    print(f"[{tag} B={batch} T={samples}] index mismatches vs oracle: {n_bad}/{total}")
+    assert ok, "an index differs by more than one level or away from a rounding boundary"
+    assert n_bad <= max(1, total // 50)
+    # decoder, given the ORACLE's indices: waveform within tolerance
+    wave_ref = O.decode_audio(w, mc, indices=ind_ref["indices"])
+    wave = codec.decode_audio(indices=ind_ref["indices"].cuda())
+    assert wave.shape == (batch, n_tok * mc.hop_length)
+    assert _err(f"{tag} wave(from oracle indices)", wave, wave_ref) < WAVE_ATOL
+    # decode_audio(q_feature) and decode_audio(indices=...) agree bit for bit on the device's own outputs
+    wave_a = codec.decode_audio(q)
+    wave_b = codec.decode_audio(indices=ind["indices"])
+    assert torch.equal(wave_a, wave_b)
+
+
+@pytest.mark.parametrize("tag", ["tiny", "1kbps", "3kbps"])
+def test_against_committed_reference_vectors(tag):
+    """tests/golden/*_e2e.npz were produced by the reference's own EnCodec wiring (see make_golden.py)."""
+    mc, w, conv, e2e = load_case(tag)
+    codec = _codec(tag, int(e2e["seed"]))
+    audio = seeded_audio(int(e2e["batch"]), int(e2e["samples"]))
+    q, ind = codec.encode_audio(audio.cuda())
+    lat = O.encode_audio(w, mc, audio, taps=(taps := {})) and taps["latents"]
+    n_bad, ok = index_mismatch_report(ind["indices"].cpu().numpy(), e2e["indices"], lat.numpy(), mc.levels, TAU)
+    print(f"[{tag}] index mismatches vs reference vectors: {n_bad}/{e2e['indices'].size}")
+    assert ok and n_bad <= max(1, e2e["indices"].size // 50)
+    wave = codec.decode_audio(indices=torch.from_numpy(e2e["indices"]).cuda()).cpu()
+    if tag == "tiny":
+        np.testing.assert_allclose(wave.numpy(), e2e["wave"], atol=WAVE_ATOL)
+    else:
+        np.testing.assert_allclose(strided(wave).numpy(), e2e["wave_strided"], atol=WAVE_ATOL)
+    # conv-stack-only vectors (reference code only): encoder feature and decoder waveform
+    ctx = codec.network.context()
+    x, _ = O.preprocess(mc, audio)
+    enc_rate = mc.hop_length // mc.en_coder_compress_rate
+    feat = G.op_plain(ctx, "l3ac_op_encoder", x.cuda(), x.shape[0], x.shape[1], (x.shape[0], x.shape[1] // enc_rate, mc.feature_dim))
+    feat = G.from_frames(feat)
+    if tag == "tiny":
+        np.testing.assert_allclose(feat.numpy(), conv["feature"], atol=FEAT_ATOL)
+        q_feat = torch.from_numpy(conv["q_feat"])
+    else:
+        np.testing.assert_allclose(strided(feat).numpy(), conv["feature_strided"], atol=FEAT_ATOL)
+        q_feat = O.to_features(w, mc, torch.from_numpy(conv["indices"]))
+    wave = G.op_plain(ctx, "l3ac_op_decoder", q_feat.cuda().contiguous(), q_feat.shape[0], q_feat.shape[1],
+                      (q_feat.shape[0], q_feat.shape[1] * enc_rate)).cpu()
+    if tag == "tiny":
+        np.testing.assert_allclose(wave.numpy(), conv["wave"], atol=WAVE_ATOL)
+    else:
+        np.testing.assert_allclose(strided(wave).numpy(), conv["wave_strided"], atol=WAVE_ATOL)
+
+
+def test_full_batch_properties_1kbps():
+    """BASELINE config 2 (1kbps, 256 x 1 s): properties that need no oracle at this size."""
+    codec = _codec("1kbps", 0)
+    mc = codec.network.mc
+    audio = seeded_audio(256, 16000).cuda()
+    q, ind = codec.encode_audio(audio)
+    idx = ind["indices"]
+    assert idx.shape == (256, 60) and int(idx.min()) >= 0 and int(idx.max()) < mc.codebook_size
+    # clips are independent: any clip processed alone gives bit-identical tokens and waveform
+    for b in (0, 101, 255):
+        q1, ind1 = codec.encode_audio(audio[b:b + 1])
+        assert torch.equal(ind1["indices"], idx[b:b + 1]) and torch.equal(q1, q[b:b + 1])
+    wave = codec.decode_audio(indices=idx)
+    assert wave.shape == (256, 16200) and torch.isfinite(wave).all() and float(wave.abs().max()) <= 1.0
+    for b in (3, 200):
+        assert torch.equal(codec.decode_audio(indices=idx[b:b + 1]), wave[b:b + 1])
+    # deterministic
+    q2, ind2 = codec.encode_audio(audio)
+    assert torch.equal(ind2["indices"], idx) and torch.equal(q2, q)
+    # right zero-padding is what the kernels assume (codec.py:79-84)
+    padded = torch.nn.functional.pad(audio[:8], (0, 200))
+    q3, ind3 = codec.encode_audio(padded)
+    assert torch.equal(ind3["indices"], idx[:8]) and torch.equal(q3, q[:8])
+    # level_indices <-> indices
+    basis = torch.cumprod(torch.tensor([1] + list(mc.levels)[:-1]), 0).cuda()
+    assert torch.equal((ind["level_indices"].long() * basis).sum(-1).int(), idx)
+    # a sample of the batch against the oracle
+    w = W.folded_weights(codec.network.state_dicts())
+    sel = [0, 77, 255]
+    taps = {}
+    _, ind_ref = O.encode_audio(w, mc, audio[sel].cpu(), taps=taps)
+    n_bad, ok = index_mismatch_report(idx[sel].cpu().numpy(), ind_ref["indices"].numpy(), taps["latents"].numpy(), mc.levels, TAU)
+    assert ok and n_bad <= 4
+
+
+def test_edge_cases():
+    codec = _codec("1kbps", 0)
+    mc = codec.network.mc
+    w = W.folded_weights(codec.network.state_dicts())
+    # digital silence: biases keep the activations alive; GRN normaliser must still be 1
+    silent = torch.zeros(2, 4000)
+    taps = {}
+    _, ind_ref = O.encode_audio(w, mc, silent, taps=taps)
+    q, ind = codec.encode_audio(silent.cuda())
+    n_bad, ok = index_mismatch_report(ind["indices"].cpu().numpy(), ind_ref["indices"].numpy(), taps["latents"].numpy(), mc.levels, TAU)
+    assert ok and n_bad <= 1
+    wave = codec.decode_audio(indices=ind_ref["indices"].cuda())
+    assert _err("silence wave", wave, O.decode_audio(w, mc, indices=ind_ref["indices"])) < WAVE_ATOL
+    # full-scale input, and a non-contiguous view
+    loud = seeded_audio(2, 3000) * 2.0
+    q, ind = codec.encode_audio(loud.cuda())
+    taps = {}
+    _, ind_ref = O.encode_audio(w, mc, loud, taps=taps)
+    n_bad, ok = index_mismatch_report(ind["indices"].cpu().numpy(), ind_ref["indices"].numpy(), taps["latents"].numpy(), mc.levels, TAU)
+    assert ok and n_bad <= 2
+    big = seeded_audio(4, 6001).cuda()
+    view = big[::2, 1:6001]
+    qa, ia = codec.encode_audio(view)
+    qb, ib = codec.encode_audio(view.contiguous())
+    assert torch.equal(ia["indices"], ib["indices"]) and torch.equal(qa, qb)
+    # exact GRN (two-pass g / (g + eps)) agrees with the fast path on ordinary input
+    exact = l3ac_amd.get_model("1kbps", synthetic_seed=0)
+    exact.network.grn_exact = True
+    exact.network.to(device="cuda").eval()
+    x = seeded_audio(2, 8000).cuda()
+    q1, i1 = codec.encode_audio(x)
+    q2, i2 = exact.encode_audio(x)
+    assert torch.equal(i1["indices"], i2["indices"])
+    assert _err("grn exact vs fast (features)", q1, q2) < 1e-5
+    assert _err("grn exact vs fast (wave)", codec.decode_audio(q1), exact.decode_audio(q1)) < 1e-5
+    # errors are loud
+    with pytest.raises(RuntimeError):
+        codec.encode_audio(torch.zeros(1, 1000))  # CPU tensor: no CPU path
+    with pytest.raises(ValueError):
+        codec.encode_audio(torch.zeros(1000).cuda())
+    with pytest.raises(ValueError):
+        codec.decode_audio()
+
+
+def test_streaming_chunks_and_graph_capture():
+    """BASELINE config 5: 1 s chunks through a captured graph give the same tokens as eager calls."""
+    codec = _codec("1kbps", 0)
+    ctx = codec.network.context()
+    ctx.reserve(1, 16000)
+    chunks = seeded_audio(6, 16000).cuda()
+    eager = [codec.encode_audio(chunks[i:i + 1]) for i in range(6)]
+    eager_wave = [codec.decode_audio(indices=e[1]["indices"]) for e in eager]
+    static_in = torch.zeros(1, 16000, device="cuda")
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        codec.encode_audio(static_in)
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        q, ind = codec.encode_audio(static_in)
+        wave = codec.decode_audio(indices=ind["indices"])
+    for i in range(6):
+        static_in.copy_(chunks[i:i + 1])
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(ind["indices"], eager[i][1]["indices"])
+        assert torch.equal(wave, eager_wave[i])

@@ -1,0 +1,117 @@
+"""CPU-side tests: config / weight plumbing, the drop-in surface's error behaviour, and that the C-ABI library
+loads and exports every symbol include/l3ac_hip.h declares (no compute without a GPU)."""
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+import torch
+
+import l3ac_amd
+from l3ac_amd import _capi, weights as W
+from l3ac_amd.config import L3ACConfig, ModelConfig, resolve_config_file
+from tests.helpers import GOLDEN
+
+REPO = Path(__file__).resolve().parent.parent
+
+
+def test_list_models_and_geometry():
+    assert l3ac_amd.list_models() == ["0k75bps", "1k5bps", "1kbps", "3kbps"]
+    want = {"0k75bps": (360, 117649, 748.6), "1kbps": (270, 117649, 998.2), "1k5bps": (180, 117649, 1497.3),
+            "3kbps": (96, 250047, 2988.6)}  # reference README.md:73-76
+    for name, (hop, k, bps) in want.items():
+        cfg = L3ACConfig(config_file=resolve_config_file(name))
+        mc = cfg.network_config
+        assert cfg.sample_rate == 16000 and cfg.model_tag == f"{name}.v1"
+        assert mc.hop_length == hop and mc.codebook_size == k
+        info = l3ac_amd.get_model_info(l3ac_amd.L3AC(cfg))
+        assert abs(info["bps"] - bps) < 0.06
+        assert cfg.weight_url.startswith("https://huggingface.co/zhai-lw/L3AC/resolve/main/weights/" + name)
+        assert cfg.model_path == Path.home() / ".cache" / "l3ac" / f"{name}.v1"
+
+
+def test_config_validation():
+    with pytest.raises(Exception):
+        ModelConfig(encoder_dims=(1, 2), encoder_depths=(1,), compress_rates=(2,))
+    with pytest.raises(Exception):
+        ModelConfig(bogus_key=1)
+    with pytest.raises(NotImplementedError):
+        ModelConfig(decoder_last_layer="dilation", en_coder_dynamic_pos=True).check_supported()
+    with pytest.raises(FileNotFoundError):
+        resolve_config_file("no_such_model")
+
+
+def test_parameter_counts_match_survey():
+    mc = L3ACConfig(config_file=resolve_config_file("1kbps")).network_config
+    count = lambda m: sum(int(torch.Size(s).numel()) for _, s in W.raw_keys(mc, m))
+    assert count("encoder") == 869316 and count("quantizer") == 1670 and count("decoder") == 8494082
+    assert len(W.raw_keys(mc, "encoder")) == 109 and len(W.raw_keys(mc, "decoder")) == 241
+
+
+def test_synthetic_weights_are_deterministic_and_fold():
+    mc = L3ACConfig(config_file=GOLDEN / "tiny.toml").network_config
+    a = W.synthetic_state_dicts(mc, seed=3)
+    b = W.synthetic_state_dicts(mc, seed=3)
+    c = W.synthetic_state_dicts(mc, seed=4)
+    for m in W.MODULE_NAMES:
+        for k in a[m]:
+            assert torch.equal(a[m][k], b[m][k])
+    assert not torch.equal(a["encoder"]["blocks.0.conv_1.bias"], c["encoder"]["blocks.0.conv_1.bias"])
+    W.check_state_dicts(a, mc)
+    folded = W.folded_weights(a)
+    g = a["encoder"]["blocks.0.conv_1.parametrizations.weight.original0"]
+    v = a["encoder"]["blocks.0.conv_1.parametrizations.weight.original1"]
+    w = folded["encoder.blocks.0.conv_1.weight"]
+    assert torch.allclose(w, g * v / v.reshape(80, -1).norm(dim=1).reshape(80, 1, 1), atol=1e-7)
+    assert torch.allclose(w.reshape(80, -1).norm(dim=1), g.reshape(-1), rtol=1e-5)
+    assert not any("parametrizations" in k for k in folded)
+    bad = {m: dict(sd) for m, sd in a.items()}
+    del bad["decoder"]["blocks.0.bias"]
+    with pytest.raises(KeyError):
+        W.check_state_dicts(bad, mc)
+
+
+def test_weight_files_roundtrip(tmp_path):
+    cfg = L3ACConfig(config_file=GOLDEN / "tiny.toml", model_dir=tmp_path)
+    sds = W.synthetic_state_dicts(cfg.network_config, seed=1)
+    W.save_state_dicts(sds, cfg.model_path)
+    assert sorted(p.name for p in cfg.model_path.iterdir()) == sorted(f"{m}.pt" for m in W.MODULE_NAMES)
+    codec = l3ac_amd.get_model(GOLDEN / "tiny.toml", model_dir=tmp_path)
+    assert torch.equal(codec.network.state_dicts()["decoder"]["blocks.0.bias"], sds["decoder"]["blocks.0.bias"])
+    (cfg.model_path / "decoder.pt").unlink()
+    with pytest.raises(FileNotFoundError):
+        l3ac_amd.get_model(GOLDEN / "tiny.toml", model_dir=tmp_path)
+    with pytest.raises(FileNotFoundError):
+        l3ac_amd.get_model("1kbps", model_dir=tmp_path / "nowhere")
+
+
+def test_no_cpu_fallback():
+    codec = l3ac_amd.get_model(GOLDEN / "tiny.toml", synthetic_seed=3)
+    with pytest.raises(RuntimeError, match="eval"):
+        codec.encode_audio(torch.zeros(1, 100))
+    codec.network.eval()
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        codec.encode_audio(torch.zeros(1, 100))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        codec.decode_audio(indices=torch.zeros(1, 4, dtype=torch.int32))
+    with pytest.raises(NotImplementedError):
+        codec.network.train()
+    x, n = codec.network.preprocess(torch.zeros(2, 25))
+    assert x.shape == (2, 36) and n == 25
+
+
+def test_library_exports_every_declared_symbol():
+    header = (REPO / "include" / "l3ac_hip.h").read_text()
+    declared = set(re.findall(r"\b(l3ac_[a-z0-9_]+)\s*\(", header))
+    declared -= {"l3ac_ctx"}
+    assert len(declared) >= 25
+    assert declared == set(_capi.SIGNATURES), declared ^ set(_capi.SIGNATURES)
+    lib = _capi.load_library()  # raises if the .so is missing or a symbol is absent
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.l3ac_abi_version() == _capi.ABI_VERSION
+    # struct layout agrees with the header (9 scalars + 6 stage arrays + the level array)
+    assert ctypes.sizeof(_capi.Config) == 4 * (9 + 6 * _capi.MAX_STAGES + _capi.MAX_LEVELS)
+    # argument validation happens before any device work
+    assert lib.l3ac_reserve(None, 1, 1) != 0 and b"null context" in lib.l3ac_last_error()
+    assert lib.l3ac_hop_length(None) == 0
