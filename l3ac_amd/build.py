@@ -28,6 +28,7 @@ SOURCES = [
     "kernels/enhance.hip",
     "kernels/attention.hip",
     "kernels/fsq.hip",
+    "kernels/conv_unit_fused.hip",
 ]
 
 

@@ -1,0 +1,291 @@
+// Fused ConvUnit for the narrow stages (C = 24 / 48 / 96), reference l3ac/modules.py:10-41 + Residual
+// (l3ac/xtract/nn/layers.py:59-62):
+//
+//     y = x + pw_conv2( GRN( snake( pw_conv1( LayerNorm( dw_conv7(x) ) ) ) ) )
+//
+// Unfused, the 4C-wide hidden tensor makes two HBM round trips and the channel contractions have K = 24..96,
+// far too short for a tiled GEMM.  Here one WAVE owns 32 consecutive frames of one clip end to end:
+//
+//   * the products are evaluated TRANSPOSED:  X[n][m] = W1[n][:] . a[m][:]   (n = hidden channel, m = frame)
+//     so the 32x32 accumulator tile has the hidden channel on its ROWS (registers) and the frame on its LANES.
+//     snake / GRN are applied to the accumulator registers, and the tile is then used directly as the B operand
+//     of the second product  Y[c][m] = W2[c][:] . X[:][m]  — the reduction runs over X's row index, which is
+//     exactly what v_mfma_f32_32x32x2_f32 takes from a register without any lane movement (register r of lane
+//     half h is row (r&3) + 8(r>>2) + 4h; the W2 fragment is fetched in the same order).  The hidden activations
+//     never leave registers: no LDS transpose, no HBM traffic.
+//   * C = 24 / 48: W1, W2 stay resident in LDS for the lifetime of a persistent workgroup and the waves never
+//     synchronise.  C = 96: the weights (295 KB) are streamed through LDS in chunks of HC hidden channels, L2-served,
+//     one block-wide barrier pair per chunk.
+//   * lane (j, h) computes the depth-wise conv + LayerNorm of frame j for the channels k = 8q + 4h + {0..3} it
+//     later feeds to the MFMAs as the B operand, from a per-wave LDS copy of the 38 input rows (halo 3 + 3).
+//   * the first product of hidden tile nt+1 is issued before the activation of tile nt, so the MFMA pipe and the
+//     VALU overlap inside one wave; fp32 throughout; bias vectors enter as the initial accumulator value.
+//
+// HBM traffic per frame: C floats in (+ 6/32 halo re-read, L2-served) and C floats out; the bound of this kernel
+// is the fp32 MFMA rate (16 C^2 FLOP per frame, + the channel padding of the second product to 32 ceil(C/32)).
+#include "../kernels.hpp"
+#include "../network.hpp"
+#include "device_math.hpp"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int C, int HC>
+struct Geo {
+    static constexpr int H4 = 4 * C;          // hidden width
+    static constexpr int NCH = H4 / HC;       // weight chunks (1 = resident)
+    static constexpr int NTC = HC / 32;       // hidden tiles per chunk
+    static constexpr int CT = (C + 31) / 32;  // output-channel tiles
+    static constexpr int KQ = C / 8;          // k groups of the first product
+    static constexpr int XS = C + 4;          // padded row strides (odd number of 16-B slots: conflict-free b128)
+    static constexpr int W1S = C + 4;
+    static constexpr int W2S = HC + 4;
+    static constexpr int ROWS = 38;           // 32 frames + 3 + 3 halo
+    // LDS carve (floats)
+    static constexpr int OFF_W1 = 0;                          // [HC][W1S]
+    static constexpr int OFF_W2 = OFF_W1 + HC * W1S;          // [C + 1][W2S], last row all zeros (padding channels)
+    static constexpr int OFF_P = OFF_W2 + (C + 1) * W2S;      // (alpha, 1/alpha, gamma, beta) per hidden channel
+    static constexpr int OFF_B1 = OFF_P + H4 * 4;
+    static constexpr int OFF_B2 = OFF_B1 + H4;
+    static constexpr int OFF_DW = OFF_B2 + 32 * CT;           // dw_w [7][C], dw_b, ln_w, ln_b
+    static constexpr int OFF_XS = OFF_DW + 10 * C;
+    static constexpr int xs_floats = ROWS * XS;
+    static constexpr int lds_floats(int waves) { return OFF_XS + waves * xs_floats; }
+    static_assert(H4 % HC == 0 && HC % 32 == 0 && C % 8 == 0, "bad geometry");
+};
+
+__device__ __forceinline__ int rowmap(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+
+template <int C, int WAVES, int HC>
+__global__ __launch_bounds__(64 * WAVES) void conv_unit_fused_kernel(const ConvUnitW w, const float* __restrict__ x,
+                                                                    float* __restrict__ y, int batch, int frames) {
+    using G = Geo<C, HC>;
+    constexpr bool RESIDENT = G::NCH == 1;
+    constexpr int THREADS = 64 * WAVES;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* W1s = smem + G::OFF_W1;
+    float* W2s = smem + G::OFF_W2;
+    float* Ps = smem + G::OFF_P;
+    float* B1s = smem + G::OFF_B1;
+    float* B2s = smem + G::OFF_B2;
+    float* DWs = smem + G::OFF_DW;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* xs = smem + G::OFF_XS + wave * G::xs_floats;
+
+    auto stage_weights = [&](int chunk) {  // hidden channels [chunk * HC, (chunk + 1) * HC)
+        for (int i = tid; i < HC * (C / 4); i += THREADS) {
+            const int row = i / (C / 4), ch = i % (C / 4);
+            *reinterpret_cast<float4*>(W1s + row * G::W1S + 4 * ch) =
+                *reinterpret_cast<const float4*>(w.w1 + (int64_t)(chunk * HC + row) * C + 4 * ch);
+        }
+        for (int i = tid; i < (C + 1) * (HC / 4); i += THREADS) {
+            const int row = i / (HC / 4), ch = i % (HC / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < C) v = *reinterpret_cast<const float4*>(w.w2 + (int64_t)row * G::H4 + chunk * HC + 4 * ch);
+            *reinterpret_cast<float4*>(W2s + row * G::W2S + 4 * ch) = v;
+        }
+    };
+
+    // ---- parameters resident for the lifetime of the workgroup -------------------------------------------
+    for (int i = tid; i < G::H4; i += THREADS) {
+        *reinterpret_cast<float4*>(Ps + 4 * i) = make_float4(w.alpha[i], w.inv_alpha[i], w.gamma[i], w.beta[i]);
+        B1s[i] = w.b1[i];
+    }
+    for (int i = tid; i < 32 * G::CT; i += THREADS) B2s[i] = i < C ? w.b2[i] : 0.f;
+    for (int i = tid; i < 7 * C; i += THREADS) DWs[i] = w.dw_w[i];
+    for (int i = tid; i < C; i += THREADS) {
+        DWs[7 * C + i] = w.dw_b[i];
+        DWs[8 * C + i] = w.ln_w[i];
+        DWs[9 * C + i] = w.ln_b[i];
+    }
+    if (RESIDENT) stage_weights(0);
+    __syncthreads();
+
+    const int lj = lane & 31;  // frame within the tile (MFMA column) / weight row within a tile (A operand)
+    const int lh = lane >> 5;
+    const int tiles_per_clip = (frames + 31) / 32;
+    const int64_t n_tiles = (int64_t)batch * tiles_per_clip;
+
+    // every wave of the block runs the same number of iterations (the chunked variant has block barriers inside)
+    for (int64_t base = (int64_t)blockIdx.x * WAVES; base < n_tiles; base += (int64_t)gridDim.x * WAVES) {
+        const int64_t tile = base + wave;
+        const bool tile_ok = tile < n_tiles;
+        const int b = tile_ok ? (int)(tile / tiles_per_clip) : 0;
+        const int t0 = tile_ok ? (int)(tile % tiles_per_clip) * 32 : 0;
+        const float* clip = x + (int64_t)b * frames * C;
+
+        // ---- stage rows [t0 - 3, t0 + 35) of this clip into the wave's LDS copy (zeros outside the clip) ----
+        for (int i = lane; i < G::ROWS * (C / 4); i += 64) {
+            const int row = i / (C / 4), ch = i % (C / 4);
+            const int t = t0 - 3 + row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tile_ok && t >= 0 && t < frames) v = *reinterpret_cast<const float4*>(clip + (int64_t)t * C + 4 * ch);
+            *reinterpret_cast<float4*>(xs + row * G::XS + 4 * ch) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // ---- depth-wise conv k7 + LayerNorm for frame lj, channels k = 8q + 4 lh + r --------------------
+        float a[4 * G::KQ];
+        float s1 = 0.f;
+#pragma unroll
+        for (int q = 0; q < G::KQ; ++q) {
+            const int k0 = 8 * q + 4 * lh;
+            float4 acc = *reinterpret_cast<const float4*>(DWs + 7 * C + k0);
+#pragma unroll
+            for (int tap = 0; tap < 7; ++tap) {
+                const float4 xv = *reinterpret_cast<const float4*>(xs + (lj + tap) * G::XS + k0);
+                const float4 wv = *reinterpret_cast<const float4*>(DWs + tap * C + k0);
+                acc.x = fmaf(xv.x, wv.x, acc.x);
+                acc.y = fmaf(xv.y, wv.y, acc.y);
+                acc.z = fmaf(xv.z, wv.z, acc.z);
+                acc.w = fmaf(xv.w, wv.w, acc.w);
+            }
+            a[4 * q] = acc.x; a[4 * q + 1] = acc.y; a[4 * q + 2] = acc.z; a[4 * q + 3] = acc.w;
+            s1 += (acc.x + acc.y) + (acc.z + acc.w);
+        }
+        s1 += __shfl_xor(s1, 32, 64);
+        const float mean = s1 / (float)C;
+        float s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4 * G::KQ; ++i) {
+            const float d = a[i] - mean;
+            s2 = fmaf(d, d, s2);
+        }
+        s2 += __shfl_xor(s2, 32, 64);
+        const float rstd = 1.0f / sqrtf(s2 / (float)C + 1e-8f);
+        const bool frame_ok = tile_ok && t0 + lj < frames;
+#pragma unroll
+        for (int q = 0; q < G::KQ; ++q) {
+            const int k0 = 8 * q + 4 * lh;
+            const float4 g = *reinterpret_cast<const float4*>(DWs + 8 * C + k0);
+            const float4 be = *reinterpret_cast<const float4*>(DWs + 9 * C + k0);
+            a[4 * q] = frame_ok ? (a[4 * q] - mean) * rstd * g.x + be.x : 0.f;
+            a[4 * q + 1] = frame_ok ? (a[4 * q + 1] - mean) * rstd * g.y + be.y : 0.f;
+            a[4 * q + 2] = frame_ok ? (a[4 * q + 2] - mean) * rstd * g.z + be.z : 0.f;
+            a[4 * q + 3] = frame_ok ? (a[4 * q + 3] - mean) * rstd * g.w + be.w : 0.f;
+        }
+
+        // ---- output accumulators start at the pw_conv2 bias ---------------------------------------------
+        f32x16 yacc[G::CT];
+#pragma unroll
+        for (int ct = 0; ct < G::CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) yacc[ct][r] = B2s[32 * ct + rowmap(r, lh)];
+
+#pragma unroll 1
+        for (int chunk = 0; chunk < G::NCH; ++chunk) {
+            if (!RESIDENT) {
+                __syncthreads();  // every wave is done with the previous chunk's weights
+                stage_weights(chunk);
+                __syncthreads();
+            }
+            const int n_base = chunk * HC;
+            // X[n][m] = b1[n] + sum_k W1[n][k] a[m][k] for hidden tile ntl of this chunk
+            auto first_product = [&](int ntl) -> f32x16 {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = B1s[n_base + 32 * ntl + rowmap(r, lh)];
+#pragma unroll
+                for (int q = 0; q < G::KQ; ++q) {
+                    const float4 wf = *reinterpret_cast<const float4*>(W1s + (32 * ntl + lj) * G::W1S + 8 * q + 4 * lh);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.x, a[4 * q], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.y, a[4 * q + 1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.z, a[4 * q + 2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.w, a[4 * q + 3], acc, 0, 0, 0);
+                }
+                return acc;
+            };
+            // software pipeline: tile ntl+1's first product (MFMA pipe) runs beside tile ntl's activation (VALU)
+            f32x16 xnext = first_product(0);
+#pragma unroll 1
+            for (int ntl = 0; ntl < G::NTC; ++ntl) {
+                f32x16 xacc = xnext;
+                if (ntl + 1 < G::NTC) xnext = first_product(ntl + 1);
+                // snake + GRN (normaliser == 1) on the accumulator registers (layers.py:29-33, :112-115)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float4 pr = *reinterpret_cast<const float4*>(Ps + 4 * (n_base + 32 * ntl + rowmap(r, lh)));
+                    const float s = snake_act(xacc[r], pr.x, pr.y);
+                    xacc[r] = (pr.z * s + pr.w) + s;
+                }
+                // Y[c][m] += sum_n W2[c][n] X[n][m]: X's registers are the B operand, row order (r&3)+8(r>>2)+4h
+#pragma unroll
+                for (int ct = 0; ct < G::CT; ++ct) {
+                    const int crow = (32 * ct + lj) < C ? 32 * ct + lj : C;  // padding channels read the zero row
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 wf = *reinterpret_cast<const float4*>(W2s + crow * G::W2S + 32 * ntl + 8 * g + 4 * lh);
+                        yacc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.x, xacc[4 * g], yacc[ct], 0, 0, 0);
+                        yacc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.y, xacc[4 * g + 1], yacc[ct], 0, 0, 0);
+                        yacc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.z, xacc[4 * g + 2], yacc[ct], 0, 0, 0);
+                        yacc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.w, xacc[4 * g + 3], yacc[ct], 0, 0, 0);
+                    }
+                }
+            }
+        }
+
+        // ---- residual + store: lane (frame lj, half lh) owns channels 32 ct + 8 g + 4 lh + {0..3} -------
+        if (frame_ok) {
+            float* dst = y + ((int64_t)b * frames + t0 + lj) * C;
+#pragma unroll
+            for (int ct = 0; ct < G::CT; ++ct)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c0 = 32 * ct + 8 * g + 4 * lh;
+                    if (c0 < C) {
+                        const float4 xr = *reinterpret_cast<const float4*>(xs + (lj + 3) * G::XS + c0);
+                        *reinterpret_cast<float4*>(dst + c0) =
+                            make_float4(xr.x + yacc[ct][4 * g], xr.y + yacc[ct][4 * g + 1], xr.z + yacc[ct][4 * g + 2],
+                                        xr.w + yacc[ct][4 * g + 3]);
+                    }
+                }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int C, int WAVES, int HC>
+int launch_fused(hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames, const char* name) {
+    using G = Geo<C, HC>;
+    const size_t lds = (size_t)G::lds_floats(WAVES) * sizeof(float);
+    static_assert(G::lds_floats(WAVES) * sizeof(float) <= 160 * 1024, "LDS budget exceeded");
+    static bool configured = false;
+    if (!configured) {
+        L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_unit_fused_kernel<C, WAVES, HC>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = true;
+    }
+    const int64_t tiles = (int64_t)batch * ((frames + 31) / 32);
+    const int per_cu = lds > 80 * 1024 ? 1 : 2;
+    int64_t blocks = ceil_div64(tiles, WAVES);
+    if (blocks > 256 * per_cu) blocks = 256 * per_cu;
+    const double rows = (double)batch * frames;
+    ProfScope prof(s, name, rows * (14.0 * C + 16.0 * C * C), rows * 8.0 * C);
+    hipLaunchKernelGGL((conv_unit_fused_kernel<C, WAVES, HC>), dim3((unsigned)blocks), dim3(64 * WAVES), lds, s, w, x, y, batch,
+                       frames);
+    L3AC_LAUNCH_CHECK();
+    return L3AC_OK;
+}
+
+}  // namespace
+
+bool conv_unit_fused_supported(int c) { return c == 24 || c == 48 || c == 96; }
+
+// In-place use is NOT allowed: a neighbouring wave's halo rows could already have been overwritten.
+int launch_conv_unit_fused(hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames) {
+    L3AC_REQUIRE(x != y, "conv_unit_fused: in-place operation is not supported");
+    switch (w.c) {
+        case 24: return launch_fused<24, 8, 96>(s, w, x, y, batch, frames, "conv_unit_fused_kernel<24>");
+        case 48: return launch_fused<48, 8, 192>(s, w, x, y, batch, frames, "conv_unit_fused_kernel<48>");
+        case 96: return launch_fused<96, 4, 96>(s, w, x, y, batch, frames, "conv_unit_fused_kernel<96>");
+        default:
+            l3ac_set_error("conv_unit_fused: C=%d not supported", w.c);
+            return L3AC_EINVAL;
+    }
+}

@@ -1,0 +1,29 @@
+// Device-side scalar helpers shared by the kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+// sin(u)^2 for the snake activation (reference l3ac/layers.py:29-33: torch.sin(alpha * x).pow(2)).
+// Quadrant reduction n = rint(u * 2/pi), r = u - n * pi/2 with a two-term Cody-Waite constant (the fma makes the
+// first step exact), then the cephes single-precision sine kernel on [-pi/4, pi/4] (|err| < 1 ulp there), and
+// sin(u)^2 = s^2 for even n, 1 - s^2 for odd n (no cancellation: s^2 <= 1/2).  Absolute error ~1e-7 for
+// |u| < 1e5 — the accuracy of sinf()^2 — at about a third of the instructions of the OCML sinf, which carries a
+// Payne-Hanek branch the activations of this network never need.
+__device__ __forceinline__ float sin_squared(float u) {
+    const float n = rintf(u * 0.636619772367581343f);
+    float r = fmaf(n, -1.57079637050628662109375f, u);
+    r = fmaf(n, 4.37113900018624283e-8f, r);
+    const float z = r * r;
+    float p = fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+    p = fmaf(p, z, -1.6666654611e-1f);
+    const float s = fmaf(p * z, r, r);
+    const float s2 = s * s;
+    return ((int)n & 1) ? 1.0f - s2 : s2;
+}
+
+// snake(h) = h + (alpha + 1e-8)^-1 * sin(alpha * h)^2
+__device__ __forceinline__ float snake_act(float h, float alpha, float inv_alpha) {
+    return fmaf(inv_alpha, sin_squared(alpha * h), h);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

@@ -10,13 +10,13 @@
 // (count_include_pad), its window summed left to right.  The 1x1 convs run on the VALU with wave-uniform
 // (scalar-loaded) weights: ~3.7 kFMA per frame against 4 B read + 4*d0 B written — compute-bound on fp32 VALU.
 #include "../kernels.hpp"
+#include "device_math.hpp"
 
 namespace {
 
 constexpr int TILE = 256;
 constexpr int HALO = 47;  // 3 (conv) + 22 (avg 45) + 22 (max 45)
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 template <int D0>
 __global__ __launch_bounds__(TILE) void first_block_kernel(const FirstBlockW w, const float* __restrict__ audio,

@@ -17,6 +17,7 @@
 //   * A can be an implicit 1-D convolution (taps > 1): row m = (clip b, frame t) gathers frames
 //     t + (tap - taps/2) * dil of the same clip, zero outside it — no im2col buffer.
 #include "../kernels.hpp"
+#include "device_math.hpp"
 
 namespace {
 
@@ -30,12 +31,6 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {  // float index of 
     return row * BK + ((chunk ^ ((row >> 1) & 7)) << 2);
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-
-__device__ __forceinline__ float snake_f(float h, float alpha, float inv_alpha) {
-    const float s = sinf(alpha * h);
-    return h + inv_alpha * (s * s);
-}
 
 template <int NT, bool CONV>
 __global__ __launch_bounds__(THREADS, 2) void gemm_f32_kernel(const GemmArgs p) {
@@ -195,9 +190,9 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_f32_kernel(const GemmArgs p) 
             if (p.epi == EPI_BIAS_RES) {
                 v = p.res[m * p.ldres + n] + v;
             } else if (p.epi == EPI_SNAKE) {
-                v = snake_f(v, alpha, inv_alpha);
+                v = snake_act(v, alpha, inv_alpha);
             } else if (p.epi == EPI_SNAKE_GRN) {
-                const float s = snake_f(v, alpha, inv_alpha);
+                const float s = snake_act(v, alpha, inv_alpha);
                 v = (gamma * s + beta) + s;  // layers.py:115 with the normaliser n_x == 1.0f
             }
             p.c[m * p.ldc + n] = v;

@@ -13,6 +13,7 @@
 // (so c <= 8 * LPR), loads are 16 B per lane and contiguous across the group; mean / variance are two-pass in
 // registers with a butterfly over the group.
 #include "../kernels.hpp"
+#include "device_math.hpp"
 
 namespace {
 
@@ -168,17 +169,11 @@ __global__ __launch_bounds__(THREADS) void snake_kernel(const float* __restrict_
         const float4 v = reinterpret_cast<const float4*>(x)[i];
         const float4 a = *reinterpret_cast<const float4*>(alpha + c0);
         const float4 ia = *reinterpret_cast<const float4*>(inv_alpha + c0);
-        float4 o;
-        float s;
-        s = sinf(a.x * v.x); o.x = v.x + ia.x * (s * s);
-        s = sinf(a.y * v.y); o.y = v.y + ia.y * (s * s);
-        s = sinf(a.z * v.z); o.z = v.z + ia.z * (s * s);
-        s = sinf(a.w * v.w); o.w = v.w + ia.w * (s * s);
+        const float4 o = make_float4(snake_act(v.x, a.x, ia.x), snake_act(v.y, a.y, ia.y), snake_act(v.z, a.z, ia.z),
+                                     snake_act(v.w, a.w, ia.w));
         reinterpret_cast<float4*>(y)[i] = o;
     }
 }
-
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 __global__ __launch_bounds__(THREADS) void geglu_kernel(const float* __restrict__ h, int64_t ldh, float* __restrict__ y,
                                                        int64_t ldy, int64_t rows, int inner) {

@@ -493,7 +493,19 @@ int workspace_ensure_clip(l3ac_ctx* ctx, int batch, int samples, hipStream_t s) 
 // ---------------------------------------------------------------------------------------------------------
 // blocks
 // ---------------------------------------------------------------------------------------------------------
+int conv_unit_step(l3ac_ctx* ctx, hipStream_t s, const ConvUnitW& w, float** cur, float** alt, int batch, int frames) {
+    if (!ctx->cfg.grn_exact && conv_unit_fused_supported(w.c)) {
+        L3AC_TRY(launch_conv_unit_fused(s, w, *cur, *alt, batch, frames));
+        float* t = *cur;
+        *cur = *alt;
+        *alt = t;
+        return L3AC_OK;
+    }
+    return run_conv_unit(ctx, s, w, *cur, *cur, batch, frames);
+}
+
 int run_conv_unit(l3ac_ctx* ctx, hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames) {
+    if (!ctx->cfg.grn_exact && x != y && conv_unit_fused_supported(w.c)) return launch_conv_unit_fused(s, w, x, y, batch, frames);
     const int64_t rows = (int64_t)batch * frames;
     Workspace& ws = ctx->ws;
     RowArgs r{};  // dw_conv + LayerNorm (modules.py:33-35)
@@ -631,7 +643,7 @@ int run_encoder(l3ac_ctx* ctx, hipStream_t s, const float* audio, int64_t audio_
     L3AC_TRY(launch_first_block(s, ctx->first, audio, audio_stride, batch, samples, frames, *cur));
     int f = frames;
     for (int i = 0; i < c.n_enc; ++i) {
-        for (const ConvUnitW& u : ctx->enc_units[i]) L3AC_TRY(run_conv_unit(ctx, s, u, *cur, *cur, batch, f));
+        for (const ConvUnitW& u : ctx->enc_units[i]) L3AC_TRY(conv_unit_step(ctx, s, u, cur, alt, batch, f));
         if (i + 1 < c.n_enc) {
             L3AC_TRY(run_down(ctx, s, ctx->enc_down[i], *cur, *alt, batch, f));
             swap_bufs(cur, alt);
@@ -681,7 +693,7 @@ int run_decoder(l3ac_ctx* ctx, hipStream_t s, int batch, int frames, float** cur
     swap_bufs(cur, alt);
     int f = frames;
     for (int i = 0; i + 1 < c.n_dec; ++i) {
-        for (const ConvUnitW& u : ctx->dec_units[i]) L3AC_TRY(run_conv_unit(ctx, s, u, *cur, *cur, batch, f));
+        for (const ConvUnitW& u : ctx->dec_units[i]) L3AC_TRY(conv_unit_step(ctx, s, u, cur, alt, batch, f));
         L3AC_TRY(run_enhance(ctx, s, ctx->dec_enh[i], *cur, *cur, batch, f));
         L3AC_TRY(run_up(ctx, s, ctx->dec_up[i], *cur, *alt, *cur, batch, f));
         f *= c.decode_rates[i];

@@ -92,6 +92,12 @@ int workspace_ensure(l3ac_ctx* ctx, size_t x_floats, size_t a_floats, size_t h_f
                      hipStream_t s);
 int workspace_ensure_clip(l3ac_ctx* ctx, int batch, int samples, hipStream_t s);
 
+// fused ConvUnit for the narrow stages (kernels/conv_unit_fused.hip); x must not alias y
+bool conv_unit_fused_supported(int c);
+int launch_conv_unit_fused(hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames);
+// one ConvUnit of a stage on the ping-pong buffers: fused kernel (result in *alt, buffers swapped) or in place
+int conv_unit_step(l3ac_ctx* ctx, hipStream_t s, const ConvUnitW& w, float** cur, float** alt, int batch, int frames);
+
 // blocks (x may alias y where noted)
 int run_conv_unit(l3ac_ctx* ctx, hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames);  // x == y ok
 int run_down(l3ac_ctx* ctx, hipStream_t s, const DownW& w, const float* x, float* y, int batch, int frames);

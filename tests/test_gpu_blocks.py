@@ -79,7 +79,9 @@ def test_conv_units(tiny, full):
     codec, mc, w = full
     for block, c, t in (("encoder.blocks.1.0.module", 24, 400), ("encoder.blocks.7.1.module", 192, 60),
                         ("decoder.blocks.1.2.module", 512, 40), ("decoder.blocks.4.0.module", 256, 50),
-                        ("decoder.blocks.10.0.module", 48, 300)):
+                        ("decoder.blocks.10.0.module", 48, 300), ("encoder.blocks.5.0.module", 96, 130),
+                        ("decoder.blocks.7.1.module", 96, 77), ("encoder.blocks.3.0.module", 48, 31),
+                        ("encoder.blocks.1.0.module", 24, 1)):
         x = _rand((2, c, t), 20 + c)
         ref = O.conv_unit(w, block, x)
         got = G.op_block(codec.network.context(), "l3ac_op_conv_unit", block, G.to_frames(x), (2, t, c))
