@@ -29,6 +29,7 @@ SOURCES = [
     "kernels/attention.hip",
     "kernels/fsq.hip",
     "kernels/conv_unit_fused.hip",
+    "kernels/last_block.hip",
 ]
 
 

@@ -31,14 +31,15 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int C, int HC>
+template <int C, int HC, int XH>  // XH: the input rows are staged in XH channel slices (LDS budget at C = 96)
 struct Geo {
     static constexpr int H4 = 4 * C;          // hidden width
     static constexpr int NCH = H4 / HC;       // weight chunks (1 = resident)
     static constexpr int NTC = HC / 32;       // hidden tiles per chunk
     static constexpr int CT = (C + 31) / 32;  // output-channel tiles
     static constexpr int KQ = C / 8;          // k groups of the first product
-    static constexpr int XS = C + 4;          // padded row strides (odd number of 16-B slots: conflict-free b128)
+    static constexpr int XC = C / XH;         // channels per staged slice
+    static constexpr int XS = XC + 4;         // padded row strides (odd number of 16-B slots: conflict-free b128)
     static constexpr int W1S = C + 4;
     static constexpr int W2S = HC + 4;
     static constexpr int ROWS = 38;           // 32 frames + 3 + 3 halo
@@ -52,15 +53,15 @@ struct Geo {
     static constexpr int OFF_XS = OFF_DW + 10 * C;
     static constexpr int xs_floats = ROWS * XS;
     static constexpr int lds_floats(int waves) { return OFF_XS + waves * xs_floats; }
-    static_assert(H4 % HC == 0 && HC % 32 == 0 && C % 8 == 0, "bad geometry");
+    static_assert(H4 % HC == 0 && HC % 32 == 0 && C % (8 * XH) == 0, "bad geometry");
 };
 
 __device__ __forceinline__ int rowmap(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 
-template <int C, int WAVES, int HC>
+template <int C, int WAVES, int HC, int XH>
 __global__ __launch_bounds__(64 * WAVES) void conv_unit_fused_kernel(const ConvUnitW w, const float* __restrict__ x,
                                                                     float* __restrict__ y, int batch, int frames) {
-    using G = Geo<C, HC>;
+    using G = Geo<C, HC, XH>;
     constexpr bool RESIDENT = G::NCH == 1;
     constexpr int THREADS = 64 * WAVES;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -117,37 +118,47 @@ __global__ __launch_bounds__(64 * WAVES) void conv_unit_fused_kernel(const ConvU
         const int t0 = tile_ok ? (int)(tile % tiles_per_clip) * 32 : 0;
         const float* clip = x + (int64_t)b * frames * C;
 
-        // ---- stage rows [t0 - 3, t0 + 35) of this clip into the wave's LDS copy (zeros outside the clip) ----
-        for (int i = lane; i < G::ROWS * (C / 4); i += 64) {
-            const int row = i / (C / 4), ch = i % (C / 4);
-            const int t = t0 - 3 + row;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (tile_ok && t >= 0 && t < frames) v = *reinterpret_cast<const float4*>(clip + (int64_t)t * C + 4 * ch);
-            *reinterpret_cast<float4*>(xs + row * G::XS + 4 * ch) = v;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-        // ---- depth-wise conv k7 + LayerNorm for frame lj, channels k = 8q + 4 lh + r --------------------
+        // ---- depth-wise conv k7 for frame lj, channels k = 8q + 4 lh + r, from the wave's LDS copy of rows
+        //      [t0 - 3, t0 + 35) of this clip (zeros outside the clip), staged one channel slice at a time ----
         float a[4 * G::KQ];
         float s1 = 0.f;
 #pragma unroll
-        for (int q = 0; q < G::KQ; ++q) {
-            const int k0 = 8 * q + 4 * lh;
-            float4 acc = *reinterpret_cast<const float4*>(DWs + 7 * C + k0);
-#pragma unroll
-            for (int tap = 0; tap < 7; ++tap) {
-                const float4 xv = *reinterpret_cast<const float4*>(xs + (lj + tap) * G::XS + k0);
-                const float4 wv = *reinterpret_cast<const float4*>(DWs + tap * C + k0);
-                acc.x = fmaf(xv.x, wv.x, acc.x);
-                acc.y = fmaf(xv.y, wv.y, acc.y);
-                acc.z = fmaf(xv.z, wv.z, acc.z);
-                acc.w = fmaf(xv.w, wv.w, acc.w);
+        for (int xh = 0; xh < XH; ++xh) {
+            for (int i = lane; i < G::ROWS * (G::XC / 4); i += 64) {
+                const int row = i / (G::XC / 4), ch = i % (G::XC / 4);
+                const int t = t0 - 3 + row;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (tile_ok && t >= 0 && t < frames)
+                    v = *reinterpret_cast<const float4*>(clip + (int64_t)t * C + xh * G::XC + 4 * ch);
+                *reinterpret_cast<float4*>(xs + row * G::XS + 4 * ch) = v;
             }
-            a[4 * q] = acc.x; a[4 * q + 1] = acc.y; a[4 * q + 2] = acc.z; a[4 * q + 3] = acc.w;
-            s1 += (acc.x + acc.y) + (acc.z + acc.w);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int ql = 0; ql < G::KQ / XH; ++ql) {
+                const int q = xh * (G::KQ / XH) + ql;
+                const int k0 = 8 * q + 4 * lh;       // channel
+                const int kl = 8 * ql + 4 * lh;      // channel within the staged slice
+                float4 acc = *reinterpret_cast<const float4*>(DWs + 7 * C + k0);
+#pragma unroll
+                for (int tap = 0; tap < 7; ++tap) {
+                    const float4 xv = *reinterpret_cast<const float4*>(xs + (lj + tap) * G::XS + kl);
+                    const float4 wv = *reinterpret_cast<const float4*>(DWs + tap * C + k0);
+                    acc.x = fmaf(xv.x, wv.x, acc.x);
+                    acc.y = fmaf(xv.y, wv.y, acc.y);
+                    acc.z = fmaf(xv.z, wv.z, acc.z);
+                    acc.w = fmaf(xv.w, wv.w, acc.w);
+                }
+                a[4 * q] = acc.x; a[4 * q + 1] = acc.y; a[4 * q + 2] = acc.z; a[4 * q + 3] = acc.w;
+                s1 += (acc.x + acc.y) + (acc.z + acc.w);
+            }
+            if (xh + 1 < XH) {  // the next slice overwrites the copy
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
         }
+        // ---- LayerNorm over the C channels of frame lj (two lanes hold one frame) -----------------------
         s1 += __shfl_xor(s1, 32, 64);
         const float mean = s1 / (float)C;
         float s2 = 0.f;
@@ -238,7 +249,9 @@ __global__ __launch_bounds__(64 * WAVES) void conv_unit_fused_kernel(const ConvU
                 for (int g = 0; g < 4; ++g) {
                     const int c0 = 32 * ct + 8 * g + 4 * lh;
                     if (c0 < C) {
-                        const float4 xr = *reinterpret_cast<const float4*>(xs + (lj + 3) * G::XS + c0);
+                        // residual: from the LDS copy when it holds all channels, else re-read (L2-served)
+                        const float4 xr = XH == 1 ? *reinterpret_cast<const float4*>(xs + (lj + 3) * G::XS + c0)
+                                                  : *reinterpret_cast<const float4*>(clip + (int64_t)(t0 + lj) * C + c0);
                         *reinterpret_cast<float4*>(dst + c0) =
                             make_float4(xr.x + yacc[ct][4 * g], xr.y + yacc[ct][4 * g + 1], xr.z + yacc[ct][4 * g + 2],
                                         xr.w + yacc[ct][4 * g + 3]);
@@ -250,14 +263,14 @@ __global__ __launch_bounds__(64 * WAVES) void conv_unit_fused_kernel(const ConvU
     }
 }
 
-template <int C, int WAVES, int HC>
+template <int C, int WAVES, int HC, int XH>
 int launch_fused(hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames, const char* name) {
-    using G = Geo<C, HC>;
+    using G = Geo<C, HC, XH>;
     const size_t lds = (size_t)G::lds_floats(WAVES) * sizeof(float);
     static_assert(G::lds_floats(WAVES) * sizeof(float) <= 160 * 1024, "LDS budget exceeded");
     static bool configured = false;
     if (!configured) {
-        L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_unit_fused_kernel<C, WAVES, HC>),
+        L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_unit_fused_kernel<C, WAVES, HC, XH>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = true;
     }
@@ -267,7 +280,7 @@ int launch_fused(hipStream_t s, const ConvUnitW& w, const float* x, float* y, in
     if (blocks > 256 * per_cu) blocks = 256 * per_cu;
     const double rows = (double)batch * frames;
     ProfScope prof(s, name, rows * (14.0 * C + 16.0 * C * C), rows * 8.0 * C);
-    hipLaunchKernelGGL((conv_unit_fused_kernel<C, WAVES, HC>), dim3((unsigned)blocks), dim3(64 * WAVES), lds, s, w, x, y, batch,
+    hipLaunchKernelGGL((conv_unit_fused_kernel<C, WAVES, HC, XH>), dim3((unsigned)blocks), dim3(64 * WAVES), lds, s, w, x, y, batch,
                        frames);
     L3AC_LAUNCH_CHECK();
     return L3AC_OK;
@@ -281,9 +294,9 @@ bool conv_unit_fused_supported(int c) { return c == 24 || c == 48 || c == 96; }
 int launch_conv_unit_fused(hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames) {
     L3AC_REQUIRE(x != y, "conv_unit_fused: in-place operation is not supported");
     switch (w.c) {
-        case 24: return launch_fused<24, 8, 96>(s, w, x, y, batch, frames, "conv_unit_fused_kernel<24>");
-        case 48: return launch_fused<48, 8, 192>(s, w, x, y, batch, frames, "conv_unit_fused_kernel<48>");
-        case 96: return launch_fused<96, 4, 96>(s, w, x, y, batch, frames, "conv_unit_fused_kernel<96>");
+        case 24: return launch_fused<24, 8, 96, 1>(s, w, x, y, batch, frames, "conv_unit_fused_kernel<24>");
+        case 48: return launch_fused<48, 8, 192, 1>(s, w, x, y, batch, frames, "conv_unit_fused_kernel<48>");
+        case 96: return launch_fused<96, 8, 96, 2>(s, w, x, y, batch, frames, "conv_unit_fused_kernel<96>");
         default:
             l3ac_set_error("conv_unit_fused: C=%d not supported", w.c);
             return L3AC_EINVAL;

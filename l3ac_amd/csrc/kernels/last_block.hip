@@ -1,0 +1,249 @@
+// Decoder output stage (reference l3ac/modules.py:47-64, :174-179, :190-195):
+//
+//   LegacyUnit (x3, dilation 1 / 3 / 9):   y = x + Conv1x1( snake( Conv_k7_dilated( snake(x) ) ) )      C -> C
+//   head:                                  audio = tanh( Conv_k7( snake(y) ) )                           C -> 1
+//
+// legacy_unit_kernel — one workgroup = 256 consecutive frames of one clip (8 waves x 32 frames):
+//   * snake(x) for the 256 + 6*dil frames the block needs is evaluated ONCE into an LDS tile (zeros outside the
+//     clip = the conv's zero padding), so the dilated k7 conv is an implicit product whose B operand is read from
+//     that tile at row (frame + tap*dil);
+//   * like the fused ConvUnit the products are transposed: X[n][m] = W1[n][(tap,c)] . S[m + (tap-3) dil][c]
+//     leaves the hidden tile in accumulator registers (hidden channel on rows, frame on lanes), snake is applied
+//     there, and the tile is fed straight back as the B operand of the 1x1 conv, Y[c][m] = W2[c][n] . X[n][m];
+//   * C <= 32 channels are padded to one 32-row MFMA tile with zero weights.
+// HBM traffic: 4C B in + 4C B out per frame (+ halo re-reads, L2-served); bound: fp32 MFMA issue
+// ((7C/2 padded to 4 ceil(7C/8)) + 16 MFMAs of 32x32x2 per 32 frames).
+//
+// head_kernel — snake(y) staged once per 256-frame tile, one thread per output sample: 7C FMAs, HBM-bound.
+#include "../kernels.hpp"
+#include "../network.hpp"
+#include "device_math.hpp"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int FRAMES = 256;  // frames per workgroup
+constexpr int WAVES = 8;
+
+__device__ __forceinline__ int rowmap(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+
+template <int C>
+struct LGeo {
+    static constexpr int K = 7 * C;
+    static constexpr int KQ = (K + 7) / 8;   // k groups of 8 (zero padded)
+    static constexpr int SS = C + 4;         // S tile row stride: an odd number of 16-B slots (conflict-free b128)
+    static constexpr int W1S = 8 * KQ + 4;
+    static constexpr int W2S = 36;
+    static constexpr int OFF_W1 = 0;                  // [32][W1S]
+    static constexpr int OFF_W2 = OFF_W1 + 32 * W1S;  // [32][W2S]
+    static constexpr int OFF_P = OFF_W2 + 32 * W2S;   // (alpha1, 1/alpha1) per hidden channel, b1, b2
+    static constexpr int OFF_S = OFF_P + 32 * 4;
+    static constexpr int lds_floats(int dil) { return OFF_S + (FRAMES + 6 * dil) * SS; }
+};
+
+template <int C>
+__global__ __launch_bounds__(64 * WAVES) void legacy_unit_kernel(const LegacyW w, const float* __restrict__ x,
+                                                                float* __restrict__ y, int frames) {
+    using G = LGeo<C>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* W1s = smem + G::OFF_W1;
+    float* W2s = smem + G::OFF_W2;
+    float* Ps = smem + G::OFF_P;
+    float* Ss = smem + G::OFF_S;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dil = w.dil;
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * FRAMES;
+    const float* clip = x + (int64_t)b * frames * C;
+
+    // ---- weights (zero padded to 32 rows / 8*KQ columns) -----------------------------------------------
+    for (int i = tid; i < 32 * (G::W1S / 4); i += 64 * WAVES) {
+        const int row = i / (G::W1S / 4), k = 4 * (i % (G::W1S / 4));
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < C && k < G::K) v = *reinterpret_cast<const float4*>(w.w1 + row * G::K + k);
+        *reinterpret_cast<float4*>(W1s + row * G::W1S + k) = v;
+    }
+    for (int i = tid; i < 32 * (G::W2S / 4); i += 64 * WAVES) {
+        const int row = i / (G::W2S / 4), k = 4 * (i % (G::W2S / 4));
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < C && k < C) v = *reinterpret_cast<const float4*>(w.w2 + row * C + k);
+        *reinterpret_cast<float4*>(W2s + row * G::W2S + k) = v;
+    }
+    if (tid < 32) {
+        const bool ok = tid < C;
+        *reinterpret_cast<float4*>(Ps + 4 * tid) =
+            make_float4(ok ? w.a1[tid] : 1.f, ok ? w.ia1[tid] : 0.f, ok ? w.b1[tid] : 0.f, ok ? w.b2[tid] : 0.f);
+    }
+    // ---- S tile: snake(x) for frames [t0 - 3 dil, t0 + FRAMES + 3 dil), zeros outside the clip ------------
+    const int rows = FRAMES + 6 * dil;
+    for (int i = tid; i < rows * (C / 4); i += 64 * WAVES) {
+        const int row = i / (C / 4), c0 = 4 * (i % (C / 4));
+        const int t = t0 - 3 * dil + row;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t >= 0 && t < frames) {
+            const float4 xv = *reinterpret_cast<const float4*>(clip + (int64_t)t * C + c0);
+            const float4 al = *reinterpret_cast<const float4*>(w.a0 + c0);
+            const float4 ia = *reinterpret_cast<const float4*>(w.ia0 + c0);
+            v = make_float4(snake_act(xv.x, al.x, ia.x), snake_act(xv.y, al.y, ia.y), snake_act(xv.z, al.z, ia.z),
+                            snake_act(xv.w, al.w, ia.w));
+        }
+        *reinterpret_cast<float4*>(Ss + row * G::SS + c0) = v;
+    }
+    __syncthreads();
+
+    const int lj = lane & 31;
+    const int lh = lane >> 5;
+    const int m0 = 32 * wave;
+    if (t0 + m0 >= frames) return;  // whole wave beyond the clip (no barriers follow)
+
+    // ---- X[n][m] = b1[n] + sum_{tap,c} W1[n][tap*C + c] S[m + (tap - 3) dil][c] ------------------------------
+    f32x16 xacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xacc[r] = Ps[4 * rowmap(r, lh) + 2];
+#pragma unroll
+    for (int q = 0; q < G::KQ; ++q) {
+        const int k = 8 * q + 4 * lh;
+        const int tap = k / C, c = k % C;
+        float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < G::K) sv = *reinterpret_cast<const float4*>(Ss + (m0 + lj + tap * dil) * G::SS + c);
+        const float4 wf = *reinterpret_cast<const float4*>(W1s + lj * G::W1S + k);
+        xacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.x, sv.x, xacc, 0, 0, 0);
+        xacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.y, sv.y, xacc, 0, 0, 0);
+        xacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.z, sv.z, xacc, 0, 0, 0);
+        xacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.w, sv.w, xacc, 0, 0, 0);
+    }
+    // ---- snake on the accumulator, then Y[c][m] = b2[c] + sum_n W2[c][n] X[n][m] ---------------------------
+    f32x16 yacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float4 pr = *reinterpret_cast<const float4*>(Ps + 4 * rowmap(r, lh));
+        xacc[r] = snake_act(xacc[r], pr.x, pr.y);  // padding rows: alpha 1, 1/alpha 0, bias 0 -> 0
+        yacc[r] = pr.w;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 wf = *reinterpret_cast<const float4*>(W2s + lj * G::W2S + 8 * g + 4 * lh);
+        yacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.x, xacc[4 * g], yacc, 0, 0, 0);
+        yacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.y, xacc[4 * g + 1], yacc, 0, 0, 0);
+        yacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.z, xacc[4 * g + 2], yacc, 0, 0, 0);
+        yacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.w, xacc[4 * g + 3], yacc, 0, 0, 0);
+    }
+    // ---- residual + store: lane (frame lj, half lh) owns channels 8 g + 4 lh + {0..3} -------------------
+    const int t = t0 + m0 + lj;
+    if (t < frames) {
+        const float* src = clip + (int64_t)t * C;
+        float* dst = y + ((int64_t)b * frames + t) * C;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c0 = 8 * g + 4 * lh;
+            if (c0 < C) {
+                const float4 xr = *reinterpret_cast<const float4*>(src + c0);
+                *reinterpret_cast<float4*>(dst + c0) = make_float4(xr.x + yacc[4 * g], xr.y + yacc[4 * g + 1],
+                                                                   xr.z + yacc[4 * g + 2], xr.w + yacc[4 * g + 3]);
+            }
+        }
+    }
+}
+
+// head: audio[t] = tanh(b + sum_{tap,c} w[tap][c] snake(x[t + tap - 3][c]))
+template <int C>
+__global__ __launch_bounds__(FRAMES) void head_fused_kernel(const HeadW w, const float* __restrict__ x, int frames,
+                                                           float* __restrict__ audio) {
+    constexpr int SS = C + 4;
+    __shared__ __attribute__((aligned(16))) float Ss[(FRAMES + 6) * SS];
+    __shared__ __attribute__((aligned(16))) float Ws[7 * C];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * FRAMES;
+    const float* clip = x + (int64_t)b * frames * C;
+    for (int i = tid; i < 7 * C; i += FRAMES) Ws[i] = w.w[i];
+    for (int i = tid; i < (FRAMES + 6) * (C / 4); i += FRAMES) {
+        const int row = i / (C / 4), c0 = 4 * (i % (C / 4));
+        const int t = t0 - 3 + row;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t >= 0 && t < frames) {
+            const float4 xv = *reinterpret_cast<const float4*>(clip + (int64_t)t * C + c0);
+            const float4 al = *reinterpret_cast<const float4*>(w.alpha + c0);
+            const float4 ia = *reinterpret_cast<const float4*>(w.inv_alpha + c0);
+            v = make_float4(snake_act(xv.x, al.x, ia.x), snake_act(xv.y, al.y, ia.y), snake_act(xv.z, al.z, ia.z),
+                            snake_act(xv.w, al.w, ia.w));
+        }
+        *reinterpret_cast<float4*>(Ss + row * SS + c0) = v;
+    }
+    __syncthreads();
+    const int t = t0 + tid;
+    if (t >= frames) return;
+    float acc = w.b[0];
+#pragma unroll
+    for (int tap = 0; tap < 7; ++tap) {
+#pragma unroll
+        for (int c0 = 0; c0 < C; c0 += 4) {
+            const float4 sv = *reinterpret_cast<const float4*>(Ss + (tid + tap) * SS + c0);
+            const float4 wv = *reinterpret_cast<const float4*>(Ws + tap * C + c0);
+            acc = fmaf(wv.x, sv.x, acc);
+            acc = fmaf(wv.y, sv.y, acc);
+            acc = fmaf(wv.z, sv.z, acc);
+            acc = fmaf(wv.w, sv.w, acc);
+        }
+    }
+    audio[(int64_t)b * frames + t] = tanhf(acc);
+}
+
+template <int C>
+int launch_legacy_t(hipStream_t s, const LegacyW& w, const float* x, float* y, int batch, int frames) {
+    using G = LGeo<C>;
+    const size_t lds = (size_t)G::lds_floats(w.dil) * sizeof(float);
+    L3AC_REQUIRE(w.dil >= 1 && w.dil <= 9, "legacy unit: dilation %d outside the LDS tile budget", w.dil);
+    static bool configured = false;
+    if (!configured) {
+        L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(legacy_unit_kernel<C>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(G::lds_floats(9) * sizeof(float))));
+        configured = true;
+    }
+    const double rows = (double)batch * frames;
+    ProfScope prof(s, "legacy_unit_kernel", rows * (2.0 * 7 * C * C + 2.0 * C * C + 40.0 * C), rows * 8.0 * C);
+    hipLaunchKernelGGL((legacy_unit_kernel<C>), dim3((unsigned)ceil_div64(frames, FRAMES), (unsigned)batch), dim3(64 * WAVES), lds,
+                       s, w, x, y, frames);
+    L3AC_LAUNCH_CHECK();
+    return L3AC_OK;
+}
+
+template <int C>
+int launch_head_t(hipStream_t s, const HeadW& w, const float* x, int batch, int frames, float* audio) {
+    const double rows = (double)batch * frames;
+    ProfScope prof(s, "head_fused_kernel", rows * (14.0 * C + 20.0 * C), rows * (4.0 * C + 4.0));
+    hipLaunchKernelGGL((head_fused_kernel<C>), dim3((unsigned)ceil_div64(frames, FRAMES), (unsigned)batch), dim3(FRAMES), 0, s, w,
+                       x, frames, audio);
+    L3AC_LAUNCH_CHECK();
+    return L3AC_OK;
+}
+
+}  // namespace
+
+bool last_block_fused_supported(int c, int max_dil) { return (c == 8 || c == 16 || c == 24 || c == 32) && max_dil <= 9; }
+
+// x must not alias y (neighbouring blocks read each other's halo frames)
+int launch_legacy_unit_fused(hipStream_t s, const LegacyW& w, const float* x, float* y, int batch, int frames) {
+    L3AC_REQUIRE(x != y && batch <= 65535, "legacy unit: bad arguments");
+    switch (w.c) {
+        case 8: return launch_legacy_t<8>(s, w, x, y, batch, frames);
+        case 16: return launch_legacy_t<16>(s, w, x, y, batch, frames);
+        case 24: return launch_legacy_t<24>(s, w, x, y, batch, frames);
+        case 32: return launch_legacy_t<32>(s, w, x, y, batch, frames);
+        default: l3ac_set_error("legacy unit: C=%d not supported by the fused kernel", w.c); return L3AC_EINVAL;
+    }
+}
+
+int launch_head_fused(hipStream_t s, const HeadW& w, const float* x, int batch, int frames, float* audio) {
+    L3AC_REQUIRE(batch <= 65535, "head: bad arguments");
+    switch (w.c) {
+        case 8: return launch_head_t<8>(s, w, x, batch, frames, audio);
+        case 16: return launch_head_t<16>(s, w, x, batch, frames, audio);
+        case 24: return launch_head_t<24>(s, w, x, batch, frames, audio);
+        case 32: return launch_head_t<32>(s, w, x, batch, frames, audio);
+        default: l3ac_set_error("head: C=%d not supported by the fused kernel", w.c); return L3AC_EINVAL;
+    }
+}

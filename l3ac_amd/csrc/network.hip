@@ -579,6 +579,19 @@ int run_up(l3ac_ctx* ctx, hipStream_t s, const UpW& w, const float* x, float* tm
 int run_last_block(l3ac_ctx* ctx, hipStream_t s, float* x, float* audio, int batch, int frames) {
     Workspace& ws = ctx->ws;
     const int64_t rows = (int64_t)batch * frames;
+    int max_dil = 1;
+    for (const LegacyW& l : ctx->legacy) max_dil = l.dil > max_dil ? l.dil : max_dil;
+    if (last_block_fused_supported(ctx->head.c, max_dil)) {  // fused units ping-pong between x and the scratch buffer
+        float* cur = x;
+        float* alt = ws.a;
+        for (const LegacyW& l : ctx->legacy) {
+            L3AC_TRY(launch_legacy_unit_fused(s, l, cur, alt, batch, frames));
+            float* t = cur;
+            cur = alt;
+            alt = t;
+        }
+        return launch_head_fused(s, ctx->head, cur, batch, frames, audio);
+    }
     for (const LegacyW& l : ctx->legacy) {  // modules.py:47-64
         L3AC_TRY(launch_snake(s, x, ws.a, rows, l.c, l.a0, l.ia0));
         GemmArgs g{};

@@ -95,6 +95,10 @@ int workspace_ensure_clip(l3ac_ctx* ctx, int batch, int samples, hipStream_t s);
 // fused ConvUnit for the narrow stages (kernels/conv_unit_fused.hip); x must not alias y
 bool conv_unit_fused_supported(int c);
 int launch_conv_unit_fused(hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames);
+// fused LegacyUnit / head (kernels/last_block.hip); x must not alias y
+bool last_block_fused_supported(int c, int max_dil);
+int launch_legacy_unit_fused(hipStream_t s, const LegacyW& w, const float* x, float* y, int batch, int frames);
+int launch_head_fused(hipStream_t s, const HeadW& w, const float* x, int batch, int frames, float* audio);
 // one ConvUnit of a stage on the ping-pong buffers: fused kernel (result in *alt, buffers swapped) or in place
 int conv_unit_step(l3ac_ctx* ctx, hipStream_t s, const ConvUnitW& w, float** cur, float** alt, int batch, int frames);
 
