@@ -157,7 +157,15 @@ def main():
         # ---- per-kernel roofline: one extra, untimed step with HIP events around every launch ----------
         with _capi.profile() as prof:
             codec.decode_audio(codec.encode_audio(audio)[0])
-        kernels = sorted(prof.entries, key=lambda e: -e["ms_total"])
+        # profile records are tagged "kernel<instantiation> shape": aggregate per kernel (= what rocprofv3's
+        # kernel_stats reports), keep the per-shape view of the GEMM for the report
+        by_kernel = {}
+        for e in prof.entries:
+            k = by_kernel.setdefault(e["name"].split(" ")[0], dict(name=e["name"].split(" ")[0], launches=0, ms_total=0.0, flops=0.0, bytes=0.0))
+            for f in ("launches", "ms_total", "flops", "bytes"):
+                k[f] += e[f]
+        shapes = sorted((e for e in prof.entries if " " in e["name"]), key=lambda e: -e["ms_total"])
+        kernels = sorted(by_kernel.values(), key=lambda e: -e["ms_total"])
         total_ms = sum(e["ms_total"] for e in kernels)
         dom = kernels[0]
         dom_ms = dom["ms_total"] / dom["launches"]
@@ -185,6 +193,8 @@ def main():
             "kernels": [{"name": e["name"], "launches": e["launches"], "ms": round(e["ms_total"], 4),
                          "tflops": round(e["flops"] / e["ms_total"] / 1e9, 2), "gbs": round(e["bytes"] / e["ms_total"] / 1e6, 1)}
                         for e in kernels],
+            "gemm_shapes": [{"name": e["name"], "launches": e["launches"], "ms": round(e["ms_total"], 4),
+                             "tflops": round(e["flops"] / e["ms_total"] / 1e9, 2)} for e in shapes[:16]],
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(codec, audio, args.cpu_batch, ind)

@@ -48,7 +48,7 @@ static inline int64_t round_up64(int64_t a, int64_t b) { return ceil_div64(a, b)
 #include <vector>
 
 struct ProfRecord {
-    const char* name;
+    char name[64];
     hipEvent_t start, stop;
     double flops, bytes;
 };
@@ -65,7 +65,10 @@ struct ProfScope {
     size_t slot = 0;
     ProfScope(hipStream_t s, const char* name, double flops, double bytes) : prof(l3ac_current_profiler()), stream(s) {
         if (!prof) return;
-        ProfRecord r{name, nullptr, nullptr, flops, bytes};
+        ProfRecord r{};
+        std::snprintf(r.name, sizeof(r.name), "%s", name);
+        r.flops = flops;
+        r.bytes = bytes;
         if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) {
             prof->failed = true;
             prof = nullptr;

@@ -19,22 +19,30 @@
 #include "../kernels.hpp"
 #include "device_math.hpp"
 
+#include <cstdio>
+#include <cstdlib>
+
 namespace {
 
 constexpr int BM = 128;
-constexpr int BK = 32;
 constexpr int THREADS = 256;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ int lds_off(int row, int chunk) {  // float index of 16-B chunk `chunk` of row `row`
-    return row * BK + ((chunk ^ ((row >> 1) & 7)) << 2);
+// float index of 16-B chunk `chunk` of row `row` in a [rows][BK] tile; the XOR spreads the 16 rows a
+// ds_read_b128 lane group touches over all 16 slots of the 256-B bank row
+template <int BK>
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+    return BK == 32 ? row * 32 + ((chunk ^ ((row >> 1) & 7)) << 2) : row * 16 + ((chunk ^ ((row >> 2) & 3)) << 2);
 }
 
-
-template <int NT, bool CONV>
-__global__ __launch_bounds__(THREADS, 2) void gemm_f32_kernel(const GemmArgs p) {
+template <int NT, bool CONV, int BK>
+__global__ __launch_bounds__(THREADS, BK == 16 ? 3 : 2) void gemm_f32_kernel(const GemmArgs p) {
     constexpr int BN = 32 * NT;
+    constexpr int CPR = BK / 4;            // 16-B chunks per tile row
+    constexpr int RP = THREADS / CPR;      // tile rows staged per pass
+    constexpr int AP = BM / RP;            // passes for the A tile
+    constexpr int WP = (BN + RP - 1) / RP; // passes for the W tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                 // [2][BM * BK]
     float* Ws = smem + 2 * BM * BK;   // [2][BN * BK]
@@ -42,35 +50,38 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_f32_kernel(const GemmArgs p) 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD), each with
+    // its own L2.  Within a group of 8 row panels, panel = blockIdx % 8 and the column tile advances every 8 blocks,
+    // so all column tiles of one A row panel run on ONE XCD and the panel is fetched from HBM once, not 8 times.
     const int n_blocks = (p.n + BN - 1) / BN;
-    const int64_t m0 = (int64_t)(blockIdx.x / n_blocks) * BM;
-    const int n0 = (int)(blockIdx.x % n_blocks) * BN;
+    const int64_t m_panels = (p.m + BM - 1) / BM;
+    const int64_t group = blockIdx.x / (8 * n_blocks);
+    const int64_t in_group = blockIdx.x % (8 * n_blocks);
+    const int64_t panels_here = (group * 8 + 8 <= m_panels) ? 8 : m_panels - group * 8;
+    const int64_t m0 = (group * 8 + in_group % panels_here) * BM;
+    const int n0 = (int)(in_group / panels_here) * BN;
 
-    // ---- staging roles: thread -> (chunk column cc, rows r0 + 32 i) ---------------------------------
-    const int cc = tid & 7;
-    const int r0 = tid >> 3;
-    const float* a_row[4];
-    int a_t[4];
-    bool a_ok[4];
+    // ---- staging roles: thread -> (chunk column cc, rows r0 + RP i) ---------------------------------
+    const int cc = tid % CPR;
+    const int r0 = tid / CPR;
+    const float* a_row[AP];
+    int a_t[AP];
+    bool a_ok[AP];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t m = m0 + r0 + 32 * i;
+    for (int i = 0; i < AP; ++i) {
+        const int64_t m = m0 + r0 + RP * i;
         a_ok[i] = m < p.m;
         const int64_t mm = a_ok[i] ? m : 0;
-        if (CONV) {
-            a_t[i] = (int)(mm % p.frames);
-            a_row[i] = p.a + mm * p.lda;
-        } else {
-            a_t[i] = 0;
-            a_row[i] = p.a + mm * p.lda;
-        }
+        a_t[i] = CONV ? (int)(mm % p.frames) : 0;
+        a_row[i] = p.a + mm * p.lda;
     }
-    const float* w_row[NT];
-    bool w_ok[NT];
+    const float* w_row[WP];
+    bool w_ok[WP];
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-        const int n = n0 + r0 + 32 * i;
-        w_ok[i] = n < p.n;
+    for (int i = 0; i < WP; ++i) {
+        const int nl = r0 + RP * i;
+        const int n = n0 + nl;
+        w_ok[i] = nl < BN && n < p.n;
         w_row[i] = p.w + (int64_t)(w_ok[i] ? n : 0) * p.ldw;
     }
     // conv bookkeeping for this thread's chunk: k = k_tile + 4 cc = tap * cin + c
@@ -80,12 +91,12 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_f32_kernel(const GemmArgs p) 
     }
     const int half = p.taps >> 1;
 
-    float4 a_reg[4], w_reg[NT];
+    float4 a_reg[AP], w_reg[WP];
     auto load_tile = [&](int k_tile) {
         const int k = k_tile + 4 * cc;
         const bool k_ok = k < p.k;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < AP; ++i) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (CONV) {
                 const int ts = a_t[i] + (tap - half) * p.dil;
@@ -97,7 +108,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_f32_kernel(const GemmArgs p) 
             a_reg[i] = v;
         }
 #pragma unroll
-        for (int i = 0; i < NT; ++i) {
+        for (int i = 0; i < WP; ++i) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (w_ok[i] && k_ok) v = *reinterpret_cast<const float4*>(w_row[i] + k);
             w_reg[i] = v;
@@ -111,9 +122,10 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_f32_kernel(const GemmArgs p) 
         float* as = As + buf * BM * BK;
         float* ws = Ws + buf * BN * BK;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(as + lds_off(r0 + 32 * i, cc)) = a_reg[i];
+        for (int i = 0; i < AP; ++i) *reinterpret_cast<float4*>(as + lds_off<BK>(r0 + RP * i, cc)) = a_reg[i];
 #pragma unroll
-        for (int i = 0; i < NT; ++i) *reinterpret_cast<float4*>(ws + lds_off(r0 + 32 * i, cc)) = w_reg[i];
+        for (int i = 0; i < WP; ++i)
+            if (r0 + RP * i < BN) *reinterpret_cast<float4*>(ws + lds_off<BK>(r0 + RP * i, cc)) = w_reg[i];
     };
 
     f32x16 acc[NT];
@@ -131,23 +143,27 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_f32_kernel(const GemmArgs p) 
     __syncthreads();
     for (int kt = 0; kt < n_tiles; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < n_tiles) load_tile((kt + 1) * BK);
+        const bool more = kt + 1 < n_tiles;
+        if (more) load_tile((kt + 1) * BK);
         const float* as = As + buf * BM * BK;
         const float* ws = Ws + buf * BN * BK;
 #pragma unroll
         for (int q = 0; q < BK / 8; ++q) {
             const int chunk = 2 * q + lh;
-            const float4 af = *reinterpret_cast<const float4*>(as + lds_off(32 * wave + li, chunk));
+            const float4 af = *reinterpret_cast<const float4*>(as + lds_off<BK>(32 * wave + li, chunk));
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const float4 bf = *reinterpret_cast<const float4*>(ws + lds_off(32 * nt + li, chunk));
+                const float4 bf = *reinterpret_cast<const float4*>(ws + lds_off<BK>(32 * nt + li, chunk));
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc[nt], 0, 0, 0);
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc[nt], 0, 0, 0);
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc[nt], 0, 0, 0);
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc[nt], 0, 0, 0);
             }
+            // the next tile goes to the OTHER buffer (last read before the previous barrier): store it from the
+            // middle of the MFMA sequence so that neither the global-load wait nor the LDS write sits in front of
+            // the barrier
+            if (q == BK / 16 - 1 && more) store_tile(buf ^ 1);
         }
-        if (kt + 1 < n_tiles) store_tile(buf ^ 1);
         __syncthreads();
     }
 
@@ -200,21 +216,21 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_f32_kernel(const GemmArgs p) 
     }
 }
 
-template <int NT, bool CONV>
+template <int NT, bool CONV, int BK>
 int launch_one(hipStream_t s, const GemmArgs& g) {
     constexpr int BN = 32 * NT;
     const int64_t blocks = ceil_div64(g.m, BM) * ceil_div64(g.n, BN);
     if (blocks <= 0) return L3AC_OK;
     L3AC_REQUIRE(blocks < (int64_t)1 << 31, "gemm: grid too large (m=%lld n=%d)", (long long)g.m, g.n);
     const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
-    static const char* const names[2][4] = {
-        {"gemm_f32_kernel<1,false>", "gemm_f32_kernel<2,false>", "gemm_f32_kernel<3,false>", "gemm_f32_kernel<4,false>"},
-        {"gemm_f32_kernel<1,true>", "gemm_f32_kernel<2,true>", "gemm_f32_kernel<3,true>", "gemm_f32_kernel<4,true>"}};
+    char name[64];  // instantiation + shape + epilogue: the profile aggregates launches of identical work
+    std::snprintf(name, sizeof(name), "gemm_f32_kernel<%d,%s,%d> %lldx%dx%d e%d", NT, CONV ? "true" : "false", BK,
+                  (long long)g.m, g.n, g.k, g.epi);
     const double a_elems = CONV ? (double)g.m * g.cin : (double)g.m * g.k;
     const double c_cols = g.epi == EPI_GEGLU ? (double)g.ldc : (double)g.n;
-    ProfScope prof(s, names[CONV ? 1 : 0][NT - 1], 2.0 * (double)g.m * g.n * g.k,
+    ProfScope prof(s, name, 2.0 * (double)g.m * g.n * g.k,
                    4.0 * (a_elems + (double)g.n * g.k + (double)g.m * c_cols * (g.epi == EPI_BIAS_RES ? 2.0 : 1.0)));
-    hipLaunchKernelGGL((gemm_f32_kernel<NT, CONV>), dim3((unsigned)blocks), dim3(THREADS), lds, s, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<NT, CONV, BK>), dim3((unsigned)blocks), dim3(THREADS), lds, s, g);
     L3AC_LAUNCH_CHECK();
     return L3AC_OK;
 }
@@ -233,9 +249,17 @@ int launch_gemm(hipStream_t s, const GemmArgs& g) {
                      "gemm: bad implicit-conv geometry (taps=%d cin=%d k=%d frames=%lld m=%lld)", g.taps, g.cin, g.k,
                      (long long)g.frames, (long long)g.m);
     }
+    // K tile: 32 floats (64 KB of LDS per block, 2 blocks per CU) or 16 (32 KB, 3 blocks per CU: more waves to cover
+    // the prologue / epilogue of short-K products).  L3AC_GEMM_BK overrides the choice for A/B measurements.
+    static const int bk_override = [] {
+        const char* e = std::getenv("L3AC_GEMM_BK");
+        return e ? std::atoi(e) : 0;
+    }();
+    const int bk = bk_override == 16 || bk_override == 32 ? bk_override : 16;
+#define L3AC_GEMM_LAUNCH(NT_, CONV_) (bk == 16 ? launch_one<NT_, CONV_, 16>(s, g) : launch_one<NT_, CONV_, 32>(s, g))
     if (g.epi == EPI_GEGLU) {
         L3AC_REQUIRE(g.n % 64 == 0 && !conv, "gemm: GEGLU epilogue needs interleaved 64-column tiles");
-        return launch_one<4, false>(s, g);
+        return L3AC_GEMM_LAUNCH(4, false);
     }
     if (g.epi == EPI_BIAS_RES) L3AC_REQUIRE(g.res, "gemm: residual epilogue without residual");
     if (g.epi == EPI_SNAKE || g.epi == EPI_SNAKE_GRN) L3AC_REQUIRE(g.alpha && g.inv_alpha, "gemm: snake without alpha");
@@ -244,16 +268,17 @@ int launch_gemm(hipStream_t s, const GemmArgs& g) {
     const int nt = g.n <= 32 ? 1 : (g.n <= 64 ? 2 : (g.n <= 96 ? 3 : 4));
     if (conv) {
         switch (nt) {
-            case 1: return launch_one<1, true>(s, g);
-            case 2: return launch_one<2, true>(s, g);
-            case 3: return launch_one<3, true>(s, g);
-            default: return launch_one<4, true>(s, g);
+            case 1: return L3AC_GEMM_LAUNCH(1, true);
+            case 2: return L3AC_GEMM_LAUNCH(2, true);
+            case 3: return L3AC_GEMM_LAUNCH(3, true);
+            default: return L3AC_GEMM_LAUNCH(4, true);
         }
     }
     switch (nt) {
-        case 1: return launch_one<1, false>(s, g);
-        case 2: return launch_one<2, false>(s, g);
-        case 3: return launch_one<3, false>(s, g);
-        default: return launch_one<4, false>(s, g);
+        case 1: return L3AC_GEMM_LAUNCH(1, false);
+        case 2: return L3AC_GEMM_LAUNCH(2, false);
+        case 3: return L3AC_GEMM_LAUNCH(3, false);
+        default: return L3AC_GEMM_LAUNCH(4, false);
     }
+#undef L3AC_GEMM_LAUNCH
 }

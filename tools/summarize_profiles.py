@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Condense a tools/collect_profiles.sh output directory into the files committed under profiles/:
+
+    kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (verbatim)
+    traffic.json       per kernel: launches, average FETCH_SIZE / WRITE_SIZE per launch and the corrected HBM bytes
+                       (gfx950: FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads -> doubled, as
+                       /opt/skills/guides/MI355X_MICROARCH.md §HBM prescribes; WRITE_SIZE is exact)
+    mfma_util.json     per kernel: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles), effective clock
+
+usage: tools/summarize_profiles.py gpurun_out/prof2 profiles/r01
+"""
+import collections
+import csv
+import glob
+import json
+import shutil
+import sys
+from pathlib import Path
+
+
+def short(name):
+    return name.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0].strip()
+
+
+def load(pattern):
+    files = glob.glob(pattern)
+    return list(csv.DictReader(open(files[0]))) if files else []
+
+
+def main(src, dst):
+    src, dst = Path(src), Path(dst)
+    dst.mkdir(parents=True, exist_ok=True)
+    stats = glob.glob(str(src / "trace/*/*_kernel_stats.csv"))
+    if stats:
+        shutil.copy(stats[0], dst / "kernel_stats.csv")
+    if (src / "trace_bench.json").exists():
+        shutil.copy(src / "trace_bench.json", dst / "bench_under_rocprof.json")
+    per = collections.defaultdict(lambda: dict(launches=0, fetch_kb=0.0, write_kb=0.0, wl=0))
+    for r in load(str(src / "pmc_fetch/*/*_counter_collection.csv")):
+        if r["Counter_Name"] == "FETCH_SIZE":
+            k = per[short(r["Kernel_Name"])]
+            k["launches"] += 1
+            k["fetch_kb"] += float(r["Counter_Value"])
+    for r in load(str(src / "pmc_write/*/*_counter_collection.csv")):
+        if r["Counter_Name"] == "WRITE_SIZE":
+            k = per[short(r["Kernel_Name"])]
+            k["wl"] += 1
+            k["write_kb"] += float(r["Counter_Value"])
+    traffic = {}
+    for name, k in per.items():
+        if not name or not k["launches"]:
+            continue
+        fetch = k["fetch_kb"] / k["launches"] * 1024
+        write = k["write_kb"] / max(k["wl"], 1) * 1024
+        traffic[name] = dict(launches=k["launches"], fetch_size_bytes_per_launch=fetch, write_size_bytes_per_launch=write,
+                             hbm_bytes_per_launch_corrected=2 * fetch + write)
+    json.dump(dict(note="FETCH_SIZE doubled (gfx950 wide-read correction), WRITE_SIZE as reported; averages per launch",
+                   kernels=traffic), open(dst / "traffic.json", "w"), indent=1)
+    sq = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in load(str(src / "pmc_sq/*/*_counter_collection.csv")):
+        d = sq[short(r["Kernel_Name"])]
+        d[r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+            d["_ns"] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+    util = {}
+    for name, d in sq.items():
+        cyc = d.get("GRBM_GUI_ACTIVE", 0.0) / 8  # summed over the 8 XCDs
+        if cyc <= 0 or not name:
+            continue
+        util[name] = dict(mfma_busy_fraction=d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024 * cyc),
+                          effective_clock_ghz=cyc / max(d["_ns"], 1.0),
+                          wait_any_per_wave_cycle=d.get("SQ_WAIT_ANY", 0.0) / max(d.get("SQ_WAVE_CYCLES", 1.0), 1.0))
+    json.dump(util, open(dst / "mfma_util.json", "w"), indent=1)
+    print(f"wrote {dst}/kernel_stats.csv traffic.json mfma_util.json")
+    for name in sorted(traffic, key=lambda n: -traffic[n]["hbm_bytes_per_launch_corrected"] * traffic[n]["launches"])[:8]:
+        t = traffic[name]
+        u = util.get(name, {})
+        print(f"{name[:44]:44s} launches {t['launches']:4d} HBM/launch {t['hbm_bytes_per_launch_corrected'] / 1e6:9.1f} MB "
+              f"mfma busy {u.get('mfma_busy_fraction', float('nan')):.2f} clock {u.get('effective_clock_ghz', float('nan')):.2f} GHz")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
