@@ -108,16 +108,15 @@ def main():
     codec.network.context().reserve(b, samples)
     n_tok = -(-samples // mc.hop_length)
     gather = world > 1 and not args.no_gather
-    if gather:
-        all_idx = torch.empty((world * b, n_tok), dtype=torch.int32, device=dev)
-        all_wave = torch.empty((world * b, n_tok * mc.hop_length), dtype=torch.float32, device=dev)
+    from l3ac_amd.dist import gather_batch
 
     def step():
         q, ind = codec.encode_audio(audio)
         wave = codec.decode_audio(q)
         if gather:  # the only exchange step of the path: outputs to every rank over xGMI
-            dist.all_gather_into_tensor(all_idx, ind["indices"])
-            dist.all_gather_into_tensor(all_wave, wave)
+            all_idx = gather_batch(ind["indices"], world * b)
+            all_wave = gather_batch(wave, world * b)
+            return {"indices": all_idx[rank * b:(rank + 1) * b]}, all_wave
         return ind, wave
 
     run = step
@@ -174,8 +173,18 @@ def main():
             roof = dict(bound="mfma", achieved=dom["flops"] / dom["ms_total"] / 1e9, peak=PEAK_F32_TFLOPS, unit="TFLOP/s")
         else:
             roof = dict(bound="hbm", achieved=dom["bytes"] / dom["ms_total"] / 1e6, peak=PEAK_HBM_GBS, unit="GB/s")
-        roof.update(frac=roof["achieved"] / roof["peak"], traffic=None, kernel=dom["name"], launches_per_step=dom["launches"],
-                    avg_launch_ms=dom_ms, share_of_step=dom["ms_total"] / total_ms)
+        # HBM bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE), which cannot run
+        # inside this process: the committed summary of tools/collect_profiles.sh for this same workload is attached
+        traffic, traffic_src = None, None
+        tfile = REPO / "profiles" / "r01" / "traffic.json"
+        if tfile.exists() and args.config == "1kbps" and b == 256 and samples == 16000:
+            pmc = {k.replace(" ", ""): v for k, v in json.load(open(tfile))["kernels"].items()}
+            hit = pmc.get(dom["name"].replace(" ", ""))
+            if hit:
+                traffic, traffic_src = hit["hbm_bytes_per_launch_corrected"], "profiles/r01/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+        roof.update(frac=roof["achieved"] / roof["peak"], traffic=traffic, traffic_source=traffic_src,
+                    algorithmic_bytes_per_launch=dom["bytes"] / dom["launches"], kernel=dom["name"],
+                    launches_per_step=dom["launches"], avg_launch_ms=dom_ms, share_of_step=dom["ms_total"] / total_ms)
         out = {
             "metric": "audio samples/sec encode+decode, 1kbps@16kHz, batch 256; indices bit-exact",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -196,12 +205,50 @@ def main():
             "gemm_shapes": [{"name": e["name"], "launches": e["launches"], "ms": round(e["ms_total"], 4),
                              "tflops": round(e["flops"] / e["ms_total"] / 1e9, 2)} for e in shapes[:16]],
         }
+        out["fsq_kernel"] = fsq_microbench(codec, dev)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(codec, audio, args.cpu_batch, ind)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def fsq_microbench(codec, dev, n_tokens=1 << 22):
+    """HBM roofline of the closed-form FSQ kernel on its own: at batch 256 it moves 16 MB per launch (below launch
+    latency), so its fraction of the HBM peak is measured at 2^22 tokens (1 052 algorithmic bytes per token)."""
+    import ctypes as C
+
+    from l3ac_amd import _capi, weights as W
+    mc = codec.network.mc
+    d, feat = len(mc.levels), mc.feature_dim
+    w = W.folded_weights(codec.network.state_dicts())
+    wt = {k: w[f"quantizer.{k}"].to(dev) for k in ("project_in.weight", "project_in.bias", "project_out.weight", "project_out.bias")}
+    x = torch.randn(n_tokens, feat, device=dev)
+    q = torch.empty_like(x)
+    idx = torch.empty(n_tokens, dtype=torch.int32, device=dev)
+    li = torch.empty(n_tokens, d, device=dev)
+    lib = _capi.load_library()
+    lv = (C.c_int32 * d)(*mc.levels)
+    s = torch.cuda.current_stream(dev).cuda_stream
+    call = lambda: _capi.check(lib.l3ac_fsq_forward(x.data_ptr(), n_tokens, feat, lv, d, wt["project_in.weight"].data_ptr(),
+                                                    wt["project_in.bias"].data_ptr(), wt["project_out.weight"].data_ptr(),
+                                                    wt["project_out.bias"].data_ptr(), q.data_ptr(), idx.data_ptr(),
+                                                    li.data_ptr(), None, s))
+    for _ in range(3):
+        call()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 10
+    e0.record()
+    for _ in range(reps):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    bytes_per_token = 4 * feat * 2 + 4 + 4 * d
+    gbs = n_tokens * bytes_per_token / ms / 1e6
+    return {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+            "tokens": n_tokens, "bytes_per_token": bytes_per_token, "ms": ms}
 
 
 def cpu_baseline(codec, audio, cpu_batch, gpu_ind):

@@ -1,0 +1,67 @@
+"""Multi-GPU use of the path: one process per GPU, batch sharded across ranks, outputs gathered over RCCL.
+
+Clips are independent (the reference has no cross-sample op), so every rank holds a full weight replica and runs
+`encode_audio` / `decode_audio` on its contiguous slice of the batch.  The only exchange step is the final
+all-gather of quantiser indices and waveforms (backend "nccl" = RCCL over xGMI on ROCm; "gloo" on CPU in the tests).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous slice [start, stop) of `total` clips owned by `rank`; the first `total % world` ranks get one more."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world of {world}")
+    base, extra = divmod(total, world)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def shard_batch(batch: torch.Tensor, rank: Optional[int] = None, world: Optional[int] = None) -> torch.Tensor:
+    rank = dist.get_rank() if rank is None else rank
+    world = dist.get_world_size() if world is None else world
+    start, stop = shard_range(batch.shape[0], rank, world)
+    return batch[start:stop]
+
+
+def gather_batch(local: torch.Tensor, total: int, group=None) -> torch.Tensor:
+    """All-gather per-rank slices (as produced by `shard_range`) back into the full batch, on every rank."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return local
+    base, extra = divmod(total, world)
+    if extra == 0:  # equal shards: one collective straight into the output
+        out = torch.empty((total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        return out
+    # ragged: pad every shard to base + 1 rows, gather, drop the padding
+    rows = base + 1
+    padded = torch.zeros((rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    padded[: local.shape[0]] = local
+    out = torch.empty((world * rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, padded, group=group)
+    parts = []
+    for r in range(world):
+        n = base + (1 if r < extra else 0)
+        parts.append(out[r * rows: r * rows + n])
+    return torch.cat(parts, dim=0)
+
+
+class ShardedCodec:
+    """Runs a codec (anything with `encode_audio` / `decode_audio`, e.g. `l3ac_amd.L3AC`) on this rank's slice of a
+    batch that every rank holds, and returns the gathered full-batch outputs on every rank."""
+
+    def __init__(self, codec, group=None):
+        self.codec = codec
+        self.group = group
+
+    def encode_decode(self, audio: torch.Tensor):
+        total = audio.shape[0]
+        local = shard_batch(audio, dist.get_rank(self.group), dist.get_world_size(self.group))
+        q_feature, ind = self.codec.encode_audio(local)
+        wave = self.codec.decode_audio(q_feature)
+        return gather_batch(ind["indices"], total, self.group), gather_batch(wave, total, self.group)
