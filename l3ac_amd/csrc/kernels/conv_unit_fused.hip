@@ -110,8 +110,39 @@ __global__ __launch_bounds__(64 * WAVES) void conv_unit_fused_kernel(const ConvU
     const int tiles_per_clip = (frames + 31) / 32;
     const int64_t n_tiles = (int64_t)batch * tiles_per_clip;
 
+    // input rows [t0 - 3, t0 + 35) of a tile's clip travel global -> registers -> the wave's LDS copy; with a single
+    // channel slice (XH == 1) the NEXT tile's rows are fetched into registers while the current tile computes
+    constexpr int NPRE = (G::ROWS * (G::XC / 4) + 63) / 64;
+    auto load_rows = [&](int64_t tl, int xh, float4 (&pre)[NPRE]) {
+        const bool ok = tl < n_tiles;
+        const int bb = ok ? (int)(tl / tiles_per_clip) : 0;
+        const int tt0 = ok ? (int)(tl % tiles_per_clip) * 32 : 0;
+        const float* cl = x + (int64_t)bb * frames * C + xh * G::XC;
+#pragma unroll
+        for (int it = 0; it < NPRE; ++it) {
+            const int i = lane + 64 * it;
+            const int row = i / (G::XC / 4), ch = i % (G::XC / 4);
+            const int t = tt0 - 3 + row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok && i < G::ROWS * (G::XC / 4) && t >= 0 && t < frames)
+                v = *reinterpret_cast<const float4*>(cl + (int64_t)t * C + 4 * ch);
+            pre[it] = v;
+        }
+    };
+    auto store_rows = [&](const float4 (&pre)[NPRE]) {
+#pragma unroll
+        for (int it = 0; it < NPRE; ++it) {
+            const int i = lane + 64 * it;
+            const int row = i / (G::XC / 4), ch = i % (G::XC / 4);
+            if (i < G::ROWS * (G::XC / 4)) *reinterpret_cast<float4*>(xs + row * G::XS + 4 * ch) = pre[it];
+        }
+    };
+    const int64_t tile_stride = (int64_t)gridDim.x * WAVES;
+    float4 pre[XH == 1 ? NPRE : 1];  // live across a tile only in the single-slice variants
+    if constexpr (XH == 1) load_rows((int64_t)blockIdx.x * WAVES + wave, 0, pre);
+
     // every wave of the block runs the same number of iterations (the chunked variant has block barriers inside)
-    for (int64_t base = (int64_t)blockIdx.x * WAVES; base < n_tiles; base += (int64_t)gridDim.x * WAVES) {
+    for (int64_t base = (int64_t)blockIdx.x * WAVES; base < n_tiles; base += tile_stride) {
         const int64_t tile = base + wave;
         const bool tile_ok = tile < n_tiles;
         const int b = tile_ok ? (int)(tile / tiles_per_clip) : 0;
@@ -124,17 +155,24 @@ __global__ __launch_bounds__(64 * WAVES) void conv_unit_fused_kernel(const ConvU
         float s1 = 0.f;
 #pragma unroll
         for (int xh = 0; xh < XH; ++xh) {
-            for (int i = lane; i < G::ROWS * (G::XC / 4); i += 64) {
-                const int row = i / (G::XC / 4), ch = i % (G::XC / 4);
-                const int t = t0 - 3 + row;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (tile_ok && t >= 0 && t < frames)
-                    v = *reinterpret_cast<const float4*>(clip + (int64_t)t * C + xh * G::XC + 4 * ch);
-                *reinterpret_cast<float4*>(xs + row * G::XS + 4 * ch) = v;
+            if constexpr (XH == 1) {
+                store_rows(pre);
+            } else {
+                // register budget at C = 96: copy one 16-B chunk at a time
+#pragma unroll 1
+                for (int i = lane; i < G::ROWS * (G::XC / 4); i += 64) {
+                    const int row = i / (G::XC / 4), ch = i % (G::XC / 4);
+                    const int t = t0 - 3 + row;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (tile_ok && t >= 0 && t < frames)
+                        v = *reinterpret_cast<const float4*>(clip + (int64_t)t * C + xh * G::XC + 4 * ch);
+                    *reinterpret_cast<float4*>(xs + row * G::XS + 4 * ch) = v;
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if constexpr (XH == 1) load_rows(tile + tile_stride, 0, pre);  // in flight until the next iteration
 #pragma unroll
             for (int ql = 0; ql < G::KQ / XH; ++ql) {
                 const int q = xh * (G::KQ / XH) + ql;

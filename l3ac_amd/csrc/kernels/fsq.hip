@@ -39,32 +39,58 @@ struct FsqDev {
     float* latents;
 };
 
-template <int D>
+template <int D, int NV>  // NV 16-byte chunks (4 channels each) per lane: lanes per token = feat / (4 NV)
 __global__ __launch_bounds__(THREADS) void fsq_kernel(const FsqDev p, const int lpt) {
+    // HBM-bound by construction (1 052 B per token); what limits it in practice is bytes in flight and issue slots,
+    // so: projection weights in LDS (not registers), the next token group's rows prefetched into registers, each
+    // block walking a contiguous token range, and ONE tanh per lane (lane d of a token's group quantises latent d
+    // and the level indices are exchanged by shuffles) instead of D redundant ones.
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Win = smem;                  // [D][feat]
+    float* Wout = smem + D * p.feat;    // [D][feat] (project_out transposed)
+    float* Bout = Wout + D * p.feat;    // [feat]
     const int tid = threadIdx.x;
-    const int sub = tid % lpt;       // lane within the token's group
-    const int c0 = sub * 8;          // this lane's 8 channels
+    for (int i = tid; i < D * p.feat; i += THREADS) {
+        const int d = i / p.feat, c = i % p.feat;
+        Win[i] = p.w_in ? p.w_in[i] : 0.f;
+        Wout[i] = p.w_out[c * D + d];
+    }
+    for (int i = tid; i < p.feat; i += THREADS) Bout[i] = p.b_out[i];
+    __syncthreads();
+
+    const int sub = tid % lpt;          // lane within the token's group
+    const int lane = tid & 63;
+    const int c0 = sub * 4 * NV;        // this lane's channels
     const int tok_per_block = THREADS / lpt;
-
-    float w_in[D][8], w_out[8][D], b_out[8], b_in[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        b_in[d] = p.b_in ? p.b_in[d] : 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) w_in[d][e] = p.w_in ? p.w_in[d * p.feat + c0 + e] : 0.f;
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        b_out[e] = p.b_out[c0 + e];
-#pragma unroll
-        for (int d = 0; d < D; ++d) w_out[e][d] = p.w_out[(c0 + e) * D + d];
-    }
-
     const int64_t n_groups = (p.n + tok_per_block - 1) / tok_per_block;
-    for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    const int64_t per_block = (n_groups + gridDim.x - 1) / gridDim.x;  // contiguous token range per block
+    const int64_t g_begin = (int64_t)blockIdx.x * per_block;
+    const int64_t g_end = g_begin + per_block < n_groups ? g_begin + per_block : n_groups;
+    const bool spread = lpt >= D;       // one latent per lane; otherwise every lane quantises all D
+
+    float4 x_next[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) x_next[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto fetch = [&](int64_t g) {
+        const int64_t t = g * tok_per_block + tid / lpt;
+        if (p.x && g < g_end && t < p.n) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) x_next[v] = *reinterpret_cast<const float4*>(p.x + t * p.feat + c0 + 4 * v);
+        }
+    };
+    auto quantise = [&](float lat, int d) -> float {
+        const float act = (tanhf(lat) + 1.0f) * 0.5f;                 // fsq_act.py:39
+        return rintf(__fmul_rn(act, (float)(p.levels[d] - 1)));       // vq/fsq.py:59 (half-to-even)
+    };
+    fetch(g_begin);
+    for (int64_t g = g_begin; g < g_end; ++g) {
         const int64_t tok = g * tok_per_block + tid / lpt;
         const bool ok = tok < p.n;
         const int64_t tk = ok ? tok : 0;
+        float4 xv[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) xv[v] = x_next[v];
+        fetch(g + 1);
         float li[D];
         if (p.idx_in) {  // decode: indices -> level indices (vq/fsq.py:70-71)
             const int idx = p.idx_in[tk];
@@ -73,16 +99,17 @@ __global__ __launch_bounds__(THREADS) void fsq_kernel(const FsqDev p, const int 
         } else {
             float lat[D];
             if (p.x) {
-                const float4 xa = *reinterpret_cast<const float4*>(p.x + tk * p.feat + c0);
-                const float4 xb = *reinterpret_cast<const float4*>(p.x + tk * p.feat + c0 + 4);
-                const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
                     float s = 0.f;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) s = fmaf(xv[e], w_in[d][e], s);
+                    for (int v = 0; v < NV; ++v) {
+                        const float4 wv = *reinterpret_cast<const float4*>(Win + d * p.feat + c0 + 4 * v);
+                        s = fmaf(xv[v].x, wv.x, s); s = fmaf(xv[v].y, wv.y, s);
+                        s = fmaf(xv[v].z, wv.z, s); s = fmaf(xv[v].w, wv.w, s);
+                    }
                     for (int mask = lpt >> 1; mask > 0; mask >>= 1) s += __shfl_xor(s, mask, 64);
-                    lat[d] = s + b_in[d];
+                    lat[d] = s + (p.b_in ? p.b_in[d] : 0.f);
                 }
             } else {
 #pragma unroll
@@ -92,32 +119,39 @@ __global__ __launch_bounds__(THREADS) void fsq_kernel(const FsqDev p, const int 
 #pragma unroll
                 for (int d = 0; d < D; ++d) p.latents[tok * D + d] = lat[d];
             }
+            if (spread) {
+                float mine = 0.f;  // latent `sub` of this token (all lanes of the group hold identical latents)
 #pragma unroll
-            for (int d = 0; d < D; ++d) {
-                const float act = (tanhf(lat[d]) + 1.0f) * 0.5f;                // fsq_act.py:39
-                li[d] = rintf(__fmul_rn(act, (float)(p.levels[d] - 1)));        // vq/fsq.py:59
+                for (int d = 0; d < D; ++d) mine = sub == d ? lat[d] : mine;
+                const float li_mine = quantise(mine, sub < D ? sub : 0);
+                const int group_base = lane - sub;
+#pragma unroll
+                for (int d = 0; d < D; ++d) li[d] = __shfl(li_mine, group_base + d, 64);
+            } else {
+#pragma unroll
+                for (int d = 0; d < D; ++d) li[d] = quantise(lat[d], d);
             }
         }
-        float q[D];
         float idx_f = 0.f;
+        float4 o[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) o[v] = *reinterpret_cast<const float4*>(Bout + c0 + 4 * v);
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             idx_f += li[d] * (float)p.basis[d];                                 // exact (vq/fsq.py:67-68)
             const float q_act = __fdiv_rn(li[d], (float)(p.levels[d] - 1));     // vq/fsq.py:60
-            q[d] = __fsub_rn(__fmul_rn(q_act, 2.0f), 1.0f);                     // vq/fsq.py:21
-        }
-        float o[8];
+            const float q = __fsub_rn(__fmul_rn(q_act, 2.0f), 1.0f);            // vq/fsq.py:21
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float s = b_out[e];
-#pragma unroll
-            for (int d = 0; d < D; ++d) s = fmaf(q[d], w_out[e][d], s);
-            o[e] = s;
+            for (int v = 0; v < NV; ++v) {
+                const float4 wv = *reinterpret_cast<const float4*>(Wout + d * p.feat + c0 + 4 * v);
+                o[v].x = fmaf(q, wv.x, o[v].x); o[v].y = fmaf(q, wv.y, o[v].y);
+                o[v].z = fmaf(q, wv.z, o[v].z); o[v].w = fmaf(q, wv.w, o[v].w);
+            }
         }
         if (ok) {
             float* dst = p.q_feature + tok * p.feat + c0;
-            *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-            *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) *reinterpret_cast<float4*>(dst + 4 * v) = o[v];
             if (sub == 0) {
                 if (p.indices) p.indices[tok] = (int32_t)idx_f;
                 if (p.level_indices) {
@@ -131,15 +165,20 @@ __global__ __launch_bounds__(THREADS) void fsq_kernel(const FsqDev p, const int 
 
 template <int D>
 int launch_fsq_t(hipStream_t s, const FsqDev& p) {
-    const int lpt = p.feat / 8;
+    const int nv = p.feat >= 128 ? 4 : 2;        // 16 or 8 channels per lane
+    const int lpt = p.feat / (4 * nv);
     const int tok_per_block = THREADS / lpt;
     int64_t blocks = ceil_div64(p.n, tok_per_block);
     if (blocks <= 0) return L3AC_OK;
-    if (blocks > 256 * 8) blocks = 256 * 8;  // grid-stride: weights stay in registers across tokens
+    if (blocks > 256 * 8) blocks = 256 * 8;  // one weight staging per block, contiguous token range each
+    const size_t lds = (size_t)(2 * D + 1) * p.feat * sizeof(float);
     const double in_b = p.x ? 4.0 * p.feat : (p.idx_in ? 4.0 : 4.0 * D);
     ProfScope prof(s, "fsq_kernel", 4.0 * D * p.feat * (double)p.n,
                    (double)p.n * (in_b + 4.0 * p.feat + (p.indices ? 4.0 : 0.0) + (p.level_indices ? 4.0 * D : 0.0)));
-    hipLaunchKernelGGL((fsq_kernel<D>), dim3((unsigned)blocks), dim3(THREADS), 0, s, p, lpt);
+    if (nv == 4)
+        hipLaunchKernelGGL((fsq_kernel<D, 4>), dim3((unsigned)blocks), dim3(THREADS), lds, s, p, lpt);
+    else
+        hipLaunchKernelGGL((fsq_kernel<D, 2>), dim3((unsigned)blocks), dim3(THREADS), lds, s, p, lpt);
     L3AC_LAUNCH_CHECK();
     return L3AC_OK;
 }
