@@ -36,7 +36,9 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
     return BK == 32 ? row * 32 + ((chunk ^ ((row >> 1) & 7)) << 2) : row * 16 + ((chunk ^ ((row >> 2) & 3)) << 2);
 }
 
-template <int NT, bool CONV, int BK>
+// FULLK: k is a multiple of BK and A is plain rows -> the staging loads are unconditional (rows / columns past the
+// edge are clamped to row 0: they only feed accumulators that are never stored), no exec-mask branches in the loop.
+template <int NT, bool CONV, int BK, bool FULLK>
 __global__ __launch_bounds__(THREADS, BK == 16 ? 3 : 2) void gemm_f32_kernel(const GemmArgs p) {
     constexpr int BN = 32 * NT;
     constexpr int CPR = BK / 4;            // 16-B chunks per tile row
@@ -102,6 +104,8 @@ __global__ __launch_bounds__(THREADS, BK == 16 ? 3 : 2) void gemm_f32_kernel(con
                 const int ts = a_t[i] + (tap - half) * p.dil;
                 if (a_ok[i] && k_ok && ts >= 0 && ts < p.frames)
                     v = *reinterpret_cast<const float4*>(a_row[i] + (int64_t)(tap - half) * p.dil * p.lda + ch);
+            } else if (FULLK) {
+                v = *reinterpret_cast<const float4*>(a_row[i] + k);
             } else {
                 if (a_ok[i] && k_ok) v = *reinterpret_cast<const float4*>(a_row[i] + k);
             }
@@ -110,7 +114,11 @@ __global__ __launch_bounds__(THREADS, BK == 16 ? 3 : 2) void gemm_f32_kernel(con
 #pragma unroll
         for (int i = 0; i < WP; ++i) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (w_ok[i] && k_ok) v = *reinterpret_cast<const float4*>(w_row[i] + k);
+            if (FULLK) {
+                v = *reinterpret_cast<const float4*>(w_row[i] + k);
+            } else if (w_ok[i] && k_ok) {
+                v = *reinterpret_cast<const float4*>(w_row[i] + k);
+            }
             w_reg[i] = v;
         }
         if (CONV) {  // advance (tap, ch) by BK for the next tile
@@ -218,19 +226,23 @@ __global__ __launch_bounds__(THREADS, BK == 16 ? 3 : 2) void gemm_f32_kernel(con
 
 template <int NT, bool CONV, int BK>
 int launch_one(hipStream_t s, const GemmArgs& g) {
+    const bool fullk = !CONV && g.k % BK == 0;
     constexpr int BN = 32 * NT;
     const int64_t blocks = ceil_div64(g.m, BM) * ceil_div64(g.n, BN);
     if (blocks <= 0) return L3AC_OK;
     L3AC_REQUIRE(blocks < (int64_t)1 << 31, "gemm: grid too large (m=%lld n=%d)", (long long)g.m, g.n);
     const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
     char name[64];  // instantiation + shape + epilogue: the profile aggregates launches of identical work
-    std::snprintf(name, sizeof(name), "gemm_f32_kernel<%d,%s,%d> %lldx%dx%d e%d", NT, CONV ? "true" : "false", BK,
-                  (long long)g.m, g.n, g.k, g.epi);
+    std::snprintf(name, sizeof(name), "gemm_f32_kernel<%d,%s,%d,%s> %lldx%dx%d e%d", NT, CONV ? "true" : "false", BK,
+                  fullk ? "true" : "false", (long long)g.m, g.n, g.k, g.epi);
     const double a_elems = CONV ? (double)g.m * g.cin : (double)g.m * g.k;
     const double c_cols = g.epi == EPI_GEGLU ? (double)g.ldc : (double)g.n;
     ProfScope prof(s, name, 2.0 * (double)g.m * g.n * g.k,
                    4.0 * (a_elems + (double)g.n * g.k + (double)g.m * c_cols * (g.epi == EPI_BIAS_RES ? 2.0 : 1.0)));
-    hipLaunchKernelGGL((gemm_f32_kernel<NT, CONV, BK>), dim3((unsigned)blocks), dim3(THREADS), lds, s, g);
+    if (fullk)
+        hipLaunchKernelGGL((gemm_f32_kernel<NT, false, BK, true>), dim3((unsigned)blocks), dim3(THREADS), lds, s, g);
+    else
+        hipLaunchKernelGGL((gemm_f32_kernel<NT, CONV, BK, false>), dim3((unsigned)blocks), dim3(THREADS), lds, s, g);
     L3AC_LAUNCH_CHECK();
     return L3AC_OK;
 }
@@ -264,8 +276,12 @@ int launch_gemm(hipStream_t s, const GemmArgs& g) {
     if (g.epi == EPI_BIAS_RES) L3AC_REQUIRE(g.res, "gemm: residual epilogue without residual");
     if (g.epi == EPI_SNAKE || g.epi == EPI_SNAKE_GRN) L3AC_REQUIRE(g.alpha && g.inv_alpha, "gemm: snake without alpha");
     if (g.epi == EPI_SNAKE_GRN) L3AC_REQUIRE(g.gamma && g.beta, "gemm: GRN without gamma/beta");
-    // widest column tile that does not over-pad n
-    const int nt = g.n <= 32 ? 1 : (g.n <= 64 ? 2 : (g.n <= 96 ? 3 : 4));
+    // widest column tile that does not over-pad n ...
+    int nt = g.n <= 32 ? 1 : (g.n <= 64 ? 2 : (g.n <= 96 ? 3 : 4));
+    // ... unless that leaves most SIMDs with a single wave (small m): narrower tiles give more workgroups, which is
+    // what hides the operand-fetch latency of these short launches (A is re-read once more per column tile, L2-served)
+    const int64_t m_panels = ceil_div64(g.m, BM);
+    while (nt > 1 && (g.n % (32 * nt) == 0 || nt == 4) && m_panels * ceil_div64(g.n, 32 * nt) < 768 && g.n % (16 * nt) == 0) nt >>= 1;
     if (conv) {
         switch (nt) {
             case 1: return L3AC_GEMM_LAUNCH(1, true);
