@@ -124,7 +124,7 @@ __global__ __launch_bounds__(64 * WAVES) void legacy_unit_kernel(const LegacyW w
         yacc[r] = pr.w;
     }
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
+    for (int g = 0; g < (C + 7) / 8; ++g) {  // hidden rows >= C are zero padding: their k-groups contribute nothing
         const float4 wf = *reinterpret_cast<const float4*>(W2s + lj * G::W2S + 8 * g + 4 * lh);
         yacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.x, xacc[4 * g], yacc, 0, 0, 0);
         yacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.y, xacc[4 * g + 1], yacc, 0, 0, 0);

@@ -119,8 +119,9 @@ __global__ __launch_bounds__(THREADS) void row_kernel(const RowArgs p, const int
             }
         }
         const float var = group_sum(q, lpr) / (float)p.c;
-        const float rstd = NORM == NORM_LN ? 1.0f / sqrtf(var + p.eps) : 0.f;
-        const float sd = NORM == NORM_CN ? sqrtf(var + p.eps) : 1.f;
+        // LN: (x - mu) * rstd (F.layer_norm).  CN: the reference divides by sqrt(var + eps) (layers.py:54); one reciprocal
+        // per row + a multiply per element differs from the per-element division by at most ~1 ulp
+        const float rstd = 1.0f / sqrtf(var + p.eps);
 #pragma unroll
         for (int i = 0; i < MAX_CH; ++i) {
             if (!ok[i]) continue;
@@ -131,8 +132,8 @@ __global__ __launch_bounds__(THREADS) void row_kernel(const RowArgs p, const int
                 v[i] = make_float4((v[i].x - mean) * rstd * w.x + bb.x, (v[i].y - mean) * rstd * w.y + bb.y,
                                    (v[i].z - mean) * rstd * w.z + bb.z, (v[i].w - mean) * rstd * w.w + bb.w);
             } else {
-                v[i] = make_float4(w.x * ((v[i].x - mean) / sd) + bb.x, w.y * ((v[i].y - mean) / sd) + bb.y,
-                                   w.z * ((v[i].z - mean) / sd) + bb.z, w.w * ((v[i].w - mean) / sd) + bb.w);
+                v[i] = make_float4(w.x * ((v[i].x - mean) * rstd) + bb.x, w.y * ((v[i].y - mean) * rstd) + bb.y,
+                                   w.z * ((v[i].z - mean) * rstd) + bb.z, w.w * ((v[i].w - mean) * rstd) + bb.w);
             }
         }
     }
