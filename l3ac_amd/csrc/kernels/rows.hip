@@ -143,6 +143,111 @@ __global__ __launch_bounds__(THREADS) void row_kernel(const RowArgs p, const int
     }
 }
 
+// ---- depth-wise conv k7 + LayerNorm with a rolling register window ------------------------------------------
+// The generic row kernel re-reads each input row seven times (L1/L2-served).  Here a lane group walks SEG consecutive
+// frames of one clip: the 7-row window of its channels, the 7 tap weights and the LayerNorm affine stay in registers,
+// each step loads ONE new row (16 B per lane, contiguous across the group).  Window slot of relative row r is r mod 7,
+// so inside a 7-way unrolled step every index is a compile-time constant.
+// SEG (a multiple of 7, chosen at launch) trades halo re-reads (6 / SEG, L2-served) against the number of independent
+// lane groups: a group's steps are serial, so short clips need short segments to keep every SIMD supplied with waves.
+
+template <int CH>
+__global__ __launch_bounds__(THREADS) void dwconv_ln_kernel(const RowArgs p, const int lpr, const int DW_SEG) {
+    const int groups_per_block = THREADS / lpr;
+    const int64_t seg_per_clip = (p.frames_out + DW_SEG - 1) / DW_SEG;
+    const int64_t seg = (int64_t)blockIdx.x * groups_per_block + threadIdx.x / lpr;
+    const int j = threadIdx.x % lpr;
+    const bool seg_ok = seg < p.batch * seg_per_clip;
+    const int64_t sg = seg_ok ? seg : 0;
+    const int64_t b = sg / seg_per_clip;
+    const int t0 = (int)(sg % seg_per_clip) * DW_SEG;
+    const int frames = (int)p.frames_in;
+    const int nchunk = p.c >> 2;
+    const float* clip = p.x + b * p.frames_in * p.c;
+    float* dst = p.y + b * p.frames_in * p.c;
+
+    bool ok[CH];
+    int c0[CH];
+    float4 wt[7][CH], bias[CH], lw[CH], lb[CH], win[7][CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int chunk = j + i * lpr;
+        ok[i] = seg_ok && chunk < nchunk;
+        c0[i] = (ok[i] ? chunk : 0) << 2;
+        bias[i] = *reinterpret_cast<const float4*>(p.dw_b + c0[i]);
+        lw[i] = *reinterpret_cast<const float4*>(p.nw + c0[i]);
+        lb[i] = *reinterpret_cast<const float4*>(p.nb + c0[i]);
+#pragma unroll
+        for (int tap = 0; tap < 7; ++tap) wt[tap][i] = *reinterpret_cast<const float4*>(p.dw_w + tap * p.c + c0[i]);
+    }
+    auto load_row = [&](int t, int i) -> float4 {
+        if (ok[i] && t >= 0 && t < frames) return *reinterpret_cast<const float4*>(clip + (int64_t)t * p.c + c0[i]);
+        return make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    // rows t0-3 .. t0+2 -> slots 4,5,6,0,1,2
+#pragma unroll
+    for (int d = -3; d <= 2; ++d)
+#pragma unroll
+        for (int i = 0; i < CH; ++i) win[(d + 7) % 7][i] = load_row(t0 + d, i);
+
+    for (int base = 0; base < DW_SEG; base += 7) {
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            const int t = t0 + base + u;
+#pragma unroll
+            for (int i = 0; i < CH; ++i) win[(u + 3) % 7][i] = load_row(t + 3, i);  // overwrites row t-4
+            float4 v[CH];
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                float4 acc = bias[i];
+#pragma unroll
+                for (int tap = 0; tap < 7; ++tap) acc = f4_fma(win[(u + tap + 4) % 7][i], wt[tap][i], acc);  // row t+tap-3
+                v[i] = ok[i] ? acc : make_float4(0.f, 0.f, 0.f, 0.f);
+                s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+            }
+            const float mean = group_sum(s, lpr) / (float)p.c;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                if (ok[i]) {
+                    const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+                    q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+                }
+            }
+            const float rstd = 1.0f / sqrtf(group_sum(q, lpr) / (float)p.c + p.eps);
+            if (t < frames) {
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    if (!ok[i]) continue;
+                    *reinterpret_cast<float4*>(dst + (int64_t)t * p.c + c0[i]) =
+                        make_float4((v[i].x - mean) * rstd * lw[i].x + lb[i].x, (v[i].y - mean) * rstd * lw[i].y + lb[i].y,
+                                    (v[i].z - mean) * rstd * lw[i].z + lb[i].z, (v[i].w - mean) * rstd * lw[i].w + lb[i].w);
+                }
+            }
+        }
+    }
+}
+
+int launch_dwconv_ln(hipStream_t s, const RowArgs& r, int lpr) {
+    // aim at ~6 waves per SIMD worth of lane groups
+    const int64_t rows_per_wave_group = (r.batch * r.frames_out * lpr / 64) / (256 * 4 * 6);
+    int DW_SEG = (int)(rows_per_wave_group / 7) * 7;
+    DW_SEG = DW_SEG < 7 ? 7 : (DW_SEG > 56 ? 56 : DW_SEG);
+    const int64_t segs = r.batch * ((r.frames_out + DW_SEG - 1) / DW_SEG);
+    const int64_t blocks = ceil_div64(segs, THREADS / lpr);
+    if (blocks <= 0) return L3AC_OK;
+    L3AC_REQUIRE(blocks < (int64_t)1 << 31, "rows: grid too large");
+    const double elems = (double)r.batch * r.frames_out * r.c;
+    ProfScope prof(s, "dwconv_ln_kernel", 22.0 * elems, 8.0 * elems);
+    if (r.c <= 4 * lpr)
+        hipLaunchKernelGGL((dwconv_ln_kernel<1>), dim3((unsigned)blocks), dim3(THREADS), 0, s, r, lpr, DW_SEG);
+    else
+        hipLaunchKernelGGL((dwconv_ln_kernel<2>), dim3((unsigned)blocks), dim3(THREADS), 0, s, r, lpr, DW_SEG);
+    L3AC_LAUNCH_CHECK();
+    return L3AC_OK;
+}
+
 template <int SRC, int NORM>
 int launch_rows_t(hipStream_t s, const RowArgs& r, int lpr) {
     const int64_t rows = r.batch * r.frames_out;
@@ -240,6 +345,7 @@ int launch_rows(hipStream_t s, const RowArgs& r) {
     if (r.src == S && r.norm == N) return launch_rows_t<S, N>(s, r, lpr)
     L3AC_ROWS_CASE(SRC_PLAIN, NORM_LN);
     L3AC_ROWS_CASE(SRC_PLAIN, NORM_CN);
+    if (r.src == SRC_DWCONV7 && r.norm == NORM_LN && r.frames_in == r.frames_out) return launch_dwconv_ln(s, r, lpr);
     L3AC_ROWS_CASE(SRC_DWCONV7, NORM_LN);
     L3AC_ROWS_CASE(SRC_LERP, NORM_NONE);
     L3AC_ROWS_CASE(SRC_LERP, NORM_CN);

@@ -206,6 +206,24 @@ def test_edge_cases():
         codec.decode_audio()
 
 
+def test_long_clip_multi_window_attention():
+    """A 6.5 s clip has more frames (1 170) than the 1kbps attention windows (750 / 250): exercises the look-back-one-
+    window masking end to end, and a ragged length (not a multiple of the hop)."""
+    codec = _codec("1kbps", 0)
+    mc = codec.network.mc
+    w = W.folded_weights(codec.network.state_dicts())
+    audio = seeded_audio(2, 104001)
+    taps = {}
+    q_ref, ind_ref = O.encode_audio(w, mc, audio, taps=taps)
+    q, ind = codec.encode_audio(audio.cuda())
+    n_bad, ok = index_mismatch_report(ind["indices"].cpu().numpy(), ind_ref["indices"].numpy(), taps["latents"].numpy(),
+                                      mc.levels, TAU)
+    print(f"[long clip] index mismatches vs oracle: {n_bad}/{ind_ref['indices'].numel()}")
+    assert ok and n_bad <= 8
+    wave = codec.decode_audio(indices=ind_ref["indices"].cuda())
+    assert _err("long clip wave", wave, O.decode_audio(w, mc, indices=ind_ref["indices"])) < WAVE_ATOL
+
+
 def test_streaming_chunks_and_graph_capture():
     """BASELINE config 5: 1 s chunks through a captured graph give the same tokens as eager calls."""
     codec = _codec("1kbps", 0)
