@@ -46,7 +46,7 @@ struct Geo {
     // LDS carve (floats)
     static constexpr int OFF_W1 = 0;                          // [HC][W1S]
     static constexpr int OFF_W2 = OFF_W1 + HC * W1S;          // [C + 1][W2S], last row all zeros (padding channels)
-    static constexpr int OFF_P = OFF_W2 + (C + 1) * W2S;      // (alpha, 1/alpha, gamma, beta) per hidden channel
+    static constexpr int OFF_P = OFF_W2 + (C + 1) * W2S;      // alpha[H4], 1/alpha[H4], gamma[H4], beta[H4]
     static constexpr int OFF_B1 = OFF_P + H4 * 4;
     static constexpr int OFF_B2 = OFF_B1 + H4;
     static constexpr int OFF_DW = OFF_B2 + 32 * CT;           // dw_w [7][C], dw_b, ln_w, ln_b
@@ -92,7 +92,10 @@ __global__ __launch_bounds__(64 * WAVES) void conv_unit_fused_kernel(const ConvU
 
     // ---- parameters resident for the lifetime of the workgroup -------------------------------------------
     for (int i = tid; i < G::H4; i += THREADS) {
-        *reinterpret_cast<float4*>(Ps + 4 * i) = make_float4(w.alpha[i], w.inv_alpha[i], w.gamma[i], w.beta[i]);
+        Ps[i] = w.alpha[i];
+        Ps[G::H4 + i] = w.inv_alpha[i];
+        Ps[2 * G::H4 + i] = w.gamma[i];
+        Ps[3 * G::H4 + i] = w.beta[i];
         B1s[i] = w.b1[i];
     }
     for (int i = tid; i < 32 * G::CT; i += THREADS) B2s[i] = i < C ? w.b2[i] : 0.f;
@@ -256,11 +259,21 @@ __global__ __launch_bounds__(64 * WAVES) void conv_unit_fused_kernel(const ConvU
                 f32x16 xacc = xnext;
                 if (ntl + 1 < G::NTC) xnext = first_product(ntl + 1);
                 // snake + GRN (normaliser == 1) on the accumulator registers (layers.py:29-33, :112-115)
+                // registers (r, r+1), r even, are adjacent hidden channels: packed fp32 math on register pairs
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float4 pr = *reinterpret_cast<const float4*>(Ps + 4 * (n_base + 32 * ntl + rowmap(r, lh)));
-                    const float s = snake_act(xacc[r], pr.x, pr.y);
-                    xacc[r] = (pr.z * s + pr.w) + s;
+                for (int r = 0; r < 16; r += 2) {
+                    const float* pp = Ps + n_base + 32 * ntl + rowmap(r, lh);
+                    const f32x2 al = *reinterpret_cast<const f32x2*>(pp);
+                    const f32x2 ia = *reinterpret_cast<const f32x2*>(pp + G::H4);
+                    const f32x2 ga = *reinterpret_cast<const f32x2*>(pp + 2 * G::H4);
+                    const f32x2 be = *reinterpret_cast<const f32x2*>(pp + 3 * G::H4);
+                    f32x2 hv;
+                    hv.x = xacc[r];
+                    hv.y = xacc[r + 1];
+                    const f32x2 s = snake_act2(hv, al, ia);
+                    const f32x2 o = __builtin_elementwise_fma(ga, s, be) + s;
+                    xacc[r] = o.x;
+                    xacc[r + 1] = o.y;
                 }
                 // Y[c][m] += sum_n W2[c][n] X[n][m]: X's registers are the B operand, row order (r&3)+8(r>>2)+4h
 #pragma unroll

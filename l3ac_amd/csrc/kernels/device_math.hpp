@@ -26,4 +26,26 @@ __device__ __forceinline__ float snake_act(float h, float alpha, float inv_alpha
     return fmaf(inv_alpha, sin_squared(alpha * h), h);
 }
 
+// Packed (two elements per lane) forms: gfx950 executes v_pk_fma_f32 / v_pk_mul_f32 on register pairs, which nearly
+// halves the VALU instruction count of the activation — what co-limits the narrow-stage kernels next to the MFMAs.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2 sin_squared2(f32x2 u) {
+    const f32x2 n = __builtin_elementwise_rint(u * 0.636619772367581343f);
+    f32x2 r = __builtin_elementwise_fma(n, (f32x2)(-1.57079637050628662109375f), u);
+    r = __builtin_elementwise_fma(n, (f32x2)(4.37113900018624283e-8f), r);
+    const f32x2 z = r * r;
+    f32x2 p = __builtin_elementwise_fma(z, (f32x2)(-1.9515295891e-4f), (f32x2)(8.3321608736e-3f));
+    p = __builtin_elementwise_fma(p, z, (f32x2)(-1.6666654611e-1f));
+    const f32x2 s = __builtin_elementwise_fma(p * z, r, r);                              // sin(r), |r| <= pi/4
+    const f32x2 c = __builtin_elementwise_fma(s * s, (f32x2)(-2.0f), (f32x2)(1.0f));      // cos(2r)
+    const i32x2 cb = __builtin_bit_cast(i32x2, c) ^ (__builtin_convertvector(n, i32x2) << 31);  // cos(2u) = (-1)^n cos(2r)
+    return __builtin_elementwise_fma(__builtin_bit_cast(f32x2, cb), (f32x2)(-0.5f), (f32x2)(0.5f));  // (1 - cos 2u) / 2
+}
+
+__device__ __forceinline__ f32x2 snake_act2(f32x2 h, f32x2 alpha, f32x2 inv_alpha) {
+    return __builtin_elementwise_fma(inv_alpha, sin_squared2(alpha * h), h);
+}
+
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

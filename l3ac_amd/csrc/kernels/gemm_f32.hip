@@ -69,19 +69,27 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[N
             gamma = p.gamma[n];
             beta = p.beta[n];
         }
+        if (p.epi == EPI_SNAKE || p.epi == EPI_SNAKE_GRN) {  // packed fp32 math on register pairs (two rows, same column)
+            const f32x2 al = (f32x2)(alpha), ia = (f32x2)(inv_alpha), ga = (f32x2)(gamma), be = (f32x2)(beta), bi = (f32x2)(bias);
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                f32x2 hv;
+                hv.x = acc[nt][r];
+                hv.y = acc[nt][r + 1];
+                const f32x2 sv = snake_act2(hv + bi, al, ia);
+                const f32x2 o = p.epi == EPI_SNAKE_GRN ? __builtin_elementwise_fma(ga, sv, be) + sv : sv;  // layers.py:115, n_x == 1
+                const int64_t m = mw + (r & 3) + 8 * (r >> 2);
+                if (m < p.m) p.c[m * p.ldc + n] = o.x;
+                if (m + 1 < p.m) p.c[(m + 1) * p.ldc + n] = o.y;
+            }
+            continue;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int64_t m = mw + (r & 3) + 8 * (r >> 2);
             if (m >= p.m) continue;
             float v = acc[nt][r] + bias;
-            if (p.epi == EPI_BIAS_RES) {
-                v = p.res[m * p.ldres + n] + v;
-            } else if (p.epi == EPI_SNAKE) {
-                v = snake_act(v, alpha, inv_alpha);
-            } else if (p.epi == EPI_SNAKE_GRN) {
-                const float s = snake_act(v, alpha, inv_alpha);
-                v = (gamma * s + beta) + s;  // layers.py:115 with the normaliser n_x == 1.0f
-            }
+            if (p.epi == EPI_BIAS_RES) v = p.res[m * p.ldres + n] + v;
             p.c[m * p.ldc + n] = v;
         }
     }

@@ -118,10 +118,18 @@ __global__ __launch_bounds__(64 * WAVES) void legacy_unit_kernel(const LegacyW w
     // ---- snake on the accumulator, then Y[c][m] = b2[c] + sum_n W2[c][n] X[n][m] ---------------------------
     f32x16 yacc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float4 pr = *reinterpret_cast<const float4*>(Ps + 4 * rowmap(r, lh));
-        xacc[r] = snake_act(xacc[r], pr.x, pr.y);  // padding rows: alpha 1, 1/alpha 0, bias 0 -> 0
-        yacc[r] = pr.w;
+    for (int r = 0; r < 16; r += 2) {  // packed fp32 math on adjacent hidden channels
+        const float4 p0 = *reinterpret_cast<const float4*>(Ps + 4 * rowmap(r, lh));
+        const float4 p1 = *reinterpret_cast<const float4*>(Ps + 4 * rowmap(r + 1, lh));
+        f32x2 hv, al, ia;
+        hv.x = xacc[r]; hv.y = xacc[r + 1];
+        al.x = p0.x; al.y = p1.x;
+        ia.x = p0.y; ia.y = p1.y;
+        const f32x2 s = snake_act2(hv, al, ia);  // padding rows: alpha 1, 1/alpha 0, bias 0 -> 0
+        xacc[r] = s.x;
+        xacc[r + 1] = s.y;
+        yacc[r] = p0.w;
+        yacc[r + 1] = p1.w;
     }
 #pragma unroll
     for (int g = 0; g < (C + 7) / 8; ++g) {  // hidden rows >= C are zero padding: their k-groups contribute nothing
