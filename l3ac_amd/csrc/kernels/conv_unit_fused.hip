@@ -116,29 +116,32 @@ __global__ __launch_bounds__(64 * WAVES) void conv_unit_fused_kernel(const ConvU
     // input rows [t0 - 3, t0 + 35) of a tile's clip travel global -> registers -> the wave's LDS copy; with a single
     // channel slice (XH == 1) the NEXT tile's rows are fetched into registers while the current tile computes
     constexpr int NPRE = (G::ROWS * (G::XC / 4) + 63) / 64;
+    int pre_row[NPRE], pre_src[NPRE], pre_dst[NPRE];  // tile-invariant: which row / chunk each of this lane's copies moves
+#pragma unroll
+    for (int it = 0; it < NPRE; ++it) {
+        const int i = lane + 64 * it;
+        const int row = i / (G::XC / 4), ch = i % (G::XC / 4);
+        pre_row[it] = i < G::ROWS * (G::XC / 4) ? row - 3 : -(1 << 28);  // past the end: never a valid frame
+        pre_src[it] = (row - 3) * C + 4 * ch;
+        pre_dst[it] = i < G::ROWS * (G::XC / 4) ? row * G::XS + 4 * ch : -1;
+    }
     auto load_rows = [&](int64_t tl, int xh, float4 (&pre)[NPRE]) {
         const bool ok = tl < n_tiles;
         const int bb = ok ? (int)(tl / tiles_per_clip) : 0;
-        const int tt0 = ok ? (int)(tl % tiles_per_clip) * 32 : 0;
-        const float* cl = x + (int64_t)bb * frames * C + xh * G::XC;
+        const int tt0 = ok ? (int)(tl % tiles_per_clip) * 32 : -(1 << 28);
+        const float* cl = x + ((int64_t)bb * frames + (ok ? tt0 : 0)) * C + xh * G::XC;
 #pragma unroll
         for (int it = 0; it < NPRE; ++it) {
-            const int i = lane + 64 * it;
-            const int row = i / (G::XC / 4), ch = i % (G::XC / 4);
-            const int t = tt0 - 3 + row;
+            const int t = tt0 + pre_row[it];
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok && i < G::ROWS * (G::XC / 4) && t >= 0 && t < frames)
-                v = *reinterpret_cast<const float4*>(cl + (int64_t)t * C + 4 * ch);
+            if (t >= 0 && t < frames) v = *reinterpret_cast<const float4*>(cl + pre_src[it]);
             pre[it] = v;
         }
     };
     auto store_rows = [&](const float4 (&pre)[NPRE]) {
 #pragma unroll
-        for (int it = 0; it < NPRE; ++it) {
-            const int i = lane + 64 * it;
-            const int row = i / (G::XC / 4), ch = i % (G::XC / 4);
-            if (i < G::ROWS * (G::XC / 4)) *reinterpret_cast<float4*>(xs + row * G::XS + 4 * ch) = pre[it];
-        }
+        for (int it = 0; it < NPRE; ++it)
+            if (pre_dst[it] >= 0) *reinterpret_cast<float4*>(xs + pre_dst[it]) = pre[it];
     };
     const int64_t tile_stride = (int64_t)gridDim.x * WAVES;
     float4 pre[XH == 1 ? NPRE : 1];  // live across a tile only in the single-slice variants
