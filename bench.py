@@ -76,7 +76,10 @@ def main():
     ap.add_argument("--seconds", type=float, default=1.0)
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL all-gather of outputs (N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-batch", type=int, default=16)
+    ap.add_argument("--cpu-threads", type=int, default=32,
+                    help="host threads for the CPU baseline (32 measured fastest on the 256-thread GPU box; "
+                         "torch's default of 128 is 3x slower: tools/experiments/cpu_threads.py)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph")
     args = ap.parse_args()
 
@@ -207,7 +210,7 @@ def main():
         }
         out["fsq_kernel"] = fsq_microbench(codec, dev)
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(codec, audio, args.cpu_batch, ind)
+            out["cpu_baseline"] = cpu_baseline(codec, audio, args.cpu_batch, ind, args.cpu_threads)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -251,7 +254,7 @@ def fsq_microbench(codec, dev, n_tokens=1 << 22):
             "tokens": n_tokens, "bytes_per_token": bytes_per_token, "ms": ms}
 
 
-def cpu_baseline(codec, audio, cpu_batch, gpu_ind):
+def cpu_baseline(codec, audio, cpu_batch, gpu_ind, threads):
     """The oracle (PyTorch-CPU restatement of the reference path) timed on this box's host cores, rank 0 only,
     on a bounded sample of the same workload; also reports index agreement of the GPU run on those clips."""
     import numpy as np
@@ -260,6 +263,7 @@ def cpu_baseline(codec, audio, cpu_batch, gpu_ind):
     from oracle import l3ac_oracle as O
     from tests.helpers import index_mismatch_report
 
+    torch.set_num_threads(max(1, min(threads, os.cpu_count() or 1)))
     mc = codec.network.mc
     w = W.folded_weights(codec.network.state_dicts())
     x = audio[:cpu_batch].cpu()
@@ -270,7 +274,7 @@ def cpu_baseline(codec, audio, cpu_batch, gpu_ind):
         q, ind = O.encode_audio(w, mc, x)
         O.decode_audio(w, mc, q)
         iters += 1
-        if time.perf_counter() - t0 > 10.0 or iters >= 8:
+        if time.perf_counter() - t0 > 12.0 or iters >= 12:
             break
     dt = (time.perf_counter() - t0) / iters
     n_bad, ok = index_mismatch_report(gpu_ind["indices"][:cpu_batch].cpu().numpy(), ind["indices"].numpy(),
