@@ -123,6 +123,15 @@ int l3ac_fsq_decode(const int32_t* indices, int64_t n, int32_t feat, const int32
 int l3ac_vq_argmin(const float* queries, int64_t n, const float* codebook, int32_t k, int32_t dim,
                    int32_t* out_idx, void* stream);
 
+/* ---- token wire format (no reference counterpart: the reference keeps int32 indices, vq/fsq.py:68) ---------------
+ * Per clip, token t occupies bits [t*bits, (t+1)*bits) of a little-endian bit stream, zero-padded to whole 32-bit
+ * words; bits = ceil(log2(codebook size)) (17 at 1kbps, 18 at 3kbps).
+ *   indices [batch][n_tok] int32  <->  packed [batch][words_per_clip] uint32,  words_per_clip >= ceil(n_tok*bits/32). */
+int l3ac_pack_indices(const int32_t* indices, int32_t batch, int32_t n_tok, int32_t bits, uint32_t* packed,
+                      int32_t words_per_clip, void* stream);
+int l3ac_unpack_indices(const uint32_t* packed, int32_t batch, int32_t n_tok, int32_t bits, int32_t words_per_clip,
+                        int32_t* indices, void* stream);
+
 /* ---- single blocks of a context's network, for per-kernel parity tests ------------------------------ */
 /* `block` is the reference state-dict prefix of the block inside its module file, e.g. "encoder.blocks.1.0.module".
  * Shapes: x / y are [batch][frames][channels] frame-major. */

@@ -27,7 +27,8 @@ from . import _capi
 from . import weights as _weights
 from .config import CONFIG_DIR, L3ACConfig, ModelConfig, list_models, resolve_config_file
 
-__all__ = ["list_models", "get_model", "get_model_info", "L3AC", "L3ACConfig", "ModelConfig", "Network"]
+__all__ = ["list_models", "get_model", "get_model_info", "L3AC", "L3ACConfig", "ModelConfig", "Network",
+           "bits_per_token", "pack_indices", "unpack_indices"]
 __version__ = "0.1.0"
 
 log = logging.getLogger("L3AC")
@@ -202,6 +203,43 @@ class L3AC:
             _capi.check(ctx.lib.l3ac_decode(ctx.handle, f_ptr, i_ptr, b, n_tok, audio.data_ptr(), stream))
         del keep
         return audio
+
+
+def bits_per_token(mc) -> int:
+    """ceil(log2(codebook size)): 17 at 1kbps (117 649 codes), 18 at 3kbps (250 047)."""
+    return max(1, (mc.codebook_size - 1).bit_length())
+
+
+def pack_indices(indices: torch.Tensor, bits: int) -> torch.Tensor:
+    """int indices (B, T_tok) on the GPU -> little-endian bit stream, one row of whole 32-bit words per clip, as
+    uint8 (B, 4 * ceil(T_tok * bits / 32)).  The reference has no wire format (it keeps int32 tensors)."""
+    if not indices.is_cuda or indices.dim() != 2:
+        raise ValueError("indices must be a (batch, tokens) CUDA tensor")
+    idx = indices.to(torch.int32).contiguous()
+    b, n_tok = idx.shape
+    words = -(-n_tok * bits // 32)
+    out = torch.empty((b, words), dtype=torch.int32, device=idx.device)
+    lib = _capi.load_library()
+    with torch.cuda.device(idx.device):
+        _capi.check(lib.l3ac_pack_indices(idx.data_ptr(), b, n_tok, bits, out.data_ptr(), words,
+                                          torch.cuda.current_stream(idx.device).cuda_stream))
+    return out.view(torch.uint8)
+
+
+def unpack_indices(packed: torch.Tensor, n_tok: int, bits: int) -> torch.Tensor:
+    """Inverse of `pack_indices`: uint8 (B, 4 * words) -> int32 (B, n_tok)."""
+    if not packed.is_cuda or packed.dim() != 2 or packed.dtype != torch.uint8 or packed.shape[1] % 4:
+        raise ValueError("packed must be a (batch, 4 * words) uint8 CUDA tensor")
+    words = packed.shape[1] // 4
+    if words * 32 < n_tok * bits:
+        raise ValueError("packed stream too short for n_tok tokens")
+    src = packed.contiguous().view(torch.int32)
+    out = torch.empty((packed.shape[0], n_tok), dtype=torch.int32, device=packed.device)
+    lib = _capi.load_library()
+    with torch.cuda.device(packed.device):
+        _capi.check(lib.l3ac_unpack_indices(src.data_ptr(), packed.shape[0], n_tok, bits, words, out.data_ptr(),
+                                            torch.cuda.current_stream(packed.device).cuda_stream))
+    return out
 
 
 def get_model(config_name, model_dir=None, synthetic_seed: Optional[int] = None) -> L3AC:

@@ -68,6 +68,8 @@ SIGNATURES = {
     "l3ac_op_en_decoder": (C.c_int, [_P, _P, _I32, _I32, _P, _P]),
     "l3ac_op_decoder": (C.c_int, [_P, _P, _I32, _I32, _P, _P]),
     "l3ac_gemm_f32": (C.c_int, [_P, _I64, _P, _P, _P, _I64, _I64, _I32, _I32, _P]),
+    "l3ac_pack_indices": (C.c_int, [_P, _I32, _I32, _I32, _P, _I32, _P]),
+    "l3ac_unpack_indices": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P]),
     "l3ac_profile_begin": (C.c_int, []),
     "l3ac_profile_end": (C.c_int, [_P, _I32, C.POINTER(_I32)]),
 }

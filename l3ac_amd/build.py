@@ -30,6 +30,7 @@ SOURCES = [
     "kernels/fsq.hip",
     "kernels/conv_unit_fused.hip",
     "kernels/last_block.hip",
+    "kernels/bitpack.hip",
 ]
 
 

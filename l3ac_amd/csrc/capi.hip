@@ -314,6 +314,18 @@ int l3ac_op_decoder(l3ac_ctx* ctx, const float* feature, int32_t batch, int32_t 
     return run_decoder(ctx, s, batch, frames, &cur, &alt, audio);
 }
 
+int l3ac_pack_indices(const int32_t* indices, int32_t batch, int32_t n_tok, int32_t bits, uint32_t* packed,
+                      int32_t words_per_clip, void* stream) {
+    L3AC_REQUIRE(indices && packed, "pack: null buffer");
+    return launch_pack_indices((hipStream_t)stream, indices, batch, n_tok, bits, packed, words_per_clip);
+}
+
+int l3ac_unpack_indices(const uint32_t* packed, int32_t batch, int32_t n_tok, int32_t bits, int32_t words_per_clip,
+                        int32_t* indices, void* stream) {
+    L3AC_REQUIRE(indices && packed, "unpack: null buffer");
+    return launch_unpack_indices((hipStream_t)stream, packed, batch, n_tok, bits, words_per_clip, indices);
+}
+
 int l3ac_profile_begin(void) {
     L3AC_REQUIRE(g_profiler == nullptr, "profile already active on this thread");
     g_profiler = new (std::nothrow) Profiler();

@@ -248,3 +248,33 @@ def test_streaming_chunks_and_graph_capture():
         torch.cuda.synchronize()
         assert torch.equal(ind["indices"], eager[i][1]["indices"])
         assert torch.equal(wave, eager_wave[i])
+
+
+def test_token_bit_packing_roundtrip():
+    """Wire format: little-endian bit stream, ceil(log2 K) bits per token, checked against numpy."""
+    for tag, bits in (("1kbps", 17), ("3kbps", 18)):
+        codec = _codec(tag, 0)
+        mc = codec.network.mc
+        assert l3ac_amd.bits_per_token(mc) == bits
+        g = torch.Generator().manual_seed(5)
+        for n_tok in (1, 7, 60, 167, 1000):
+            idx = torch.randint(0, mc.codebook_size, (5, n_tok), generator=g, dtype=torch.int32)
+            idx[0, 0] = mc.codebook_size - 1
+            packed = l3ac_amd.pack_indices(idx.cuda(), bits)
+            assert packed.dtype == torch.uint8 and packed.shape == (5, 4 * (-(-n_tok * bits // 32)))
+            # numpy reference: token t occupies stream bits [t*bits, (t+1)*bits), bit b = bit b%8 of byte b//8
+            ref = np.zeros((5, packed.shape[1] * 8), dtype=np.uint8)
+            for t in range(n_tok):
+                for k in range(bits):
+                    ref[:, t * bits + k] = (idx[:, t].numpy() >> k) & 1
+            ref_bytes = np.packbits(ref, axis=1, bitorder="little")
+            np.testing.assert_array_equal(packed.cpu().numpy(), ref_bytes)
+            back = l3ac_amd.unpack_indices(packed, n_tok, bits)
+            assert torch.equal(back.cpu(), idx)
+    # end to end: audio -> tokens -> bytes -> tokens -> audio is bit-identical to decoding the tokens directly
+    codec = _codec("1kbps", 0)
+    q, ind = codec.encode_audio(seeded_audio(3, 16000).cuda())
+    packed = l3ac_amd.pack_indices(ind["indices"], 17)
+    assert packed.shape[1] * 8 / 1.0125 <= 1024 + 8  # 60 tokens * 17 bits = 1020 bits for 1.0125 s ~ 998 bps + padding
+    wave = codec.decode_audio(indices=l3ac_amd.unpack_indices(packed, 60, 17))
+    assert torch.equal(wave, codec.decode_audio(indices=ind["indices"]))
