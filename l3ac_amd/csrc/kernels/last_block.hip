@@ -3,7 +3,9 @@
 //   LegacyUnit (x3, dilation 1 / 3 / 9):   y = x + Conv1x1( snake( Conv_k7_dilated( snake(x) ) ) )      C -> C
 //   head:                                  audio = tanh( Conv_k7( snake(y) ) )                           C -> 1
 //
-// legacy_unit_kernel — one workgroup = 256 consecutive frames of one clip (8 waves x 32 frames):
+// legacy_unit_kernel — persistent workgroups (2 per CU) walk tiles of 256 consecutive frames of one clip
+// (8 waves x 32 frames); the weights are staged into LDS once per workgroup and the next tile's input rows are
+// prefetched into registers while the current tile's products run:
 //   * snake(x) for the 256 + 6*dil frames the block needs is evaluated ONCE into an LDS tile (zeros outside the
 //     clip = the conv's zero padding), so the dilated k7 conv is an implicit product whose B operand is read from
 //     that tile at row (frame + tap*dil);
@@ -30,6 +32,7 @@ __device__ __forceinline__ int rowmap(int r, int hh) { return (r & 3) + 8 * (r >
 
 template <int C>
 struct LGeo {
+    static_assert(C % 8 == 0, "a k-group of 8 must not straddle two taps");
     static constexpr int K = 7 * C;
     static constexpr int KQ = (K + 7) / 8;   // k groups of 8 (zero padded)
     static constexpr int SS = C + 4;         // S tile row stride: an odd number of 16-B slots (conflict-free b128)
@@ -43,30 +46,53 @@ struct LGeo {
 };
 
 template <int C>
-__global__ __launch_bounds__(64 * WAVES) void legacy_unit_kernel(const LegacyW w, const float* __restrict__ x,
-                                                                float* __restrict__ y, int frames) {
+__global__ __launch_bounds__(64 * WAVES, 4) void legacy_unit_kernel(const LegacyW w, const float* __restrict__ x,
+                                                                float* __restrict__ y, int frames, int tiles_per_clip,
+                                                                int total_tiles) {
     using G = LGeo<C>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* W1s = smem + G::OFF_W1;
     float* W2s = smem + G::OFF_W2;
     float* Ps = smem + G::OFF_P;
     float* Ss = smem + G::OFF_S;
+    constexpr int NT = 64 * WAVES;
+    // input staging: RPP rows per pass, each thread keeps ONE channel quad c0 (so snake's parameters are loaded
+    // once) and PF rows of it; threads beyond RPP * C/4 idle (C = 24: 2 of 512)
+    constexpr int RPP = NT / (C / 4);
+    constexpr int PF = (FRAMES + 54 + RPP - 1) / RPP;  // dil <= 9
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int dil = w.dil;
-    const int b = blockIdx.y;
-    const int t0 = blockIdx.x * FRAMES;
-    const float* clip = x + (int64_t)b * frames * C;
+    const int rows = FRAMES + 6 * dil;
 
-    // ---- weights (zero padded to 32 rows / 8*KQ columns) -----------------------------------------------
-    for (int i = tid; i < 32 * (G::W1S / 4); i += 64 * WAVES) {
+    const int srow = tid / (C / 4) + (tid < RPP * (C / 4) ? 0 : FRAMES + 54);  // idle threads: row beyond the tile
+    const int sc0 = 4 * (tid % (C / 4));
+    // input rows of one tile -> registers (zeros outside the clip = the conv's zero padding; snake(0) = 0)
+    float4 pre[PF];
+    auto prefetch = [&](int tile) {
+        const int b = tile / tiles_per_clip;
+        const int t0 = (tile - b * tiles_per_clip) * FRAMES;
+        const float* clip = x + (int64_t)b * frames * C;
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            const int row = srow + j * RPP;
+            const int t = t0 - 3 * dil + row;
+            pre[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < rows && t >= 0 && t < frames) pre[j] = *reinterpret_cast<const float4*>(clip + (int64_t)t * C + sc0);
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < total_tiles) prefetch(tile);
+
+    // ---- weights (zero padded to 32 rows / 8*KQ columns), staged once per workgroup ---------------------------
+    for (int i = tid; i < 32 * (G::W1S / 4); i += NT) {
         const int row = i / (G::W1S / 4), k = 4 * (i % (G::W1S / 4));
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (row < C && k < G::K) v = *reinterpret_cast<const float4*>(w.w1 + row * G::K + k);
         *reinterpret_cast<float4*>(W1s + row * G::W1S + k) = v;
     }
-    for (int i = tid; i < 32 * (G::W2S / 4); i += 64 * WAVES) {
+    for (int i = tid; i < 32 * (G::W2S / 4); i += NT) {
         const int row = i / (G::W2S / 4), k = 4 * (i % (G::W2S / 4));
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (row < C && k < C) v = *reinterpret_cast<const float4*>(w.w2 + row * C + k);
@@ -77,82 +103,100 @@ __global__ __launch_bounds__(64 * WAVES) void legacy_unit_kernel(const LegacyW w
         *reinterpret_cast<float4*>(Ps + 4 * tid) =
             make_float4(ok ? w.a1[tid] : 1.f, ok ? w.ia1[tid] : 0.f, ok ? w.b1[tid] : 0.f, ok ? w.b2[tid] : 0.f);
     }
-    // ---- S tile: snake(x) for frames [t0 - 3 dil, t0 + FRAMES + 3 dil), zeros outside the clip ------------
-    const int rows = FRAMES + 6 * dil;
-    for (int i = tid; i < rows * (C / 4); i += 64 * WAVES) {
-        const int row = i / (C / 4), c0 = 4 * (i % (C / 4));
-        const int t = t0 - 3 * dil + row;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t >= 0 && t < frames) {
-            const float4 xv = *reinterpret_cast<const float4*>(clip + (int64_t)t * C + c0);
-            const float4 al = *reinterpret_cast<const float4*>(w.a0 + c0);
-            const float4 ia = *reinterpret_cast<const float4*>(w.ia0 + c0);
-            v = make_float4(snake_act(xv.x, al.x, ia.x), snake_act(xv.y, al.y, ia.y), snake_act(xv.z, al.z, ia.z),
-                            snake_act(xv.w, al.w, ia.w));
-        }
-        *reinterpret_cast<float4*>(Ss + row * G::SS + c0) = v;
-    }
-    __syncthreads();
-
     const int lj = lane & 31;
     const int lh = lane >> 5;
     const int m0 = 32 * wave;
-    if (t0 + m0 >= frames) return;  // whole wave beyond the clip (no barriers follow)
 
-    // ---- X[n][m] = b1[n] + sum_{tap,c} W1[n][tap*C + c] S[m + (tap - 3) dil][c] ------------------------------
-    f32x16 xacc;
+    for (; tile < total_tiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_clip;
+        const int t0 = (tile - b * tiles_per_clip) * FRAMES;
+        const float* clip = x + (int64_t)b * frames * C;
+        // ---- S tile: snake(x) for frames [t0 - 3 dil, t0 + FRAMES + 3 dil) ---------------------------------
+        const float4 al = *reinterpret_cast<const float4*>(w.a0 + sc0);
+        const float4 ia = *reinterpret_cast<const float4*>(w.ia0 + sc0);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) xacc[r] = Ps[4 * rowmap(r, lh) + 2];
-#pragma unroll
-    for (int q = 0; q < G::KQ; ++q) {
-        const int k = 8 * q + 4 * lh;
-        const int tap = k / C, c = k % C;
-        float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < G::K) sv = *reinterpret_cast<const float4*>(Ss + (m0 + lj + tap * dil) * G::SS + c);
-        const float4 wf = *reinterpret_cast<const float4*>(W1s + lj * G::W1S + k);
-        xacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.x, sv.x, xacc, 0, 0, 0);
-        xacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.y, sv.y, xacc, 0, 0, 0);
-        xacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.z, sv.z, xacc, 0, 0, 0);
-        xacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.w, sv.w, xacc, 0, 0, 0);
-    }
-    // ---- snake on the accumulator, then Y[c][m] = b2[c] + sum_n W2[c][n] X[n][m] ---------------------------
-    f32x16 yacc;
-#pragma unroll
-    for (int r = 0; r < 16; r += 2) {  // packed fp32 math on adjacent hidden channels
-        const float4 p0 = *reinterpret_cast<const float4*>(Ps + 4 * rowmap(r, lh));
-        const float4 p1 = *reinterpret_cast<const float4*>(Ps + 4 * rowmap(r + 1, lh));
-        f32x2 hv, al, ia;
-        hv.x = xacc[r]; hv.y = xacc[r + 1];
-        al.x = p0.x; al.y = p1.x;
-        ia.x = p0.y; ia.y = p1.y;
-        const f32x2 s = snake_act2(hv, al, ia);  // padding rows: alpha 1, 1/alpha 0, bias 0 -> 0
-        xacc[r] = s.x;
-        xacc[r + 1] = s.y;
-        yacc[r] = p0.w;
-        yacc[r + 1] = p1.w;
-    }
-#pragma unroll
-    for (int g = 0; g < (C + 7) / 8; ++g) {  // hidden rows >= C are zero padding: their k-groups contribute nothing
-        const float4 wf = *reinterpret_cast<const float4*>(W2s + lj * G::W2S + 8 * g + 4 * lh);
-        yacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.x, xacc[4 * g], yacc, 0, 0, 0);
-        yacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.y, xacc[4 * g + 1], yacc, 0, 0, 0);
-        yacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.z, xacc[4 * g + 2], yacc, 0, 0, 0);
-        yacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.w, xacc[4 * g + 3], yacc, 0, 0, 0);
-    }
-    // ---- residual + store: lane (frame lj, half lh) owns channels 8 g + 4 lh + {0..3} -------------------
-    const int t = t0 + m0 + lj;
-    if (t < frames) {
-        const float* src = clip + (int64_t)t * C;
-        float* dst = y + ((int64_t)b * frames + t) * C;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int c0 = 8 * g + 4 * lh;
-            if (c0 < C) {
-                const float4 xr = *reinterpret_cast<const float4*>(src + c0);
-                *reinterpret_cast<float4*>(dst + c0) = make_float4(xr.x + yacc[4 * g], xr.y + yacc[4 * g + 1],
-                                                                   xr.z + yacc[4 * g + 2], xr.w + yacc[4 * g + 3]);
+        for (int j = 0; j < PF; ++j) {
+            const int row = srow + j * RPP;
+            if (row < rows) {
+                const float4 xv = pre[j];
+                *reinterpret_cast<float4*>(Ss + row * G::SS + sc0) =
+                    make_float4(snake_act(xv.x, al.x, ia.x), snake_act(xv.y, al.y, ia.y), snake_act(xv.z, al.z, ia.z),
+                                snake_act(xv.w, al.w, ia.w));
             }
         }
+        __syncthreads();
+        if (tile + (int)gridDim.x < total_tiles) prefetch(tile + gridDim.x);  // in flight during the products
+
+        // An opaque zero offset per tile keeps the (tile-invariant) weight fragments in LDS: hoisted out of the
+        // tile loop they would cost ~100 VGPRs and halve the occupancy.
+        int woff = 0;
+        asm volatile("" : "+s"(woff));
+        const float* W1t = W1s + woff;
+        const float* W2t = W2s + woff;
+        const float* Pt = Ps + woff;
+        if (t0 + m0 < frames) {  // wave-uniform: a wave wholly beyond the clip only takes part in the barriers
+            // ---- X[n][m] = b1[n] + sum_{tap,c} W1[n][tap*C + c] S[m + (tap - 3) dil][c] ----------------------
+            f32x16 xacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xacc[r] = Pt[4 * rowmap(r, lh) + 2];
+            // C % 8 == 0: both halves of a k-group of 8 lie in the same tap, so the S address is one per-lane base
+            // + a wave-uniform tap offset + an immediate
+            const float* sl = Ss + (m0 + lj) * G::SS + 4 * lh;
+            const float* wl = W1t + lj * G::W1S + 4 * lh;
+#pragma unroll
+            for (int tap = 0; tap < 7; ++tap) {
+                const float* st = sl + tap * dil * G::SS;
+#pragma unroll
+                for (int g = 0; g < C / 8; ++g) {
+                    const float4 sv = *reinterpret_cast<const float4*>(st + 8 * g);
+                    const float4 wf = *reinterpret_cast<const float4*>(wl + tap * C + 8 * g);
+                    xacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.x, sv.x, xacc, 0, 0, 0);
+                    xacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.y, sv.y, xacc, 0, 0, 0);
+                    xacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.z, sv.z, xacc, 0, 0, 0);
+                    xacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.w, sv.w, xacc, 0, 0, 0);
+                }
+            }
+            // ---- snake on the accumulator, then Y[c][m] = b2[c] + sum_n W2[c][n] X[n][m] -------------------
+            f32x16 yacc;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {  // packed fp32 math on adjacent hidden channels
+                const float4 p0 = *reinterpret_cast<const float4*>(Pt + 4 * rowmap(r, lh));
+                const float4 p1 = *reinterpret_cast<const float4*>(Pt + 4 * rowmap(r + 1, lh));
+                f32x2 hv, al, ia;
+                hv.x = xacc[r]; hv.y = xacc[r + 1];
+                al.x = p0.x; al.y = p1.x;
+                ia.x = p0.y; ia.y = p1.y;
+                const f32x2 s = snake_act2(hv, al, ia);  // padding rows: alpha 1, 1/alpha 0, bias 0 -> 0
+                xacc[r] = s.x;
+                xacc[r + 1] = s.y;
+                yacc[r] = p0.w;
+                yacc[r + 1] = p1.w;
+            }
+#pragma unroll
+            for (int g = 0; g < (C + 7) / 8; ++g) {  // hidden rows >= C are zero padding: no contribution
+                const float4 wf = *reinterpret_cast<const float4*>(W2t + lj * G::W2S + 8 * g + 4 * lh);
+                yacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.x, xacc[4 * g], yacc, 0, 0, 0);
+                yacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.y, xacc[4 * g + 1], yacc, 0, 0, 0);
+                yacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.z, xacc[4 * g + 2], yacc, 0, 0, 0);
+                yacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.w, xacc[4 * g + 3], yacc, 0, 0, 0);
+            }
+            // ---- residual + store: lane (frame lj, half lh) owns channels 8 g + 4 lh + {0..3} ---------------
+            const int t = t0 + m0 + lj;
+            if (t < frames) {
+                const float* src = clip + (int64_t)t * C;
+                float* dst = y + ((int64_t)b * frames + t) * C;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c0 = 8 * g + 4 * lh;
+                    if (c0 < C) {
+                        const float4 xr = *reinterpret_cast<const float4*>(src + c0);
+                        *reinterpret_cast<float4*>(dst + c0) = make_float4(xr.x + yacc[4 * g], xr.y + yacc[4 * g + 1],
+                                                                           xr.z + yacc[4 * g + 2], xr.w + yacc[4 * g + 3]);
+                    }
+                }
+            }
+        }
+        __syncthreads();  // every wave is done with the S tile before the next one overwrites it
     }
 }
 
@@ -212,9 +256,13 @@ int launch_legacy_t(hipStream_t s, const LegacyW& w, const float* x, float* y, i
         configured = true;
     }
     const double rows = (double)batch * frames;
+    const int tiles_per_clip = (int)ceil_div64(frames, FRAMES);
+    const int64_t total = (int64_t)tiles_per_clip * batch;
+    L3AC_REQUIRE(total < (1ll << 31), "legacy unit: too many tiles");
+    const unsigned grid = (unsigned)std::min<int64_t>(total, 2 * 256);  // persistent: 2 workgroups per CU
     ProfScope prof(s, "legacy_unit_kernel", rows * (2.0 * 7 * C * C + 2.0 * C * C + 40.0 * C), rows * 8.0 * C);
-    hipLaunchKernelGGL((legacy_unit_kernel<C>), dim3((unsigned)ceil_div64(frames, FRAMES), (unsigned)batch), dim3(64 * WAVES), lds,
-                       s, w, x, y, frames);
+    hipLaunchKernelGGL((legacy_unit_kernel<C>), dim3(grid), dim3(64 * WAVES), lds, s, w, x, y, frames, tiles_per_clip,
+                       (int)total);
     L3AC_LAUNCH_CHECK();
     return L3AC_OK;
 }
