@@ -175,6 +175,23 @@ int l3ac_profile_end(l3ac_profile_entry* out, int32_t cap, int32_t* n_out);
 int l3ac_gemm_f32(const float* a, int64_t lda, const float* w, const float* bias, float* c, int64_t ldc,
                   int64_t m, int32_t n, int32_t k, void* stream);
 
+/* ---- fp32 products on the bf16 matrix cores ("bf16x3" operand splitting; kernels/gemm_split.hip) -----------------
+ * Every fp32 operand is split exactly into three bf16 planes (3 x 8 significant bits = the 24-bit significand) and the
+ * product is the six plane products of order <= 2, accumulated in fp32: error vs fp64 no larger than the fp32 fmaf
+ * chain's (tests/test_gpu_blocks.py::test_gemm_split_accuracy), at 2.67x fewer matrix-core cycles.  The network's large
+ * channel contractions use it by default; l3ac_set_gemm_split(0) (or L3AC_GEMM_SPLIT=0 in the environment) routes
+ * every product through the exact v_mfma_f32_32x32x2_f32 kernel instead.  Process-wide switch.
+ * (reference counterpart: none — torch.nn.functional.linear / conv1d on fp32 tensors.) */
+void l3ac_set_gemm_split(int32_t enable);
+int32_t l3ac_get_gemm_split(void);
+/* Weight image for l3ac_gemm_split_f32: w [n][k] fp32 -> `image` (device, l3ac_gemm_split_image_bytes(n, k) bytes;
+ * 0 = shape not eligible: needs n >= 128, k >= 32, k % 8 == 0). */
+int64_t l3ac_gemm_split_image_bytes(int32_t n, int32_t k);
+int l3ac_gemm_split_image(const float* w, int32_t n, int32_t k, void* image, void* stream);
+/* c[m][n] = a[m][:] . w[n][:] + bias[n] with w given as its split image (a [m][k] fp32, row stride lda). */
+int l3ac_gemm_split_f32(const float* a, int64_t lda, const void* image, const float* bias, float* c, int64_t ldc,
+                        int64_t m, int32_t n, int32_t k, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,7 +27,7 @@ from . import _capi
 from . import weights as _weights
 from .config import CONFIG_DIR, L3ACConfig, ModelConfig, list_models, resolve_config_file
 
-__all__ = ["list_models", "get_model", "get_model_info", "L3AC", "L3ACConfig", "ModelConfig", "Network",
+__all__ = ["set_gemm_split", "get_gemm_split", "list_models", "get_model", "get_model_info", "L3AC", "L3ACConfig", "ModelConfig", "Network",
            "bits_per_token", "pack_indices", "unpack_indices"]
 __version__ = "0.1.0"
 
@@ -203,6 +203,16 @@ class L3AC:
             _capi.check(ctx.lib.l3ac_decode(ctx.handle, f_ptr, i_ptr, b, n_tok, audio.data_ptr(), stream))
         del keep
         return audio
+
+
+def set_gemm_split(enable: bool) -> None:
+    """Process-wide: route the large fp32 channel contractions through the bf16x3 split-operand kernel (default, fp32
+    accuracy on the bf16 matrix cores) or through the exact v_mfma_f32_32x32x2_f32 kernel (include/l3ac_hip.h)."""
+    _capi.load_library().l3ac_set_gemm_split(int(bool(enable)))
+
+
+def get_gemm_split() -> bool:
+    return bool(_capi.load_library().l3ac_get_gemm_split())
 
 
 def bits_per_token(mc) -> int:

@@ -23,6 +23,7 @@ SOURCES = [
     "capi.hip",
     "network.hip",
     "kernels/gemm_f32.hip",
+    "kernels/gemm_split.hip",
     "kernels/rows.hip",
     "kernels/first_block.hip",
     "kernels/enhance.hip",

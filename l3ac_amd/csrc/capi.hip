@@ -378,4 +378,24 @@ int l3ac_gemm_f32(const float* a, int64_t lda, const float* w, const float* bias
     return launch_gemm((hipStream_t)stream, g);
 }
 
+void l3ac_set_gemm_split(int32_t enable) { gemm_split_set_enabled(enable != 0); }
+int32_t l3ac_get_gemm_split(void) { return gemm_split_enabled() ? 1 : 0; }
+
+int64_t l3ac_gemm_split_image_bytes(int32_t n, int32_t k) {
+    return (n > 0 && k > 0 && gemm_split_eligible(n, k)) ? gemm_split_image_bytes(n, k) : 0;
+}
+
+int l3ac_gemm_split_image(const float* w, int32_t n, int32_t k, void* image, void* stream) {
+    L3AC_REQUIRE(gemm_split_eligible(n, k), "split image: shape n=%d k=%d is not eligible (n >= 128, k >= 32, k %% 8 == 0)", n, k);
+    return launch_gemm_split_image((hipStream_t)stream, w, k, n, k, (unsigned char*)image);
+}
+
+int l3ac_gemm_split_f32(const float* a, int64_t lda, const void* image, const float* bias, float* c, int64_t ldc, int64_t m,
+                        int32_t n, int32_t k, void* stream) {
+    GemmArgs g{};
+    g.a = a; g.lda = lda; g.w_img = (const unsigned char*)image; g.c = c; g.ldc = ldc; g.m = m; g.n = n; g.k = k; g.bias = bias;
+    g.epi = EPI_BIAS;
+    return launch_gemm_split((hipStream_t)stream, g);
+}
+
 }  // extern "C"

@@ -25,6 +25,9 @@ struct GemmArgs {
     // W operand [n][k] (row stride ldw), output c [m][ldc]
     const float* w = nullptr;
     int64_t ldw = 0;
+    // optional pre-split bf16x3 image of w (gemm_split.hip); when set, enabled and the shape is eligible the product
+    // runs on the bf16 matrix cores at fp32 accuracy, otherwise on the exact-fp32 MFMA kernel
+    const unsigned char* w_img = nullptr;
     float* c = nullptr;
     int64_t ldc = 0;
     int64_t m = 0;
@@ -41,6 +44,16 @@ struct GemmArgs {
     int n_out = 0;                     // EPI_GEGLU: number of valid output columns (ff inner)
 };
 int launch_gemm(hipStream_t s, const GemmArgs& g);
+
+// bf16x3 split-operand GEMM (kernels/gemm_split.hip)
+#define L3AC_SPLIT_TILE_BYTES 24576  // one k tile (32) of one column block (128): 3 planes x 128 rows x 64 B
+bool gemm_split_enabled();                 // L3AC_GEMM_SPLIT (default 1) or the last gemm_split_set_enabled()
+void gemm_split_set_enabled(bool on);
+bool gemm_split_eligible(int n, int k);
+int64_t gemm_split_image_bytes(int n, int k);
+void gemm_split_image_host(const float* w, int64_t ldw, int n, int k, unsigned char* img);  // img: host buffer
+int launch_gemm_split_image(hipStream_t s, const float* w, int64_t ldw, int n, int k, unsigned char* img);  // device
+int launch_gemm_split(hipStream_t s, const GemmArgs& g);
 
 // ------------------------------------------------------------------------------------------------
 // row kernels: one output row = one frame (all channels), optional per-row normalisation

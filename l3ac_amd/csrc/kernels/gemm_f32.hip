@@ -18,6 +18,7 @@
 //     t + (tap - taps/2) * dil of the same clip, zero outside it — no im2col buffer.
 #include "../kernels.hpp"
 #include "device_math.hpp"
+#include "gemm_epilogue.hpp"
 
 #include <cstdio>
 #include <cstdlib>
@@ -27,72 +28,11 @@ namespace {
 constexpr int BM = 128;
 constexpr int THREADS = 256;
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
 // float index of 16-B chunk `chunk` of row `row` in a [rows][BK] tile; the XOR spreads the 16 rows a
 // ds_read_b128 lane group touches over all 16 slots of the 256-B bank row
 template <int BK>
 __device__ __forceinline__ int lds_off(int row, int chunk) {
     return BK == 32 ? row * 32 + ((chunk ^ ((row >> 1) & 7)) << 2) : row * 16 + ((chunk ^ ((row >> 2) & 3)) << 2);
-}
-
-// ---- epilogue: lane holds column n = n0 + 32 nt + li, rows m0 + 32 wave + (r&3) + 8 (r>>2) + 4 lh ----
-template <int NT>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[NT], int64_t m0, int n0, int wave, int li, int lh) {
-    const int64_t mw = m0 + 32 * wave + 4 * lh;
-    if (p.epi == EPI_GEGLU) {
-        // column tiles come in (value, gate) pairs; output column j = n0/2 + 32 (nt/2) + li
-#pragma unroll
-        for (int nt = 0; nt + 1 < NT; nt += 2) {
-            const int j = (n0 >> 1) + 16 * nt + li;
-            if (j < (int)p.ldc) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t m = mw + (r & 3) + 8 * (r >> 2);
-                    if (m < p.m) p.c[m * p.ldc + j] = acc[nt][r] * gelu_erf(acc[nt + 1][r]);
-                }
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int n = n0 + 32 * nt + li;
-        if (n >= p.n) continue;
-        const float bias = p.bias ? p.bias[n] : 0.f;
-        float alpha = 0.f, inv_alpha = 0.f, gamma = 0.f, beta = 0.f;
-        if (p.epi == EPI_SNAKE || p.epi == EPI_SNAKE_GRN) {
-            alpha = p.alpha[n];
-            inv_alpha = p.inv_alpha[n];
-        }
-        if (p.epi == EPI_SNAKE_GRN) {
-            gamma = p.gamma[n];
-            beta = p.beta[n];
-        }
-        if (p.epi == EPI_SNAKE || p.epi == EPI_SNAKE_GRN) {  // packed fp32 math on register pairs (two rows, same column)
-            const f32x2 al = (f32x2)(alpha), ia = (f32x2)(inv_alpha), ga = (f32x2)(gamma), be = (f32x2)(beta), bi = (f32x2)(bias);
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                f32x2 hv;
-                hv.x = acc[nt][r];
-                hv.y = acc[nt][r + 1];
-                const f32x2 sv = snake_act2(hv + bi, al, ia);
-                const f32x2 o = p.epi == EPI_SNAKE_GRN ? __builtin_elementwise_fma(ga, sv, be) + sv : sv;  // layers.py:115, n_x == 1
-                const int64_t m = mw + (r & 3) + 8 * (r >> 2);
-                if (m < p.m) p.c[m * p.ldc + n] = o.x;
-                if (m + 1 < p.m) p.c[(m + 1) * p.ldc + n] = o.y;
-            }
-            continue;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t m = mw + (r & 3) + 8 * (r >> 2);
-            if (m >= p.m) continue;
-            float v = acc[nt][r] + bias;
-            if (p.epi == EPI_BIAS_RES) v = p.res[m * p.ldres + n] + v;
-            p.c[m * p.ldc + n] = v;
-        }
-    }
 }
 
 // FULLK: k is a multiple of BK and A is plain rows -> the staging loads are unconditional (rows / columns past the
@@ -405,6 +345,9 @@ int launch_gemm(hipStream_t s, const GemmArgs& g) {
                  (long long)g.ldw);
     L3AC_REQUIRE(((uintptr_t)g.a & 15) == 0 && ((uintptr_t)g.w & 15) == 0, "gemm: operands must be 16-byte aligned");
     const bool conv = g.taps > 1;
+    // bf16x3 split route (gemm_split.hip).  The choice depends on the WEIGHT's shape only, never on m: a clip must give
+    // bit-identical tokens and samples whether it is coded alone or inside a batch (tests: test_full_batch_properties).
+    if (g.w_img && !conv && gemm_split_eligible(g.n, g.k) && gemm_split_enabled()) return launch_gemm_split(s, g);
     if (conv) {
         L3AC_REQUIRE(g.cin > 0 && g.cin % 4 == 0 && g.k == g.taps * g.cin && g.frames > 0 && g.m % g.frames == 0,
                      "gemm: bad implicit-conv geometry (taps=%d cin=%d k=%d frames=%lld m=%lld)", g.taps, g.cin, g.k,

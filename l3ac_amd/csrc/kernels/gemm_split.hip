@@ -1,0 +1,279 @@
+// fp32-grade GEMM on the bf16 matrix cores by operand splitting ("bf16x3"), used for the large channel contractions
+// (same call sites as gemm_f32.hip; reference: nn.Linear / nn.Conv1d in l3ac/modules.py:19-36,96-99,161 and the
+// local_attention linears).
+//
+//   c[m][n] = epilogue( sum_k a[m][k] * w[n][k] )
+//
+// Numerics.  x = x0 + x1 + x2 with x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1), round-to-nearest-even:
+// three 8-bit significands = the whole 24-bit fp32 significand, so the split loses nothing.  a.w is evaluated as the
+// six plane products with i + j <= 2 (a2w0, a1w1, a0w2, a1w0, a0w1, a0w0 — smallest first), each product exact in
+// fp32 (8 x 8 bits), accumulated in the MFMA's fp32 accumulator; the three dropped products are <= 2^-26 |a.w|, below
+// fp32's own product rounding (2^-24).  Measured against fp64 on the L3AC shapes (tools/experiments/split_gemm.hip,
+// tests/test_gpu_blocks.py::test_gemm_split_accuracy) the error is <= that of the k-ordered fp32 fmaf chain which
+// v_mfma_f32_32x32x2_f32 (gemm_f32.hip) computes: rms 2.0e-8 vs 2.4e-8 of sum|a.w|.  This is NOT a reduced-precision
+// path: every bit of both fp32 operands takes part.
+//
+// Why.  Six v_mfma_f32_32x32x16_bf16 (32 cycles each) do the work of eight v_mfma_f32_32x32x2_f32 (64 cycles each):
+// 2.67x fewer matrix-core cycles per fp32 MAC; effective peak 2516.6 / 6 = 419 TFLOP/s(fp32-equivalent) vs 157.3.
+//
+// gfx950 design
+//   * block = 4 waves, tile 128 (m) x 128 (n) x 32 (k); wave w owns rows [32w, 32w+32) across the 4 column tiles
+//     (same ownership as gemm_f32.hip, so the fused epilogues are shared: gemm_epilogue.hpp); 3 blocks per CU.
+//   * A never touches LDS: lane (row r, half h) loads the 16 fp32 of ITS MFMA fragments (k = 8h..8h+7 and
+//     16+8h..16+8h+7 of the k tile: one 128-B line per two lanes) straight into registers, two k tiles ahead, and
+//     splits them there (11 VALU ops per two values, v_cvt_pk_bf16_f32 based).
+//   * W is split ONCE at model-build time into a tile-ordered image: [n/128][k/32][plane][128 rows x 64 B], the 16-B
+//     chunks XOR-swizzled exactly as the LDS tile wants them, so a k tile of a column block is 24 KB contiguous in
+//     HBM/L2 and is copied to LDS verbatim (coalesced 1 KB per wave instruction), double-buffered.
+//   * XCD-aware block -> tile order as in gemm_f32.hip.
+#include "../kernels.hpp"
+#include "device_math.hpp"
+#include "gemm_epilogue.hpp"
+
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32, THREADS = 256;
+constexpr int W_PLANE = BN * 64;      // bytes of one bf16 plane of a W tile (64-B rows)
+constexpr int W_TILE = 3 * W_PLANE;   // = L3AC_SPLIT_TILE_BYTES
+constexpr int W_LOADS = W_TILE / (16 * THREADS);
+static_assert(W_TILE == L3AC_SPLIT_TILE_BYTES, "image geometry");
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));  // (arrays of HIP's uint4 struct are not promoted to registers)
+
+// byte offset of 16-B chunk `chunk` (8 k values) of row `row` in a [128][32] bf16 plane; the XOR spreads the 16 rows a
+// ds_read_b128 lane group touches over all 16 slots of the 256-B bank row
+__host__ __device__ __forceinline__ int tile_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+// two fp32 -> three packed bf16 pairs (low half = first value), round to nearest even at every level
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& p0, unsigned& p1, unsigned& p2) {
+    const f32x2 v = {x0, x1};
+    p0 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    const f32x2 r = {x0 - __builtin_bit_cast(float, p0 << 16), x1 - __builtin_bit_cast(float, p0 & 0xffff0000u)};
+    p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+    const f32x2 q = {r.x - __builtin_bit_cast(float, p1 << 16), r.y - __builtin_bit_cast(float, p1 & 0xffff0000u)};
+    p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(q, bf16x2));
+}
+
+// w [n][k] fp32 (row stride ldw) -> tile-ordered split image (device-side builder; network.hip builds the same image on
+// the host).  One thread = one 16-B chunk (8 k values of one row) of each plane.
+__global__ void split_image_kernel(const float* __restrict__ w, int64_t ldw, int n, int k, unsigned char* __restrict__ img) {
+    const int k_tiles = (k + BK - 1) / BK;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t chunks = (int64_t)((n + BN - 1) / BN) * BN * k_tiles * 4;
+    if (i >= chunks) return;
+    const int row = (int)(i / (k_tiles * 4)), kc = (int)(i % (k_tiles * 4));
+    unsigned p[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int kk = 8 * kc + 2 * j;
+        const float x0 = (row < n && kk < k) ? w[(int64_t)row * ldw + kk] : 0.f;
+        const float x1 = (row < n && kk + 1 < k) ? w[(int64_t)row * ldw + kk + 1] : 0.f;
+        split2(x0, x1, p[0][j], p[1][j], p[2][j]);
+    }
+    unsigned char* tile = img + ((int64_t)(row / BN) * k_tiles + kc / 4) * W_TILE;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+        *reinterpret_cast<u32x4*>(tile + pl * W_PLANE + tile_off(row % BN, kc % 4)) = u32x4{p[pl][0], p[pl][1], p[pl][2], p[pl][3]};
+}
+
+// KTAIL: k % 32 != 0 (k % 8 == 0): the last tile's out-of-range 8-value groups re-read the row's last valid group —
+// finite numbers that meet the image's zero padding
+template <bool KTAIL>
+__global__ __launch_bounds__(THREADS, 3) void gemm_split_kernel(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_split[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    // XCD-aware tile order (gemm_f32.hip): all column tiles of one A row panel run on one XCD
+    const int n_blocks = (p.n + BN - 1) / BN;
+    const int64_t m_panels = (p.m + BM - 1) / BM;
+    const int64_t group = blockIdx.x / (8 * n_blocks);
+    const int64_t in_group = blockIdx.x % (8 * n_blocks);
+    const int64_t panels_here = (group * 8 + 8 <= m_panels) ? 8 : m_panels - group * 8;
+    const int64_t m0 = (group * 8 + in_group % panels_here) * BM;
+    const int n0 = (int)(in_group / panels_here) * BN;
+    const int n_tiles = (p.k + BK - 1) / BK;
+    const int last = n_tiles - 1;
+
+    // rows past the edge are clamped to row 0: they only feed accumulators that are never stored
+    const int64_t row = m0 + 32 * wave + li;
+    const float* a_src = p.a + (row < p.m ? row : 0) * p.lda + 8 * lh;
+    const unsigned char* w_src = p.w_img + (int64_t)(n0 / BN) * n_tiles * W_TILE + 16 * tid;
+
+    float4 a_pre[2][4];
+    u32x4 w_reg[W_LOADS];
+    auto load_a = [&](int kt, float4 (&dst)[4]) __attribute__((always_inline)) {
+        int o0 = kt * BK, o1 = kt * BK + 16;
+        if (KTAIL) {
+            const int kmax = p.k - 8 - 8 * lh;
+            o0 = o0 < kmax ? o0 : kmax;
+            o1 = o1 < kmax ? o1 : kmax;
+        }
+        dst[0] = *reinterpret_cast<const float4*>(a_src + o0);
+        dst[1] = *reinterpret_cast<const float4*>(a_src + o0 + 4);
+        dst[2] = *reinterpret_cast<const float4*>(a_src + o1);
+        dst[3] = *reinterpret_cast<const float4*>(a_src + o1 + 4);
+    };
+    auto load_w = [&](int kt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < W_LOADS; ++i) w_reg[i] = *reinterpret_cast<const u32x4*>(w_src + (int64_t)kt * W_TILE + 16 * THREADS * i);
+    };
+    auto store_w = [&](int buf) __attribute__((always_inline)) {
+        unsigned char* base = smem_split + buf * W_TILE + 16 * tid;
+#pragma unroll
+        for (int i = 0; i < W_LOADS; ++i) *reinterpret_cast<u32x4*>(base + 16 * THREADS * i) = w_reg[i];
+    };
+    auto read_b = [&](const unsigned char* ws, int s, int j, bf16x8 (&b)[3]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) b[pl] = *reinterpret_cast<const bf16x8*>(ws + pl * W_PLANE + tile_off(32 * j + li, 2 * s + lh));
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    load_a(0, a_pre[0]);
+    load_a(last < 1 ? last : 1, a_pre[1]);
+    load_w(0);
+    store_w(0);
+    __syncthreads();
+    // straight-line body: tile indices are clamped instead of branched on, which keeps hipcc's s_waitcnt counts exact
+    // (the tail re-loads the last tile and stores it into the idle buffer)
+    auto step = [&](int kt, float4 (&cur)[4]) __attribute__((always_inline)) {
+        const int buf = kt & 1;
+        load_w(kt + 1 < last ? kt + 1 : last);
+        u32x4 af[2][3];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            unsigned x0, x1, x2, y0, y1, y2, z0, z1, z2, u0, u1, u2;
+            split2(cur[2 * s].x, cur[2 * s].y, x0, x1, x2);
+            split2(cur[2 * s].z, cur[2 * s].w, y0, y1, y2);
+            split2(cur[2 * s + 1].x, cur[2 * s + 1].y, z0, z1, z2);
+            split2(cur[2 * s + 1].z, cur[2 * s + 1].w, u0, u1, u2);
+            af[s][0] = u32x4{x0, y0, z0, u0};
+            af[s][1] = u32x4{x1, y1, z1, u1};
+            af[s][2] = u32x4{x2, y2, z2, u2};
+        }
+        load_a(kt + 2 < last ? kt + 2 : last, cur);  // the registers are free again: two tiles ahead
+        const unsigned char* ws = smem_split + buf * W_TILE;
+        bf16x8 bq[2][3];
+        read_b(ws, 0, 0, bq[0]);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int s = it >> 2, j = it & 3;
+            if (it + 1 < 8) read_b(ws, (it + 1) >> 2, (it + 1) & 3, bq[(it + 1) & 1]);
+            const bf16x8 a0 = __builtin_bit_cast(bf16x8, af[s][0]);
+            const bf16x8 a1 = __builtin_bit_cast(bf16x8, af[s][1]);
+            const bf16x8 a2 = __builtin_bit_cast(bf16x8, af[s][2]);
+            const bf16x8 b0 = bq[it & 1][0], b1 = bq[it & 1][1], b2 = bq[it & 1][2];
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[j], 0, 0, 0);
+            if (it == 3) store_w(buf ^ 1);
+        }
+        __syncthreads();
+    };
+    for (int kt = 0; kt < n_tiles; kt += 2) {
+        step(kt, a_pre[0]);
+        if (kt + 1 < n_tiles) step(kt + 1, a_pre[1]);
+    }
+    gemm_epilogue<4>(p, acc, m0, n0, wave, li, lh);
+}
+
+std::atomic<int> g_split_enabled{-1};
+
+}  // namespace
+
+bool gemm_split_enabled() {
+    int v = g_split_enabled.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = std::getenv("L3AC_GEMM_SPLIT");
+        v = e ? (std::atoi(e) != 0) : 1;
+        g_split_enabled.store(v, std::memory_order_relaxed);
+    }
+    return v != 0;
+}
+void gemm_split_set_enabled(bool on) { g_split_enabled.store(on ? 1 : 0, std::memory_order_relaxed); }
+
+bool gemm_split_eligible(int n, int k) { return n >= 128 && k >= 32 && k % 8 == 0; }
+
+int64_t gemm_split_image_bytes(int n, int k) { return (int64_t)((n + BN - 1) / BN) * ((k + BK - 1) / BK) * W_TILE; }
+
+static inline uint16_t bf16_rne(float x) {
+    uint32_t u;
+    std::memcpy(&u, &x, 4);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);  // finite inputs only (weights)
+}
+static inline float bf16_to_f32(uint16_t h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+void gemm_split_image_host(const float* w, int64_t ldw, int n, int k, unsigned char* img) {
+    const int k_tiles = (k + BK - 1) / BK;
+    const int n_pad = (n + BN - 1) / BN * BN;
+    for (int row = 0; row < n_pad; ++row)
+        for (int kc = 0; kc < 4 * k_tiles; ++kc) {
+            uint16_t pl[3][8];
+            for (int j = 0; j < 8; ++j) {
+                const int kk = 8 * kc + j;
+                const float x = (row < n && kk < k) ? w[(int64_t)row * ldw + kk] : 0.f;
+                const uint16_t h0 = bf16_rne(x);
+                const float r1 = x - bf16_to_f32(h0);
+                const uint16_t h1 = bf16_rne(r1);
+                const float r2 = r1 - bf16_to_f32(h1);
+                pl[0][j] = h0;
+                pl[1][j] = h1;
+                pl[2][j] = bf16_rne(r2);
+            }
+            unsigned char* tile = img + ((int64_t)(row / BN) * k_tiles + kc / 4) * W_TILE;
+            for (int p = 0; p < 3; ++p) std::memcpy(tile + p * W_PLANE + tile_off(row % BN, kc % 4), pl[p], 16);
+        }
+}
+
+int launch_gemm_split_image(hipStream_t s, const float* w, int64_t ldw, int n, int k, unsigned char* img) {
+    L3AC_REQUIRE(w && img && n > 0 && k > 0, "split image: bad arguments");
+    const int64_t chunks = gemm_split_image_bytes(n, k) / 48;
+    hipLaunchKernelGGL(split_image_kernel, dim3((unsigned)ceil_div64(chunks, 256)), dim3(256), 0, s, w, ldw, n, k, img);
+    L3AC_LAUNCH_CHECK();
+    return L3AC_OK;
+}
+
+int launch_gemm_split(hipStream_t s, const GemmArgs& g) {
+    L3AC_REQUIRE(g.a && g.w_img && g.c, "split gemm: null operand");
+    L3AC_REQUIRE(g.taps == 1 && gemm_split_eligible(g.n, g.k), "split gemm: unsupported shape n=%d k=%d taps=%d", g.n, g.k, g.taps);
+    L3AC_REQUIRE(g.lda % 4 == 0 && ((uintptr_t)g.a & 15) == 0 && ((uintptr_t)g.w_img & 15) == 0, "split gemm: operands must be 16-byte aligned");
+    if (g.epi == EPI_GEGLU) L3AC_REQUIRE(g.n % 64 == 0, "split gemm: GEGLU epilogue needs interleaved 64-column tiles");
+    if (g.epi == EPI_BIAS_RES) L3AC_REQUIRE(g.res, "split gemm: residual epilogue without residual");
+    if (g.epi == EPI_SNAKE || g.epi == EPI_SNAKE_GRN) L3AC_REQUIRE(g.alpha && g.inv_alpha, "split gemm: snake without alpha");
+    if (g.epi == EPI_SNAKE_GRN) L3AC_REQUIRE(g.gamma && g.beta, "split gemm: GRN without gamma/beta");
+    const int64_t blocks = ceil_div64(g.m, BM) * ceil_div64(g.n, BN);
+    if (blocks <= 0) return L3AC_OK;
+    L3AC_REQUIRE(blocks < (int64_t)1 << 31, "split gemm: grid too large (m=%lld n=%d)", (long long)g.m, g.n);
+    char name[64];
+    std::snprintf(name, sizeof(name), "gemm_split_kernel %lldx%dx%d e%d", (long long)g.m, g.n, g.k, g.epi);
+    const double c_cols = g.epi == EPI_GEGLU ? (double)g.ldc : (double)g.n;
+    ProfScope prof(s, name, 2.0 * (double)g.m * g.n * g.k,
+                   4.0 * ((double)g.m * g.k + (double)g.m * c_cols * (g.epi == EPI_BIAS_RES ? 2.0 : 1.0)) + 6.0 * (double)g.n * g.k);
+    if (g.k % BK == 0)
+        hipLaunchKernelGGL((gemm_split_kernel<false>), dim3((unsigned)blocks), dim3(THREADS), 2 * W_TILE, s, g);
+    else
+        hipLaunchKernelGGL((gemm_split_kernel<true>), dim3((unsigned)blocks), dim3(THREADS), 2 * W_TILE, s, g);
+    L3AC_LAUNCH_CHECK();
+    return L3AC_OK;
+}

@@ -14,7 +14,13 @@ struct Builder {
     float* dev = nullptr;
     size_t cap = 0;
     std::string err;
+    struct GemmWeight { const float* d; int n, k; };
+    std::vector<GemmWeight> gemm_ws;  // [n][k] weights that get a split image
 
+    const float* gemm(const float* d, int n, int k) {
+        if (d && gemm_split_eligible(n, k)) gemm_ws.push_back({d, n, k});
+        return d;
+    }
     const float* find(const std::string& name, int64_t numel) {
         auto it = map.find(name);
         if (it == map.end()) {
@@ -119,13 +125,13 @@ ConvUnitW build_conv_unit(Builder& b, const std::string& p, int c) {
     u.dw_b = b.copy(p + ".dw_conv.bias", c);
     u.ln_w = b.copy(p + ".norm.weight", c);
     u.ln_b = b.copy(p + ".norm.bias", c);
-    u.w1 = b.copy(p + ".pw_conv1.weight", (int64_t)4 * c * c);
+    u.w1 = b.gemm(b.copy(p + ".pw_conv1.weight", (int64_t)4 * c * c), 4 * c, c);
     u.b1 = b.copy(p + ".pw_conv1.bias", 4 * c);
     u.alpha = b.copy(p + ".act.alpha", 4 * c);
     u.inv_alpha = b.inv_alpha(p + ".act.alpha", 4 * c);
     u.gamma = b.copy(p + ".grn.gamma", 4 * c);
     u.beta = b.copy(p + ".grn.beta", 4 * c);
-    u.w2 = b.copy(p + ".pw_conv2.weight", (int64_t)4 * c * c);
+    u.w2 = b.gemm(b.copy(p + ".pw_conv2.weight", (int64_t)4 * c * c), c, 4 * c);
     u.b2 = b.copy(p + ".pw_conv2.bias", c);
     return u;
 }
@@ -141,8 +147,8 @@ LocalTransW build_local_trans(Builder& b, l3ac_ctx* ctx, const std::string& p, i
         TransLayerW w{};
         w.ln1w = b.copy(a + ".norm.weight", dim);
         w.ln1b = b.copy(a + ".norm.bias", dim);
-        w.wqkv = b.copy(a + ".to_qkv.weight", (int64_t)3 * inner * dim);
-        w.wout = b.copy(a + ".to_out.weight", (int64_t)dim * inner);
+        w.wqkv = b.gemm(b.copy(a + ".to_qkv.weight", (int64_t)3 * inner * dim), 3 * inner, dim);
+        w.wout = b.gemm(b.copy(a + ".to_out.weight", (int64_t)dim * inner), dim, inner);
         w.ln2w = b.copy(f + ".0.weight", dim);
         w.ln2b = b.copy(f + ".0.bias", dim);
         {  // ff.1 [2*ffi][dim] -> (value, gate) 32-row tiles interleaved, zero padded: [ff_n][dim]
@@ -158,7 +164,7 @@ LocalTransW build_local_trans(Builder& b, l3ac_ctx* ctx, const std::string& p, i
                         std::memcpy(h + (size_t)(64 * jb + 32 + r) * dim, src + (size_t)(ffi + j) * dim, dim * sizeof(float));
                     }
             }
-            w.wff1 = d;
+            w.wff1 = b.gemm(d, ctx->ff_n, dim);
         }
         {  // ff.4 [dim][ffi] -> [dim][ff_pad] zero padded along k
             const float* src = b.find(f + ".4.weight", (int64_t)dim * ffi);
@@ -166,7 +172,7 @@ LocalTransW build_local_trans(Builder& b, l3ac_ctx* ctx, const std::string& p, i
             float* h = b.alloc((size_t)dim * ctx->ff_pad, &d);
             if (src && d)
                 for (int o = 0; o < dim; ++o) std::memcpy(h + (size_t)o * ctx->ff_pad, src + (size_t)o * ffi, ffi * sizeof(float));
-            w.wff2 = d;
+            w.wff2 = b.gemm(d, dim, ctx->ff_pad);
         }
         t.layers.push_back(w);
     }
@@ -261,7 +267,7 @@ int network_build(l3ac_ctx* ctx, const l3ac_tensor* tensors, int n_tensors) {
         d.stride = c.compress_rates[i];
         L3AC_REQUIRE(d.stride >= 1, "bad compress rate");
         const std::string p = "encoder.blocks." + std::to_string(blk + 1);
-        d.w = b.conv(p + ".0.weight", d.cout, d.cin, d.stride);
+        d.w = b.gemm(b.conv(p + ".0.weight", d.cout, d.cin, d.stride), d.cout, d.stride * d.cin);
         d.b = b.copy(p + ".0.bias", d.cout);
         d.nw = b.copy(p + ".1.weight", d.cout);
         d.nb = b.copy(p + ".1.bias", d.cout);
@@ -283,7 +289,7 @@ int network_build(l3ac_ctx* ctx, const l3ac_tensor* tensors, int n_tensors) {
         ctx->en_enc.push_back(build_local_trans(b, ctx, "en_encoder.local_trans", win, 3 - 3 / 2));
         ctx->en_down.cin = ctx->en_down.cout = c.feature_dim;
         ctx->en_down.stride = r;
-        ctx->en_down.w = b.conv("en_encoder.down_trans.down_layer.weight", c.feature_dim, c.feature_dim, r);
+        ctx->en_down.w = b.gemm(b.conv("en_encoder.down_trans.down_layer.weight", c.feature_dim, c.feature_dim, r), c.feature_dim, r * c.feature_dim);
         ctx->en_down.b = b.copy("en_encoder.down_trans.down_layer.bias", c.feature_dim);
         ctx->en_dec.push_back(build_local_trans(b, ctx, "en_decoder.local_trans", win, c.en_coder_depth - 2));
         ctx->en_dec.push_back(build_local_trans(b, ctx, "en_decoder.up_trans.trans", win * r, 2));
@@ -336,7 +342,7 @@ int network_build(l3ac_ctx* ctx, const l3ac_tensor* tensors, int n_tensors) {
         u.cout = co;
         u.scale = c.decode_rates[i];
         const std::string up = "decoder.blocks." + std::to_string(blk + 2);
-        u.w = b.copy(up + ".0.weight", (int64_t)co * ci);
+        u.w = b.gemm(b.copy(up + ".0.weight", (int64_t)co * ci), co, ci);
         u.b = b.copy(up + ".0.bias", co);
         u.nw = b.copy(up + ".2.weight", co);
         u.nb = b.copy(up + ".2.bias", co);
@@ -373,6 +379,24 @@ int network_build(l3ac_ctx* ctx, const l3ac_tensor* tensors, int n_tensors) {
     }
     L3AC_HIP_CHECK(hipMemcpy(ctx->arena, b.host.data(), b.host.size() * sizeof(float), hipMemcpyHostToDevice));
 
+    // ---- bf16x3 split images of the GEMM weights, from the arena's host staging copy (final layouts) ----------
+    {
+        size_t total_img = 0;
+        for (const auto& g : b.gemm_ws) total_img += (size_t)gemm_split_image_bytes(g.n, g.k);
+        if (total_img) {
+            std::vector<unsigned char> himg(total_img);
+            L3AC_HIP_CHECK(hipMalloc((void**)&ctx->img_arena, total_img));
+            ctx->img_bytes = total_img;
+            size_t off = 0;
+            for (const auto& g : b.gemm_ws) {
+                gemm_split_image_host(b.host.data() + (g.d - b.dev), g.k, g.n, g.k, himg.data() + off);
+                ctx->split_img[g.d] = ctx->img_arena + off;
+                off += (size_t)gemm_split_image_bytes(g.n, g.k);
+            }
+            L3AC_HIP_CHECK(hipMemcpy(ctx->img_arena, himg.data(), total_img, hipMemcpyHostToDevice));
+        }
+    }
+
     // ---- name index for the per-block entry points ------------------------------------------------------
     blk = 1;
     for (int i = 0; i < c.n_enc; ++i) {
@@ -407,6 +431,9 @@ int network_build(l3ac_ctx* ctx, const l3ac_tensor* tensors, int n_tensors) {
 void network_free(l3ac_ctx* ctx) {
     if (ctx->arena) (void)hipFree(ctx->arena);
     ctx->arena = nullptr;
+    if (ctx->img_arena) (void)hipFree(ctx->img_arena);
+    ctx->img_arena = nullptr;
+    ctx->split_img.clear();
     Workspace& w = ctx->ws;
     for (float** p : {&w.x0, &w.x1, &w.a, &w.h, &w.yi, &w.stats, &w.sumsq}) {
         if (*p) (void)hipFree(*p);
@@ -513,7 +540,7 @@ int run_conv_unit(l3ac_ctx* ctx, hipStream_t s, const ConvUnitW& w, const float*
     r.src = SRC_DWCONV7; r.norm = NORM_LN; r.dw_w = w.dw_w; r.dw_b = w.dw_b; r.nw = w.ln_w; r.nb = w.ln_b; r.eps = 1e-8f;
     L3AC_TRY(launch_rows(s, r));
     GemmArgs g{};  // pw_conv1 -> snake -> GRN (modules.py:36-38)
-    g.a = ws.a; g.lda = w.c; g.w = w.w1; g.ldw = w.c; g.c = ws.h; g.ldc = 4 * w.c; g.m = rows; g.n = 4 * w.c; g.k = w.c;
+    g.a = ws.a; g.lda = w.c; g.w = w.w1; g.w_img = ctx->img(w.w1); g.ldw = w.c; g.c = ws.h; g.ldc = 4 * w.c; g.m = rows; g.n = 4 * w.c; g.k = w.c;
     g.bias = w.b1; g.alpha = w.alpha; g.inv_alpha = w.inv_alpha; g.gamma = w.gamma; g.beta = w.beta;
     g.epi = ctx->cfg.grn_exact ? EPI_SNAKE : EPI_SNAKE_GRN;
     L3AC_TRY(launch_gemm(s, g));
@@ -522,7 +549,7 @@ int run_conv_unit(l3ac_ctx* ctx, hipStream_t s, const ConvUnitW& w, const float*
         L3AC_TRY(launch_grn_apply(s, ws.h, batch, frames, 4 * w.c, ws.sumsq, w.gamma, w.beta));
     }
     GemmArgs g2{};  // pw_conv2 + residual (modules.py:39, xtract/nn/layers.py:59-62)
-    g2.a = ws.h; g2.lda = 4 * w.c; g2.w = w.w2; g2.ldw = 4 * w.c; g2.c = y; g2.ldc = w.c; g2.m = rows; g2.n = w.c; g2.k = 4 * w.c;
+    g2.a = ws.h; g2.lda = 4 * w.c; g2.w = w.w2; g2.w_img = ctx->img(w.w2); g2.ldw = 4 * w.c; g2.c = y; g2.ldc = w.c; g2.m = rows; g2.n = w.c; g2.k = 4 * w.c;
     g2.bias = w.b2; g2.epi = EPI_BIAS_RES; g2.res = x; g2.ldres = w.c;
     return launch_gemm(s, g2);
 }
@@ -531,7 +558,7 @@ int run_down(l3ac_ctx* ctx, hipStream_t s, const DownW& w, const float* x, float
     L3AC_REQUIRE(frames % w.stride == 0, "down layer: frames=%d not a multiple of stride %d", frames, w.stride);
     const int64_t rows_out = (int64_t)batch * (frames / w.stride);
     GemmArgs g{};  // Conv1d(k = stride): non-overlapping patches are contiguous in the frame-major layout
-    g.a = x; g.lda = (int64_t)w.stride * w.cin; g.w = w.w; g.ldw = (int64_t)w.stride * w.cin; g.c = y; g.ldc = w.cout;
+    g.a = x; g.lda = (int64_t)w.stride * w.cin; g.w = w.w; g.w_img = ctx->img(w.w); g.ldw = (int64_t)w.stride * w.cin; g.c = y; g.ldc = w.cout;
     g.m = rows_out; g.n = w.cout; g.k = w.stride * w.cin; g.bias = w.b; g.epi = EPI_BIAS;
     L3AC_TRY(launch_gemm(s, g));
     if (w.nw) {  // ChannelNorm channels_first (modules.py:98), in place
@@ -547,7 +574,7 @@ int run_down(l3ac_ctx* ctx, hipStream_t s, const DownW& w, const float* x, float
 int run_conv_k3(l3ac_ctx* ctx, hipStream_t s, const ConvK3W& w, const float* x, float* y, int batch, int frames) {
     GemmArgs g{};
     g.a = x; g.lda = w.cin; g.taps = 3; g.dil = 1; g.cin = w.cin; g.frames = frames;
-    g.w = w.w; g.ldw = 3 * w.cin; g.c = y; g.ldc = w.cout; g.m = (int64_t)batch * frames; g.n = w.cout; g.k = 3 * w.cin;
+    g.w = w.w; g.w_img = ctx->img(w.w); g.ldw = 3 * w.cin; g.c = y; g.ldc = w.cout; g.m = (int64_t)batch * frames; g.n = w.cout; g.k = 3 * w.cin;
     g.bias = w.b; g.epi = EPI_BIAS;
     (void)ctx;
     return launch_gemm(s, g);
@@ -566,7 +593,7 @@ int run_enhance(l3ac_ctx* ctx, hipStream_t s, const EnhW& w, const float* x, flo
 
 int run_up(l3ac_ctx* ctx, hipStream_t s, const UpW& w, const float* x, float* tmp, float* y, int batch, int frames) {
     GemmArgs g{};  // 1x1 conv (modules.py:161)
-    g.a = x; g.lda = w.cin; g.w = w.w; g.ldw = w.cin; g.c = tmp; g.ldc = w.cout; g.m = (int64_t)batch * frames; g.n = w.cout; g.k = w.cin;
+    g.a = x; g.lda = w.cin; g.w = w.w; g.w_img = ctx->img(w.w); g.ldw = w.cin; g.c = tmp; g.ldc = w.cout; g.m = (int64_t)batch * frames; g.n = w.cout; g.k = w.cin;
     g.bias = w.b; g.epi = EPI_BIAS;
     L3AC_TRY(launch_gemm(s, g));
     RowArgs r{};  // Upsample(linear) + ChannelNorm (modules.py:162-163)
@@ -596,11 +623,11 @@ int run_last_block(l3ac_ctx* ctx, hipStream_t s, float* x, float* audio, int bat
         L3AC_TRY(launch_snake(s, x, ws.a, rows, l.c, l.a0, l.ia0));
         GemmArgs g{};
         g.a = ws.a; g.lda = l.c; g.taps = 7; g.dil = l.dil; g.cin = l.c; g.frames = frames;
-        g.w = l.w1; g.ldw = 7 * l.c; g.c = ws.h; g.ldc = l.c; g.m = rows; g.n = l.c; g.k = 7 * l.c;
+        g.w = l.w1; g.w_img = ctx->img(l.w1); g.ldw = 7 * l.c; g.c = ws.h; g.ldc = l.c; g.m = rows; g.n = l.c; g.k = 7 * l.c;
         g.bias = l.b1; g.epi = EPI_SNAKE; g.alpha = l.a1; g.inv_alpha = l.ia1;
         L3AC_TRY(launch_gemm(s, g));
         GemmArgs g2{};
-        g2.a = ws.h; g2.lda = l.c; g2.w = l.w2; g2.ldw = l.c; g2.c = x; g2.ldc = l.c; g2.m = rows; g2.n = l.c; g2.k = l.c;
+        g2.a = ws.h; g2.lda = l.c; g2.w = l.w2; g2.w_img = ctx->img(l.w2); g2.ldw = l.c; g2.c = x; g2.ldc = l.c; g2.m = rows; g2.n = l.c; g2.k = l.c;
         g2.bias = l.b2; g2.epi = EPI_BIAS_RES; g2.res = x; g2.ldres = l.c;
         L3AC_TRY(launch_gemm(s, g2));
     }
@@ -619,22 +646,22 @@ int run_local_trans(l3ac_ctx* ctx, hipStream_t s, const LocalTransW& w, float* x
         r.src = SRC_PLAIN; r.norm = NORM_LN; r.nw = l.ln1w; r.nb = l.ln1b; r.eps = 1e-5f;
         L3AC_TRY(launch_rows(s, r));
         GemmArgs g{};  // to_qkv (no bias)
-        g.a = ws.a; g.lda = dim; g.w = l.wqkv; g.ldw = dim; g.c = ws.h; g.ldc = 3 * ctx->inner; g.m = rows; g.n = 3 * ctx->inner; g.k = dim;
+        g.a = ws.a; g.lda = dim; g.w = l.wqkv; g.w_img = ctx->img(l.wqkv); g.ldw = dim; g.c = ws.h; g.ldc = 3 * ctx->inner; g.m = rows; g.n = 3 * ctx->inner; g.k = dim;
         g.epi = EPI_BIAS;
         L3AC_TRY(launch_gemm(s, g));
         L3AC_TRY(launch_attention(s, ws.h, ws.a, w.bias_table, batch, frames, HEADS, ctx->dim_head, w.window));
         GemmArgs go{};  // to_out + residual (local_trans.py:45)
-        go.a = ws.a; go.lda = ctx->inner; go.w = l.wout; go.ldw = ctx->inner; go.c = x; go.ldc = dim; go.m = rows; go.n = dim; go.k = ctx->inner;
+        go.a = ws.a; go.lda = ctx->inner; go.w = l.wout; go.w_img = ctx->img(l.wout); go.ldw = ctx->inner; go.c = x; go.ldc = dim; go.m = rows; go.n = dim; go.k = ctx->inner;
         go.epi = EPI_BIAS_RES; go.res = x; go.ldres = dim;
         L3AC_TRY(launch_gemm(s, go));
         r.nw = l.ln2w; r.nb = l.ln2b;  // FeedForward LayerNorm
         L3AC_TRY(launch_rows(s, r));
         GemmArgs f1{};  // Linear(dim, 2*inner) + GEGLU, value/gate tiles interleaved at upload
-        f1.a = ws.a; f1.lda = dim; f1.w = l.wff1; f1.ldw = dim; f1.c = ws.h; f1.ldc = ctx->ff_pad; f1.m = rows; f1.n = ctx->ff_n; f1.k = dim;
+        f1.a = ws.a; f1.lda = dim; f1.w = l.wff1; f1.w_img = ctx->img(l.wff1); f1.ldw = dim; f1.c = ws.h; f1.ldc = ctx->ff_pad; f1.m = rows; f1.n = ctx->ff_n; f1.k = dim;
         f1.epi = EPI_GEGLU; f1.n_out = ctx->ff_inner;
         L3AC_TRY(launch_gemm(s, f1));
         GemmArgs f2{};  // Linear(inner, dim) + residual (local_trans.py:46)
-        f2.a = ws.h; f2.lda = ctx->ff_pad; f2.w = l.wff2; f2.ldw = ctx->ff_pad; f2.c = x; f2.ldc = dim; f2.m = rows; f2.n = dim; f2.k = ctx->ff_pad;
+        f2.a = ws.h; f2.lda = ctx->ff_pad; f2.w = l.wff2; f2.w_img = ctx->img(l.wff2); f2.ldw = ctx->ff_pad; f2.c = x; f2.ldc = dim; f2.m = rows; f2.n = dim; f2.k = ctx->ff_pad;
         f2.epi = EPI_BIAS_RES; f2.res = x; f2.ldres = dim;
         L3AC_TRY(launch_gemm(s, f2));
     }

@@ -59,6 +59,14 @@ struct l3ac_ctx {
     int hop = 0, enc_rate = 1, dim_head = 0, inner = 0, ff_inner = 0, ff_pad = 0, ff_n = 0;
     float* arena = nullptr;
     size_t arena_floats = 0;
+    // bf16x3 split images of the GEMM weights (kernels/gemm_split.hip), keyed by the fp32 weight's device pointer
+    unsigned char* img_arena = nullptr;
+    size_t img_bytes = 0;
+    std::unordered_map<const float*, const unsigned char*> split_img;
+    const unsigned char* img(const float* w) const {
+        auto it = split_img.find(w);
+        return it == split_img.end() ? nullptr : it->second;
+    }
 
     FirstBlockW first{};
     std::vector<std::vector<ConvUnitW>> enc_units;  // per encoder stage (incl. the tail stage)

@@ -94,3 +94,19 @@ def gemm(a, w, bias):
                                   c.data_ptr(), n, m, n, k, _stream(a.device)))
     torch.cuda.synchronize()
     return c
+
+
+def gemm_split(a, w, bias):
+    """bf16x3 split-operand GEMM through the C ABI: builds the weight image on the device, then multiplies."""
+    lib = _capi.load_library()
+    m, k = a.shape
+    n = w.shape[0]
+    nbytes = lib.l3ac_gemm_split_image_bytes(n, k)
+    assert nbytes > 0, f"shape n={n} k={k} is not eligible for the split kernel"
+    img = torch.empty((nbytes,), dtype=torch.uint8, device=a.device)
+    c = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    _capi.check(lib.l3ac_gemm_split_image(w.data_ptr(), n, k, img.data_ptr(), _stream(a.device)))
+    _capi.check(lib.l3ac_gemm_split_f32(a.data_ptr(), a.stride(0), img.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                        c.data_ptr(), n, m, n, k, _stream(a.device)))
+    torch.cuda.synchronize()
+    return c

@@ -61,6 +61,27 @@ def test_gemm_against_fp64():
         assert err <= 4e-7 * scale + 1e-6
 
 
+def test_gemm_split_accuracy():
+    """bf16x3 split GEMM (gemm_split.hip) against fp64: its error must stay within the fp32-MFMA kernel's own error
+    budget and, in rms, not exceed the exact-fp32 kernel's error on the same operands."""
+    torch.manual_seed(0)
+    for (m, n, k, heavy) in [(1000, 128, 32, False), (257, 256, 1024, False), (129, 512, 2048, True), (1000, 130, 344, False),
+                             (384, 704, 128, True), (4096, 1024, 256, False)]:
+        a, w, b = _rand((m, k), 1), _rand((n, k), 2, 0.1), _rand((n,), 3)
+        if heavy:  # wide dynamic range inside one dot product
+            a = a * torch.exp(3.0 * _rand((m, k), 4))
+        ref = a.double() @ w.double().T + b.double()
+        mag = a.abs().double() @ w.abs().double().T + b.abs().double()
+        got_s = G.gemm_split(a.cuda(), w.cuda(), b.cuda()).cpu()
+        got_f = G.gemm(a.cuda(), w.cuda(), b.cuda()).cpu()
+        es = ((got_s.double() - ref).abs() / mag)
+        ef = ((got_f.double() - ref).abs() / mag)
+        print(f"[gemm_split {m}x{n}x{k}] err/sum|a.w|: split max {es.max():.3e} rms {es.pow(2).mean().sqrt():.3e} | "
+              f"fp32 mfma max {ef.max():.3e} rms {ef.pow(2).mean().sqrt():.3e}")
+        assert es.max().item() <= max(4e-7, 1.05 * ef.max().item())
+        assert es.pow(2).mean().sqrt().item() <= 1.05 * ef.pow(2).mean().sqrt().item() + 1e-9
+
+
 def test_first_block(tiny, full):
     for codec, mc, w in (tiny, full):
         x = seeded_audio(2, 1000)

@@ -91,8 +91,19 @@ def test_encode_decode_against_oracle(tag, seed, batch, samples):
     assert torch.equal(wave_a, wave_b)
 
 
+@pytest.fixture
+def gemm_mode(request):
+    """Runs a test under one GEMM route: "split" (default: bf16x3 operands on the bf16 matrix cores) or "exact"
+    (every product on v_mfma_f32_32x32x2_f32)."""
+    before = l3ac_amd.get_gemm_split()
+    l3ac_amd.set_gemm_split(request.param == "split")
+    yield request.param
+    l3ac_amd.set_gemm_split(before)
+
+
+@pytest.mark.parametrize("gemm_mode", ["split", "exact"], indirect=True)
 @pytest.mark.parametrize("tag", ["tiny", "1kbps", "3kbps"])
-def test_against_committed_reference_vectors(tag):
+def test_against_committed_reference_vectors(tag, gemm_mode):
     """tests/golden/*_e2e.npz were produced by the reference's own EnCodec wiring (see make_golden.py)."""
     mc, w, conv, e2e = load_case(tag)
     codec = _codec(tag, int(e2e["seed"]))
@@ -125,6 +136,27 @@ def test_against_committed_reference_vectors(tag):
         np.testing.assert_allclose(wave.numpy(), conv["wave"], atol=WAVE_ATOL)
     else:
         np.testing.assert_allclose(strided(wave).numpy(), conv["wave_strided"], atol=WAVE_ATOL)
+
+
+def test_split_and_exact_gemm_routes_agree():
+    """Same model, same clips, both GEMM routes: identical tokens; the waveforms differ by no more than either differs
+    from the CPU oracle (the decoder amplifies fp32 rounding noise of ANY evaluation order to a few 1e-4)."""
+    codec = _codec("1kbps", 0)
+    audio = seeded_audio(8, 16000).cuda()
+    out = {}
+    before = l3ac_amd.get_gemm_split()
+    try:
+        for mode in (True, False):
+            l3ac_amd.set_gemm_split(mode)
+            q, ind = codec.encode_audio(audio)
+            out[mode] = (ind["indices"].cpu(), codec.decode_audio(indices=ind["indices"]).cpu())
+    finally:
+        l3ac_amd.set_gemm_split(before)
+    n_diff = int((out[True][0] != out[False][0]).sum())
+    err = (out[True][1] - out[False][1]).abs().max().item()
+    print(f"[split vs exact] token differences {n_diff}/{out[True][0].numel()}, waveform max |diff| {err:.3e}")
+    assert n_diff == 0
+    assert err <= WAVE_ATOL
 
 
 def test_full_batch_properties_1kbps():
