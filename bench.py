@@ -21,6 +21,10 @@ sys.path.insert(0, str(REPO))
 import torch
 
 PEAK_F32_TFLOPS = 157.3  # MI355X fp32 MFMA = fp32 vector peak (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA (same guide: ~2.5 PFLOP/s)
+# gemm_split_kernel evaluates every fp32 MAC as 6 bf16 plane products (kernels/gemm_split.hip): its roofline in
+# fp32-equivalent FLOPs is the bf16 peak / 6
+PEAK_SPLIT_TFLOPS = PEAK_BF16_TFLOPS / 6.0
 PEAK_HBM_GBS = 8000.0    # HBM3E spec
 
 
@@ -81,6 +85,9 @@ def main():
                     help="host threads for the CPU baseline (32 measured fastest on the 256-thread GPU box; "
                          "torch's default of 128 is 3x slower: tools/experiments/cpu_threads.py)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph")
+    ap.add_argument("--gemm", choices=["split", "exact"], default="split",
+                    help="split: large fp32 contractions as exact bf16x3 operand splits on the bf16 matrix cores (default); "
+                         "exact: every product on the fp32 MFMA instruction")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -101,6 +108,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
 
+    l3ac_amd.set_gemm_split(args.gemm == "split")
     codec = l3ac_amd.get_model(args.config, synthetic_seed=0)  # identical weights on every rank
     codec.network.to(device=dev).eval()
     mc = codec.network.mc
@@ -172,7 +180,13 @@ def main():
         dom = kernels[0]
         dom_ms = dom["ms_total"] / dom["launches"]
         ai = dom["flops"] / max(dom["bytes"], 1.0)
-        if ai > PEAK_F32_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9):
+        if dom["name"].startswith("gemm_split_kernel"):
+            ach = dom["flops"] / dom["ms_total"] / 1e9
+            roof = dict(bound="mfma", achieved=ach, peak=PEAK_SPLIT_TFLOPS, unit="TFLOP/s",
+                        peak_note="fp32-equivalent FLOPs (2*m*n*k); each fp32 MAC = 6 bf16 MFMA plane products, so peak = dense bf16 "
+                                  f"MFMA peak {PEAK_BF16_TFLOPS:g} / 6; hardware rate = 6 x achieved",
+                        hw_bf16_tflops=6.0 * ach, vs_exact_f32_mfma_peak=ach / PEAK_F32_TFLOPS)
+        elif ai > PEAK_F32_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9):
             roof = dict(bound="mfma", achieved=dom["flops"] / dom["ms_total"] / 1e9, peak=PEAK_F32_TFLOPS, unit="TFLOP/s")
         else:
             roof = dict(bound="hbm", achieved=dom["bytes"] / dom["ms_total"] / 1e6, peak=PEAK_HBM_GBS, unit="GB/s")
@@ -193,6 +207,11 @@ def main():
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "arithmetic": ("fp32 storage and fp32 accumulation everywhere; the large channel contractions split each fp32 operand "
+                           "EXACTLY into 3 bf16 planes and sum the 6 plane products of order <= 2 on the bf16 matrix cores "
+                           "(error vs fp64 <= the fp32 fmaf chain's, tests/test_gpu_blocks.py::test_gemm_split_accuracy); "
+                           "all other products use v_mfma_f32_32x32x2_f32") if l3ac_amd.get_gemm_split() else
+                          "fp32 everywhere: every product on v_mfma_f32_32x32x2_f32 (--gemm exact)",
             "config": {"workload": f"{args.config} config, {b} x {args.seconds:g} s 16 kHz clips per GPU, "
                                    "encode_audio + decode_audio(q_feature)" + (", RCCL all-gather of indices+waveforms" if gather else ""),
                        "batch_per_gpu": b, "samples_per_clip": samples, "weights": "seeded synthetic (seed 0)",
@@ -208,6 +227,20 @@ def main():
             "gemm_shapes": [{"name": e["name"], "launches": e["launches"], "ms": round(e["ms_total"], 4),
                              "tflops": round(e["flops"] / e["ms_total"] / 1e9, 2)} for e in shapes[:16]],
         }
+        if args.gemm == "split" and world == 1 and not args.graph:
+            # the same step with every product on the exact fp32 MFMA instruction, for reference (5 steps, untimed above)
+            l3ac_amd.set_gemm_split(False)
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                ind_x, _ = step()
+            torch.cuda.synchronize()
+            ex = (time.perf_counter() - t1) / 5
+            l3ac_amd.set_gemm_split(True)
+            out["exact_f32_mfma_route"] = {"ms_per_step": ex * 1e3, "value": b * samples / ex, "unit": "samples/s",
+                                           "token_differences_vs_split_route": int((ind_x["indices"] != ind["indices"]).sum())}
         out["fsq_kernel"] = fsq_microbench(codec, dev)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(codec, audio, args.cpu_batch, ind, args.cpu_threads)

@@ -185,7 +185,7 @@ int l3ac_gemm_f32(const float* a, int64_t lda, const float* w, const float* bias
 void l3ac_set_gemm_split(int32_t enable);
 int32_t l3ac_get_gemm_split(void);
 /* Weight image for l3ac_gemm_split_f32: w [n][k] fp32 -> `image` (device, l3ac_gemm_split_image_bytes(n, k) bytes;
- * 0 = shape not eligible: needs n >= 128, k >= 32, k % 8 == 0). */
+ * 0 = shape not eligible: needs n >= 192, k >= 32, k % 8 == 0). */
 int64_t l3ac_gemm_split_image_bytes(int32_t n, int32_t k);
 int l3ac_gemm_split_image(const float* w, int32_t n, int32_t k, void* image, void* stream);
 /* c[m][n] = a[m][:] . w[n][:] + bias[n] with w given as its split image (a [m][k] fp32, row stride lda). */

@@ -386,7 +386,7 @@ int64_t l3ac_gemm_split_image_bytes(int32_t n, int32_t k) {
 }
 
 int l3ac_gemm_split_image(const float* w, int32_t n, int32_t k, void* image, void* stream) {
-    L3AC_REQUIRE(gemm_split_eligible(n, k), "split image: shape n=%d k=%d is not eligible (n >= 128, k >= 32, k %% 8 == 0)", n, k);
+    L3AC_REQUIRE(gemm_split_eligible(n, k), "split image: shape n=%d k=%d is not eligible (n >= 192, k >= 32, k %% 8 == 0)", n, k);
     return launch_gemm_split_image((hipStream_t)stream, w, k, n, k, (unsigned char*)image);
 }
 

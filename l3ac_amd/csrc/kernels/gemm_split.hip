@@ -208,7 +208,9 @@ bool gemm_split_enabled() {
 }
 void gemm_split_set_enabled(bool on) { g_split_enabled.store(on ? 1 : 0, std::memory_order_relaxed); }
 
-bool gemm_split_eligible(int n, int k) { return n >= 128 && k >= 32 && k % 8 == 0; }
+// n < 192 would be a single 128-column block per row panel: too few workgroups at the transformer's row counts, where
+// the exact kernel's narrower tiles win (measured: 128 x 344 and 128 x 192 weights, 26 vs 45 TFLOP/s at 15360 rows)
+bool gemm_split_eligible(int n, int k) { return n >= 192 && k >= 32 && k % 8 == 0; }
 
 int64_t gemm_split_image_bytes(int n, int k) { return (int64_t)((n + BN - 1) / BN) * ((k + BK - 1) / BK) * W_TILE; }
 

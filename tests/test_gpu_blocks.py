@@ -65,7 +65,7 @@ def test_gemm_split_accuracy():
     """bf16x3 split GEMM (gemm_split.hip) against fp64: its error must stay within the fp32-MFMA kernel's own error
     budget and, in rms, not exceed the exact-fp32 kernel's error on the same operands."""
     torch.manual_seed(0)
-    for (m, n, k, heavy) in [(1000, 128, 32, False), (257, 256, 1024, False), (129, 512, 2048, True), (1000, 130, 344, False),
+    for (m, n, k, heavy) in [(1000, 192, 32, False), (257, 256, 1024, False), (129, 512, 2048, True), (1000, 200, 344, False),
                              (384, 704, 128, True), (4096, 1024, 256, False)]:
         a, w, b = _rand((m, k), 1), _rand((n, k), 2, 0.1), _rand((n,), 3)
         if heavy:  # wide dynamic range inside one dot product

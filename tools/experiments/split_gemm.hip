@@ -291,6 +291,9 @@ __global__ __launch_bounds__(V2_T, V2_OCC) void split_gemm_v2_kernel(const float
         const unsigned char* ws = smem + buf * V2_STAGE;
         bf16x8 bq[2][3];
         read_b(ws, 0, 0, bq[0]);
+#ifdef V2_PRIO
+        __builtin_amdgcn_s_setprio(V2_PRIO);
+#endif
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int s = it >> 2, j = it & 3;
@@ -308,6 +311,130 @@ __global__ __launch_bounds__(V2_T, V2_OCC) void split_gemm_v2_kernel(const float
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[j], 0, 0, 0);
             if (it == STORE_AT && !(DIAG & 8)) store_w(buf ^ 1);
         }
+#ifdef V2_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        __syncthreads();
+    };
+    for (int kt = 0; kt < n_tiles; kt += 2) {
+        step(kt, a_pre[0]);
+        if (kt + 1 < n_tiles) step(kt + 1, a_pre[1]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = n0 + 32 * j + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (!(DIAG & 16) || acc[j][r] == 1234.5f) c[row * n + col] = acc[j][r];
+        }
+    }
+}
+
+template <int DIAG>  // diagnostic bits: 1 no A loads, 2 no split math, 4 no B fragment reads, 8 no W staging, 16 no C store
+__global__ __launch_bounds__(V2_T, V2_OCC) void split_gemm_v3_kernel(const float* __restrict__ a, const uint16_t* __restrict__ wp,
+                                                               float* __restrict__ c, int64_t m, int n, int k) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_blocks = n / 128;
+    const int64_t m_panels = m / V2_BM;
+    const int64_t group = blockIdx.x / (8 * n_blocks);
+    const int64_t in_group = blockIdx.x % (8 * n_blocks);
+    const int64_t panels_here = (group * 8 + 8 <= m_panels) ? 8 : m_panels - group * 8;
+    const int64_t m0 = (group * 8 + in_group % panels_here) * V2_BM;
+    const int n0 = (int)(in_group / panels_here) * 128;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const float* a_src = a + (m0 + 32 * wave + li) * k + 8 * lh;
+    const unsigned char* w_src = reinterpret_cast<const unsigned char*>(wp) + (int64_t)(n0 / 128) * (k / 32) * V2_STAGE + 16 * tid;
+
+    float4 a_pre[2][4];
+    // W tiles go global -> LDS by DMA (no staging VGPRs, no ds_write): wave-uniform LDS base in M0, lane * 16 B added by HW
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    auto dma16 = [&](const unsigned char* src, unsigned lds_byte) __attribute__((always_inline)) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(src), "s"(lds_byte)
+                     : "memory");
+    };
+    auto load_a = [&](int kt, float4 (&dst)[4]) __attribute__((always_inline)) {
+        const float* src = a_src + kt * 32;
+        dst[0] = *reinterpret_cast<const float4*>(src);
+        dst[1] = *reinterpret_cast<const float4*>(src + 4);
+        dst[2] = *reinterpret_cast<const float4*>(src + 16);
+        dst[3] = *reinterpret_cast<const float4*>(src + 20);
+    };
+    auto dma_w = [&](int kt, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < V2_WLD; ++i)
+            dma16(w_src + (int64_t)kt * V2_STAGE + 16 * V2_T * i,
+                  __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(buf * V2_STAGE + 16 * V2_T * i + 1024 * wave)));
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    const int n_tiles = k / 32;
+    load_a(0, a_pre[0]);
+    if (n_tiles > 1) load_a(1, a_pre[1]);
+    dma_w(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    auto read_b = [&](const unsigned char* ws, int s, int j, bf16x8 (&b)[3]) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const bf16x8*>(ws + p * V2_W_PLANE + tile_off(32 * j + li, 2 * s + lh));
+    };
+    // straight-line body (tile indices are clamped instead of branching: hipcc's s_waitcnt insertion stays exact)
+    auto step = [&](int kt, float4 (&cur)[4]) __attribute__((always_inline)) {
+        const int buf = kt & 1;
+        const int last = n_tiles - 1;
+        if (!(DIAG & 8)) dma_w(kt + 1 < last ? kt + 1 : last, buf ^ 1);
+        u32x4 af[2][3];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (DIAG & 2) {
+                af[s][0] = __builtin_bit_cast(u32x4, cur[2 * s]);
+                af[s][1] = __builtin_bit_cast(u32x4, cur[2 * s + 1]);
+                af[s][2] = __builtin_bit_cast(u32x4, cur[2 * s]);
+                continue;
+            }
+            unsigned x0, x1, x2, y0, y1, y2, z0, z1, z2, u0, u1, u2;
+            split2(cur[2 * s].x, cur[2 * s].y, x0, x1, x2);
+            split2(cur[2 * s].z, cur[2 * s].w, y0, y1, y2);
+            split2(cur[2 * s + 1].x, cur[2 * s + 1].y, z0, z1, z2);
+            split2(cur[2 * s + 1].z, cur[2 * s + 1].w, u0, u1, u2);
+            af[s][0] = u32x4{x0, y0, z0, u0};
+            af[s][1] = u32x4{x1, y1, z1, u1};
+            af[s][2] = u32x4{x2, y2, z2, u2};
+        }
+        if (!(DIAG & 1)) load_a(kt + 2 < last ? kt + 2 : last, cur);  // the registers are free again: two tiles ahead
+        const unsigned char* ws = smem + buf * V2_STAGE;
+        bf16x8 bq[2][3];
+        read_b(ws, 0, 0, bq[0]);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int s = it >> 2, j = it & 3;
+            if (it + 1 < 8 && !(DIAG & 4)) read_b(ws, (it + 1) >> 2, (it + 1) & 3, bq[(it + 1) & 1]);
+            const bf16x8 a0 = __builtin_bit_cast(bf16x8, af[s][0]);
+            const bf16x8 a1 = __builtin_bit_cast(bf16x8, af[s][1]);
+            const bf16x8 a2 = __builtin_bit_cast(bf16x8, af[s][2]);
+            const int bi = (DIAG & 4) ? 0 : (it & 1);
+            const bf16x8 b0 = bq[bi][0], b1 = bq[bi][1], b2 = bq[bi][2];
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[j], 0, 0, 0);
+        }
+        // own DMA pieces of the next tile have landed (only the 4 younger A loads may still be in flight), then everybody's
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         __syncthreads();
     };
     for (int kt = 0; kt < n_tiles; kt += 2) {
@@ -362,6 +489,43 @@ float run(const float* a, const uint16_t* wp, float* c, int64_t m, int n, int k,
     return ms / iters;
 }
 
+template <int DIAG>
+float run_v3(const float* a, const uint16_t* wp, float* c, int64_t m, int n, int k, int iters) {
+    const unsigned grid = (unsigned)((m / V2_BM) * (n / 128));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(split_gemm_v3_kernel<DIAG>, dim3(grid), dim3(V2_T), 2 * V2_STAGE, 0, a, wp, c, m, n, k);
+    CHECK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(split_gemm_v3_kernel<DIAG>, dim3(grid), dim3(V2_T), 2 * V2_STAGE, 0, a, wp, c, m, n, k);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    CHECK(hipGetLastError());
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / iters;
+}
+
+template <int MODE>
+float run_unused(const float* a, const uint16_t* wp, float* c, int64_t m, int n, int k, int iters) {
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(split_gemm_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              2 * STAGE));
+    const unsigned grid = (unsigned)((m / BM) * (n / BN));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(split_gemm_kernel<MODE>, dim3(grid), dim3(THREADS), 2 * STAGE, 0, a, wp, c, m, n, k);
+    CHECK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i)
+        hipLaunchKernelGGL(split_gemm_kernel<MODE>, dim3(grid), dim3(THREADS), 2 * STAGE, 0, a, wp, c, m, n, k);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    CHECK(hipGetLastError());
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / iters;
+}
+
 int main(int argc, char** argv) {
     struct Shape { int64_t m; int n, k; };
     const Shape shapes[] = {{230400, 1024, 256}, {230400, 256, 1024}, {46080, 2048, 512}, {46080, 512, 2048}, {46080, 768, 192}};
@@ -395,7 +559,7 @@ int main(int argc, char** argv) {
             const uint16_t* dimg16 = reinterpret_cast<const uint16_t*>(dimg);
             for (int mode = 2; mode < 3; ++mode) {
                 const int iters = 10;
-                const float ms = mode == 0 ? run<0>(da, dp, dc, m, n, k, iters) : mode == 1 ? run<1>(da, dp, dc, m, n, k, iters) : run_v2<0>(da, dimg16, dc, m, n, k, iters);
+                const float ms = mode == 0 ? run<0>(da, dp, dc, m, n, k, iters) : mode == 1 ? run<1>(da, dp, dc, m, n, k, iters) : mode == 2 ? run_v2<0>(da, dimg16, dc, m, n, k, iters) : run_v3<0>(da, dimg16, dc, m, n, k, iters);
                 // error on sampled rows
                 const int rows = 48;
                 std::vector<float> hc((size_t)n);
