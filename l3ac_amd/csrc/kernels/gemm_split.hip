@@ -29,6 +29,7 @@
 #include "../kernels.hpp"
 #include "device_math.hpp"
 #include "gemm_epilogue.hpp"
+#include "split_bf16.hpp"
 
 #include <atomic>
 #include <cstdio>
@@ -43,23 +44,9 @@ constexpr int W_TILE = 3 * W_PLANE;   // = L3AC_SPLIT_TILE_BYTES
 constexpr int W_LOADS = W_TILE / (16 * THREADS);
 static_assert(W_TILE == L3AC_SPLIT_TILE_BYTES, "image geometry");
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));  // (arrays of HIP's uint4 struct are not promoted to registers)
-
 // byte offset of 16-B chunk `chunk` (8 k values) of row `row` in a [128][32] bf16 plane; the XOR spreads the 16 rows a
 // ds_read_b128 lane group touches over all 16 slots of the 256-B bank row
 __host__ __device__ __forceinline__ int tile_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
-
-// two fp32 -> three packed bf16 pairs (low half = first value), round to nearest even at every level
-__device__ __forceinline__ void split2(float x0, float x1, unsigned& p0, unsigned& p1, unsigned& p2) {
-    const f32x2 v = {x0, x1};
-    p0 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-    const f32x2 r = {x0 - __builtin_bit_cast(float, p0 << 16), x1 - __builtin_bit_cast(float, p0 & 0xffff0000u)};
-    p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
-    const f32x2 q = {r.x - __builtin_bit_cast(float, p1 << 16), r.y - __builtin_bit_cast(float, p1 & 0xffff0000u)};
-    p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(q, bf16x2));
-}
 
 // w [n][k] fp32 (row stride ldw) -> tile-ordered split image (device-side builder; network.hip builds the same image on
 // the host).  One thread = one 16-B chunk (8 k values of one row) of each plane.
@@ -214,18 +201,6 @@ bool gemm_split_eligible(int n, int k) { return n >= 192 && k >= 32 && k % 8 == 
 
 int64_t gemm_split_image_bytes(int n, int k) { return (int64_t)((n + BN - 1) / BN) * ((k + BK - 1) / BK) * W_TILE; }
 
-static inline uint16_t bf16_rne(float x) {
-    uint32_t u;
-    std::memcpy(&u, &x, 4);
-    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);  // finite inputs only (weights)
-}
-static inline float bf16_to_f32(uint16_t h) {
-    const uint32_t u = (uint32_t)h << 16;
-    float f;
-    std::memcpy(&f, &u, 4);
-    return f;
-}
-
 void gemm_split_image_host(const float* w, int64_t ldw, int n, int k, unsigned char* img) {
     const int k_tiles = (k + BK - 1) / BK;
     const int n_pad = (n + BN - 1) / BN * BN;
@@ -235,13 +210,11 @@ void gemm_split_image_host(const float* w, int64_t ldw, int n, int k, unsigned c
             for (int j = 0; j < 8; ++j) {
                 const int kk = 8 * kc + j;
                 const float x = (row < n && kk < k) ? w[(int64_t)row * ldw + kk] : 0.f;
-                const uint16_t h0 = bf16_rne(x);
-                const float r1 = x - bf16_to_f32(h0);
-                const uint16_t h1 = bf16_rne(r1);
-                const float r2 = r1 - bf16_to_f32(h1);
-                pl[0][j] = h0;
-                pl[1][j] = h1;
-                pl[2][j] = bf16_rne(r2);
+                uint16_t h[3];
+                split3_host(x, h);
+                pl[0][j] = h[0];
+                pl[1][j] = h[1];
+                pl[2][j] = h[2];
             }
             unsigned char* tile = img + ((int64_t)(row / BN) * k_tiles + kc / 4) * W_TILE;
             for (int p = 0; p < 3; ++p) std::memcpy(tile + p * W_PLANE + tile_off(row % BN, kc % 4), pl[p], 16);

@@ -20,6 +20,7 @@
 #include "../kernels.hpp"
 #include "../network.hpp"
 #include "device_math.hpp"
+#include "split_bf16.hpp"
 
 namespace {
 
@@ -200,6 +201,185 @@ __global__ __launch_bounds__(64 * WAVES, 4) void legacy_unit_kernel(const Legacy
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// bf16x3 variant (split_bf16.hpp): the same tile walk, both products on the bf16 matrix cores at fp32 accuracy.
+//   * snake(x) is split ONCE per element while it is staged: three bf16 planes of the S tile in LDS (row stride an odd
+//     multiple of 16 B: conflict-free 16-B fragment reads);
+//   * k order of the dilated conv: k step s = 8-channel groups g = 2s (lane half 0) and 2s+1 (lane half 1), g = tap * C/8 +
+//     channel group, so a lane reads 8 consecutive channels of one tap's row; the W1 image is laid out to match;
+//   * the hidden tile X^T (accumulator registers) is split in registers and is the B operand of the 1x1 conv; the W2
+//     image uses the accumulator's row order (split_sigma);
+//   * weight images hold only the C real rows: lanes of the padding rows read row C-1 (finite values whose products meet
+//     zero weights or are never stored).
+// MFMA cycles per 32 frames: (ceil(7C/16) + 2) * 6 * 32 vs (7C/2 + 16) * 64 for the fp32 kernel (C = 24: 2.5k vs 6.4k).
+template <int C>
+struct LSGeo {
+    static constexpr int NG = C / 8;                // 8-channel groups per tap
+    static constexpr int NGT = 7 * NG;              // groups in all
+    static constexpr int NS1 = (NGT + 1) / 2;       // k steps (16) of the dilated conv
+    static constexpr int NS2 = (C + 15) / 16;       // k steps of the 1x1 conv (hidden rows >= C are padding)
+    static constexpr int PS = 2 * C + ((2 * C) % 32 == 16 ? 0 : 16);  // S plane row stride in bytes
+    static constexpr int W1_BYTES = NS1 * 3 * 2 * C * 16;
+    static constexpr int W2_BYTES = 2 * 3 * 2 * C * 16;
+    static constexpr int OFF_W2 = W1_BYTES;
+    static constexpr int OFF_P = OFF_W2 + W2_BYTES;  // 32 x (alpha1, 1/alpha1, b1, b2)
+    static constexpr int OFF_S = OFF_P + 512;
+    static constexpr int lds_bytes(int dil) { return OFF_S + 3 * (FRAMES + 6 * dil) * PS; }
+};
+
+template <int C>
+__global__ __launch_bounds__(64 * WAVES, 4) void legacy_unit_split_kernel(const LegacyW w, const float* __restrict__ x,
+                                                                        float* __restrict__ y, int frames, int tiles_per_clip,
+                                                                        int total_tiles) {
+    using G = LSGeo<C>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    unsigned char* W1b = smem_b;
+    unsigned char* W2b = smem_b + G::OFF_W2;
+    float* Ps = reinterpret_cast<float*>(smem_b + G::OFF_P);
+    unsigned char* Sb = smem_b + G::OFF_S;
+    constexpr int NT = 64 * WAVES;
+    constexpr int RPP = NT / (C / 4);
+    constexpr int PF = (FRAMES + 54 + RPP - 1) / RPP;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dil = w.dil;
+    const int rows = FRAMES + 6 * dil;
+    const int splane = rows * G::PS;  // bytes between the planes of the S tile
+    const int srow = tid / (C / 4) + (tid < RPP * (C / 4) ? 0 : FRAMES + 54);
+    const int sc0 = 4 * (tid % (C / 4));
+
+    float4 pre[PF];
+    auto prefetch = [&](int tile) __attribute__((always_inline)) {
+        const int b = tile / tiles_per_clip;
+        const int t0 = (tile - b * tiles_per_clip) * FRAMES;
+        const float* clip = x + (int64_t)b * frames * C;
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            const int row = srow + j * RPP;
+            const int t = t0 - 3 * dil + row;
+            pre[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < rows && t >= 0 && t < frames) pre[j] = *reinterpret_cast<const float4*>(clip + (int64_t)t * C + sc0);
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < total_tiles) prefetch(tile);
+
+    // weight images are copied verbatim, once per workgroup
+    for (int i = tid; i < (G::W1_BYTES + G::W2_BYTES) / 16; i += NT) {
+        const int off = 16 * i;
+        const u32x4 v = off < G::W1_BYTES ? *reinterpret_cast<const u32x4*>(w.w1_img + off)
+                                         : *reinterpret_cast<const u32x4*>(w.w2_img + (off - G::W1_BYTES));
+        *reinterpret_cast<u32x4*>(smem_b + off) = v;
+    }
+    if (tid < 32) {
+        const bool ok = tid < C;
+        *reinterpret_cast<float4*>(Ps + 4 * tid) =
+            make_float4(ok ? w.a1[tid] : 1.f, ok ? w.ia1[tid] : 0.f, ok ? w.b1[tid] : 0.f, ok ? w.b2[tid] : 0.f);
+    }
+    const int lj = lane & 31;
+    const int lh = lane >> 5;
+    const int m0 = 32 * wave;
+    const int rc = lj < C ? lj : C - 1;           // weight-image row of this lane
+    const int wlane = (lh * C + rc) * 16;         // + (step * 3 + plane) * 2 * C * 16
+    const int dps = dil * G::PS;
+
+    for (; tile < total_tiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_clip;
+        const int t0 = (tile - b * tiles_per_clip) * FRAMES;
+        const float* clip = x + (int64_t)b * frames * C;
+        // ---- S tile: snake(x), split into three bf16 planes ----------------------------------------------------
+        const float4 al = *reinterpret_cast<const float4*>(w.a0 + sc0);
+        const float4 ia = *reinterpret_cast<const float4*>(w.ia0 + sc0);
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            const int row = srow + j * RPP;
+            if (row < rows) {
+                const float4 xv = pre[j];
+                unsigned a0, a1, a2, b0, b1, b2;
+                split2(snake_act(xv.x, al.x, ia.x), snake_act(xv.y, al.y, ia.y), a0, a1, a2);
+                split2(snake_act(xv.z, al.z, ia.z), snake_act(xv.w, al.w, ia.w), b0, b1, b2);
+                unsigned char* dst = Sb + row * G::PS + 2 * sc0;
+                *reinterpret_cast<uint2*>(dst) = make_uint2(a0, b0);
+                *reinterpret_cast<uint2*>(dst + splane) = make_uint2(a1, b1);
+                *reinterpret_cast<uint2*>(dst + 2 * splane) = make_uint2(a2, b2);
+            }
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < total_tiles) prefetch(tile + gridDim.x);  // in flight during the products
+
+        int woff = 0;  // opaque per tile: keeps the (tile-invariant) weight fragments in LDS instead of ~100 hoisted VGPRs
+        asm volatile("" : "+s"(woff));
+        int lhv = lh;  // likewise opaque: the per-step S offsets (a select on the lane half) are recomputed, not hoisted and spilled
+        asm volatile("" : "+v"(lhv));
+        const unsigned char* W1t = W1b + woff + wlane;
+        const unsigned char* W2t = W2b + woff + wlane;
+        const float* Pt = Ps + woff;
+        if (t0 + m0 < frames) {  // wave-uniform: a wave wholly beyond the clip only takes part in the barriers
+            // ---- X^T[n][m] = b1[n] + sum_{tap,c} W1[n][tap][c] S[m + (tap - 3) dil][c] -------------------------
+            f32x16_t xacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xacc[r] = Pt[4 * rowmap(r, lh) + 2];
+            const unsigned char* sl = Sb + (m0 + lj) * G::PS;
+#pragma unroll
+            for (int s = 0; s < G::NS1; ++s) {
+                const int g0 = 2 * s, g1 = 2 * s + 1 < G::NGT ? 2 * s + 1 : 0;  // the padding half re-reads group 0 (zero weights)
+                const int o0 = (g0 / G::NG) * dps + (g0 % G::NG) * 16;
+                const int o1 = (g1 / G::NG) * dps + (g1 % G::NG) * 16;
+                const unsigned char* sp = sl + (lhv ? o1 : o0);
+                bf16x8 sf[3], wf[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    sf[p] = *reinterpret_cast<const bf16x8*>(sp + p * splane);
+                    wf[p] = *reinterpret_cast<const bf16x8*>(W1t + (s * 3 + p) * 2 * C * 16);
+                }
+                xacc = mfma_split(wf, sf, xacc);
+            }
+            // ---- snake on the accumulator, split it, then Y^T[c][m] = b2[c] + sum_n W2[c][n] X^T[n][m] -----------
+            f32x16_t yacc;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float4 p0 = *reinterpret_cast<const float4*>(Pt + 4 * rowmap(r, lh));
+                const float4 p1 = *reinterpret_cast<const float4*>(Pt + 4 * rowmap(r + 1, lh));
+                f32x2 hv, al2, ia2;
+                hv.x = xacc[r]; hv.y = xacc[r + 1];
+                al2.x = p0.x; al2.y = p1.x;
+                ia2.x = p0.y; ia2.y = p1.y;
+                const f32x2 sv = snake_act2(hv, al2, ia2);  // padding rows (copies of row C-1) stay finite
+                xacc[r] = sv.x;
+                xacc[r + 1] = sv.y;
+                yacc[r] = p0.w;
+                yacc[r + 1] = p1.w;
+            }
+            bf16x8 xb[2][3];
+            split_acc_tile(xacc, xb);
+#pragma unroll
+            for (int s = 0; s < G::NS2; ++s) {
+                bf16x8 wf[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) wf[p] = *reinterpret_cast<const bf16x8*>(W2t + (s * 3 + p) * 2 * C * 16);
+                yacc = mfma_split(wf, xb[s], yacc);
+            }
+            // ---- residual + store: lane (frame lj, half lh) owns channels 8 g + 4 lh + {0..3} ---------------
+            const int t = t0 + m0 + lj;
+            if (t < frames) {
+                const float* src = clip + (int64_t)t * C;
+                float* dst = y + ((int64_t)b * frames + t) * C;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c0 = 8 * g + 4 * lh;
+                    if (c0 < C) {
+                        const float4 xr = *reinterpret_cast<const float4*>(src + c0);
+                        *reinterpret_cast<float4*>(dst + c0) = make_float4(xr.x + yacc[4 * g], xr.y + yacc[4 * g + 1],
+                                                                           xr.z + yacc[4 * g + 2], xr.w + yacc[4 * g + 3]);
+                    }
+                }
+            }
+        }
+        __syncthreads();  // every wave is done with the S tile before the next one overwrites it
+    }
+}
+
 // head: audio[t] = tanh(b + sum_{tap,c} w[tap][c] snake(x[t + tap - 3][c]))
 template <int C>
 __global__ __launch_bounds__(FRAMES) void head_fused_kernel(const HeadW w, const float* __restrict__ x, int frames,
@@ -246,13 +426,17 @@ __global__ __launch_bounds__(FRAMES) void head_fused_kernel(const HeadW w, const
 
 template <int C>
 int launch_legacy_t(hipStream_t s, const LegacyW& w, const float* x, float* y, int batch, int frames) {
-    using G = LGeo<C>;
-    const size_t lds = (size_t)G::lds_floats(w.dil) * sizeof(float);
     L3AC_REQUIRE(w.dil >= 1 && w.dil <= 9, "legacy unit: dilation %d outside the LDS tile budget", w.dil);
+    const bool split = w.w1_img && w.w2_img && gemm_split_enabled();
+    using G = LGeo<C>;
+    using GS = LSGeo<C>;
+    const size_t lds = split ? (size_t)GS::lds_bytes(w.dil) : (size_t)G::lds_floats(w.dil) * sizeof(float);
     static bool configured = false;
     if (!configured) {
         L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(legacy_unit_kernel<C>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(G::lds_floats(9) * sizeof(float))));
+        L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(legacy_unit_split_kernel<C>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, GS::lds_bytes(9)));
         configured = true;
     }
     const double rows = (double)batch * frames;
@@ -260,9 +444,13 @@ int launch_legacy_t(hipStream_t s, const LegacyW& w, const float* x, float* y, i
     const int64_t total = (int64_t)tiles_per_clip * batch;
     L3AC_REQUIRE(total < (1ll << 31), "legacy unit: too many tiles");
     const unsigned grid = (unsigned)std::min<int64_t>(total, 2 * 256);  // persistent: 2 workgroups per CU
-    ProfScope prof(s, "legacy_unit_kernel", rows * (2.0 * 7 * C * C + 2.0 * C * C + 40.0 * C), rows * 8.0 * C);
-    hipLaunchKernelGGL((legacy_unit_kernel<C>), dim3(grid), dim3(64 * WAVES), lds, s, w, x, y, frames, tiles_per_clip,
-                       (int)total);
+    ProfScope prof(s, split ? "legacy_unit_split_kernel" : "legacy_unit_kernel", rows * (2.0 * 7 * C * C + 2.0 * C * C + 40.0 * C),
+                   rows * 8.0 * C);
+    if (split)
+        hipLaunchKernelGGL((legacy_unit_split_kernel<C>), dim3(grid), dim3(64 * WAVES), lds, s, w, x, y, frames, tiles_per_clip,
+                           (int)total);
+    else
+        hipLaunchKernelGGL((legacy_unit_kernel<C>), dim3(grid), dim3(64 * WAVES), lds, s, w, x, y, frames, tiles_per_clip, (int)total);
     L3AC_LAUNCH_CHECK();
     return L3AC_OK;
 }
@@ -302,4 +490,40 @@ int launch_head_fused(hipStream_t s, const HeadW& w, const float* x, int batch, 
         case 32: return launch_head_t<32>(s, w, x, batch, frames, audio);
         default: l3ac_set_error("head: C=%d not supported by the fused kernel", w.c); return L3AC_EINVAL;
     }
+}
+
+// ---- host builders of the bf16x3 weight images (layouts: legacy_unit_split_kernel) ---------------------------------------
+std::vector<unsigned char> legacy_w1_image(const float* w1, int c) {
+    const int ng = c / 8, ngt = 7 * ng, ns1 = (ngt + 1) / 2;
+    std::vector<unsigned char> img((size_t)ns1 * 3 * 2 * c * 16, 0);
+    for (int s = 0; s < ns1; ++s)
+        for (int h = 0; h < 2; ++h) {
+            const int g = 2 * s + h;
+            if (g >= ngt) continue;  // zero padding of the last half step
+            const int tap = g / ng, cg = g % ng;
+            for (int r = 0; r < c; ++r)
+                for (int j = 0; j < 8; ++j) {
+                    uint16_t pl[3];
+                    split3_host(w1[(size_t)r * 7 * c + (size_t)tap * c + 8 * cg + j], pl);
+                    for (int p = 0; p < 3; ++p)
+                        std::memcpy(img.data() + ((((size_t)s * 3 + p) * 2 + h) * c + r) * 16 + 2 * j, &pl[p], 2);
+                }
+        }
+    return img;
+}
+
+std::vector<unsigned char> legacy_w2_image(const float* w2, int c) {
+    std::vector<unsigned char> img((size_t)2 * 3 * 2 * c * 16, 0);
+    for (int s = 0; s < 2; ++s)
+        for (int h = 0; h < 2; ++h)
+            for (int r = 0; r < c; ++r)
+                for (int j = 0; j < 8; ++j) {
+                    const int n = split_sigma(s, h, j);  // hidden channel this fragment element multiplies
+                    if (n >= c) continue;
+                    uint16_t pl[3];
+                    split3_host(w2[(size_t)r * c + n], pl);
+                    for (int p = 0; p < 3; ++p)
+                        std::memcpy(img.data() + ((((size_t)s * 3 + p) * 2 + h) * c + r) * 16 + 2 * j, &pl[p], 2);
+                }
+    return img;
 }

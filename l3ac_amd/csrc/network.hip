@@ -16,6 +16,9 @@ struct Builder {
     std::string err;
     struct GemmWeight { const float* d; int n, k; };
     std::vector<GemmWeight> gemm_ws;  // [n][k] weights that get a split image
+    struct ExtraImage { std::vector<unsigned char> bytes; const unsigned char** target; };
+    std::vector<ExtraImage> extra_imgs;  // other bf16x3 images (fused kernels), bound to *target after the upload
+    const float* host_of(const float* d) const { return host.data() + (d - dev); }
 
     const float* gemm(const float* d, int n, int k) {
         if (d && gemm_split_eligible(n, k)) gemm_ws.push_back({d, n, k});
@@ -367,6 +370,12 @@ int network_build(l3ac_ctx* ctx, const l3ac_tensor* tensors, int n_tensors) {
             l.b2 = b.copy(p + ".3.bias", cl);
             ctx->legacy.push_back(l);
         }
+        if (b.err.empty() && last_block_fused_supported(cl, 9)) {  // (ctx->legacy no longer reallocates: the targets stay valid)
+            for (LegacyW& l : ctx->legacy) {
+                b.extra_imgs.push_back({legacy_w1_image(b.host_of(l.w1), cl), &l.w1_img});
+                b.extra_imgs.push_back({legacy_w2_image(b.host_of(l.w2), cl), &l.w2_img});
+            }
+        }
         ctx->head.c = cl;
         ctx->head.alpha = b.copy(lp + ".1.alpha", cl);
         ctx->head.inv_alpha = b.inv_alpha(lp + ".1.alpha", cl);
@@ -379,19 +388,27 @@ int network_build(l3ac_ctx* ctx, const l3ac_tensor* tensors, int n_tensors) {
     }
     L3AC_HIP_CHECK(hipMemcpy(ctx->arena, b.host.data(), b.host.size() * sizeof(float), hipMemcpyHostToDevice));
 
-    // ---- bf16x3 split images of the GEMM weights, from the arena's host staging copy (final layouts) ----------
+    // ---- bf16x3 split images of the GEMM weights (from the arena's host staging copy: final layouts) and of the
+    //      fused kernels' weights, in one device allocation ------------------------------------------------------
     {
+        auto pad = [](size_t n) { return (n + 255) / 256 * 256; };
         size_t total_img = 0;
-        for (const auto& g : b.gemm_ws) total_img += (size_t)gemm_split_image_bytes(g.n, g.k);
+        for (const auto& g : b.gemm_ws) total_img += pad((size_t)gemm_split_image_bytes(g.n, g.k));
+        for (const auto& e : b.extra_imgs) total_img += pad(e.bytes.size());
         if (total_img) {
-            std::vector<unsigned char> himg(total_img);
+            std::vector<unsigned char> himg(total_img, 0);
             L3AC_HIP_CHECK(hipMalloc((void**)&ctx->img_arena, total_img));
             ctx->img_bytes = total_img;
             size_t off = 0;
             for (const auto& g : b.gemm_ws) {
-                gemm_split_image_host(b.host.data() + (g.d - b.dev), g.k, g.n, g.k, himg.data() + off);
+                gemm_split_image_host(b.host_of(g.d), g.k, g.n, g.k, himg.data() + off);
                 ctx->split_img[g.d] = ctx->img_arena + off;
-                off += (size_t)gemm_split_image_bytes(g.n, g.k);
+                off += pad((size_t)gemm_split_image_bytes(g.n, g.k));
+            }
+            for (const auto& e : b.extra_imgs) {
+                std::memcpy(himg.data() + off, e.bytes.data(), e.bytes.size());
+                *e.target = ctx->img_arena + off;
+                off += pad(e.bytes.size());
             }
             L3AC_HIP_CHECK(hipMemcpy(ctx->img_arena, himg.data(), total_img, hipMemcpyHostToDevice));
         }

@@ -33,6 +33,8 @@ struct UpW {  // modules.py:160-164
 struct LegacyW {  // modules.py:47-64
     int c = 0, dil = 1;
     const float *a0, *ia0, *w1, *b1, *a1, *ia1, *w2, *b2;
+    // bf16x3 fragment images of w1 / w2 for the split kernel (kernels/last_block.hip), null when not built
+    const unsigned char *w1_img = nullptr, *w2_img = nullptr;
 };
 struct HeadW {  // modules.py:192-194
     int c = 0;
@@ -105,6 +107,9 @@ bool conv_unit_fused_supported(int c);
 int launch_conv_unit_fused(hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames);
 // fused LegacyUnit / head (kernels/last_block.hip); x must not alias y
 bool last_block_fused_supported(int c, int max_dil);
+// host builders of the LegacyUnit weight images: w1 [c][7][c] (tap-major rows), w2 [c][c]
+std::vector<unsigned char> legacy_w1_image(const float* w1, int c);
+std::vector<unsigned char> legacy_w2_image(const float* w2, int c);
 int launch_legacy_unit_fused(hipStream_t s, const LegacyW& w, const float* x, float* y, int batch, int frames);
 int launch_head_fused(hipStream_t s, const HeadW& w, const float* x, int batch, int frames, float* audio);
 // one ConvUnit of a stage on the ping-pong buffers: fused kernel (result in *alt, buffers swapped) or in place
