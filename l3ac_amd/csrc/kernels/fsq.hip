@@ -39,6 +39,16 @@ struct FsqDev {
     float* latents;
 };
 
+// streamed once: non-temporal accesses keep the rows out of the way of L2 / MALL residents
+typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load4(const float* p) {
+    const f32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void nt_store4(float* p, const float4& v) {
+    __builtin_nontemporal_store(f32x4_nt{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4_nt*>(p));
+}
+
 template <int D, int NV>  // NV 16-byte chunks (4 channels each) per lane: lanes per token = feat / (4 NV)
 __global__ __launch_bounds__(THREADS) void fsq_kernel(const FsqDev p, const int lpt) {
     // HBM-bound by construction (1 052 B per token); what limits it in practice is bytes in flight and issue slots,
@@ -60,7 +70,9 @@ __global__ __launch_bounds__(THREADS) void fsq_kernel(const FsqDev p, const int 
 
     const int sub = tid % lpt;          // lane within the token's group
     const int lane = tid & 63;
-    const int c0 = sub * 4 * NV;        // this lane's channels
+    // channel quads are dealt round-robin over the lanes of a token: quad v of lane `sub` = channels 4 (v lpt + sub) .. +3,
+    // so every load / store instruction of a wave covers whole 128-B lines (8 lanes x 16 B contiguous per token)
+    const int cq = 4 * sub, cstep = 4 * lpt;
     const int tok_per_block = THREADS / lpt;
     const int64_t n_groups = (p.n + tok_per_block - 1) / tok_per_block;
     const int64_t per_block = (n_groups + gridDim.x - 1) / gridDim.x;  // contiguous token range per block
@@ -75,7 +87,7 @@ __global__ __launch_bounds__(THREADS) void fsq_kernel(const FsqDev p, const int 
         const int64_t t = g * tok_per_block + tid / lpt;
         if (p.x && g < g_end && t < p.n) {
 #pragma unroll
-            for (int v = 0; v < NV; ++v) x_next[v] = *reinterpret_cast<const float4*>(p.x + t * p.feat + c0 + 4 * v);
+            for (int v = 0; v < NV; ++v) x_next[v] = *reinterpret_cast<const float4*>(p.x + t * p.feat + cq + cstep * v);
         }
     };
     auto quantise = [&](float lat, int d) -> float {
@@ -104,7 +116,7 @@ __global__ __launch_bounds__(THREADS) void fsq_kernel(const FsqDev p, const int 
                     float s = 0.f;
 #pragma unroll
                     for (int v = 0; v < NV; ++v) {
-                        const float4 wv = *reinterpret_cast<const float4*>(Win + d * p.feat + c0 + 4 * v);
+                        const float4 wv = *reinterpret_cast<const float4*>(Win + d * p.feat + cq + cstep * v);
                         s = fmaf(xv[v].x, wv.x, s); s = fmaf(xv[v].y, wv.y, s);
                         s = fmaf(xv[v].z, wv.z, s); s = fmaf(xv[v].w, wv.w, s);
                     }
@@ -135,7 +147,7 @@ __global__ __launch_bounds__(THREADS) void fsq_kernel(const FsqDev p, const int 
         float idx_f = 0.f;
         float4 o[NV];
 #pragma unroll
-        for (int v = 0; v < NV; ++v) o[v] = *reinterpret_cast<const float4*>(Bout + c0 + 4 * v);
+        for (int v = 0; v < NV; ++v) o[v] = *reinterpret_cast<const float4*>(Bout + cq + cstep * v);
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             idx_f += li[d] * (float)p.basis[d];                                 // exact (vq/fsq.py:67-68)
@@ -143,15 +155,15 @@ __global__ __launch_bounds__(THREADS) void fsq_kernel(const FsqDev p, const int 
             const float q = __fsub_rn(__fmul_rn(q_act, 2.0f), 1.0f);            // vq/fsq.py:21
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
-                const float4 wv = *reinterpret_cast<const float4*>(Wout + d * p.feat + c0 + 4 * v);
+                const float4 wv = *reinterpret_cast<const float4*>(Wout + d * p.feat + cq + cstep * v);
                 o[v].x = fmaf(q, wv.x, o[v].x); o[v].y = fmaf(q, wv.y, o[v].y);
                 o[v].z = fmaf(q, wv.z, o[v].z); o[v].w = fmaf(q, wv.w, o[v].w);
             }
         }
         if (ok) {
-            float* dst = p.q_feature + tok * p.feat + c0;
+            float* dst = p.q_feature + tok * p.feat + cq;
 #pragma unroll
-            for (int v = 0; v < NV; ++v) *reinterpret_cast<float4*>(dst + 4 * v) = o[v];
+            for (int v = 0; v < NV; ++v) *reinterpret_cast<float4*>(dst + cstep * v) = o[v];
             if (sub == 0) {
                 if (p.indices) p.indices[tok] = (int32_t)idx_f;
                 if (p.level_indices) {

@@ -57,3 +57,9 @@ if __name__ == "__main__":
         ms = time_ms(fn, reps=3)
         print(f"vq_argmin K={cb.shape[0]} N={n}: {ms:.3f} ms  {18.0 * n * cb.shape[0] / ms / 1e9:.1f} TFLOP/s "
               f"({18.0 * n * cb.shape[0] / ms / 1e9 / 157.3:.1%} of fp32 peak)", flush=True)
+    # calibration: what a plain device-to-device copy of the same volume reaches (read + write counted)
+    for mb in (512, 2048):
+        a = torch.empty(mb * (1 << 20) // 4, device=dev)
+        b = torch.empty_like(a)
+        ms = time_ms(lambda: b.copy_(a))
+        print(f"copy {mb} MiB: {2 * a.numel() * 4 / ms / 1e6:8.1f} GB/s ({2 * a.numel() * 4 / ms / 1e6 / 8000:.1%} of 8 TB/s)", flush=True)
