@@ -143,6 +143,9 @@ def main():
             captured = step()
         run = lambda: (graph.replay(), captured)[1]
 
+    # the quantiser's stand-alone HBM roofline (its own large-N launch) is taken first, on an idle chip: after the MFMA-heavy
+    # pipeline the same launch measures ~10 % lower while the clocks recover
+    fsq_line = fsq_microbench(codec, dev) if rank == 0 else None
     for _ in range(args.warmup):
         run()
     if world > 1:
@@ -241,7 +244,7 @@ def main():
             l3ac_amd.set_gemm_split(True)
             out["exact_f32_mfma_route"] = {"ms_per_step": ex * 1e3, "value": b * samples / ex, "unit": "samples/s",
                                            "token_differences_vs_split_route": int((ind_x["indices"] != ind["indices"]).sum())}
-        out["fsq_kernel"] = fsq_microbench(codec, dev)
+        out["fsq_kernel"] = fsq_line
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(codec, audio, args.cpu_batch, ind, args.cpu_threads)
         print(json.dumps(out), flush=True)
@@ -271,10 +274,10 @@ def fsq_microbench(codec, dev, n_tokens=1 << 22):
                                                     wt["project_in.bias"].data_ptr(), wt["project_out.weight"].data_ptr(),
                                                     wt["project_out.bias"].data_ptr(), q.data_ptr(), idx.data_ptr(),
                                                     li.data_ptr(), None, s))
-    for _ in range(3):
+    for _ in range(50):  # ~50 ms: lets the memory / fabric clocks ramp from idle before the timed launches
         call()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 10
+    reps = 20
     e0.record()
     for _ in range(reps):
         call()

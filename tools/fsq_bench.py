@@ -31,7 +31,7 @@ if __name__ == "__main__":
         d, feat = len(levels), 128
         lv = (C.c_int32 * d)(*levels)
         g = torch.Generator().manual_seed(0)
-        w_in = (torch.rand(d, feat, generator=g) - 0.5).to(dev) * 0.2
+        w_in = (torch.rand(d, feat, generator=g) - 0.5).to(dev) * float(sys.argv[1] if len(sys.argv) > 1 else 0.2)
         b_in = torch.zeros(d, device=dev)
         w_out = (torch.rand(feat, d, generator=g) - 0.5).to(dev)
         b_out = torch.zeros(feat, device=dev)
