@@ -333,6 +333,37 @@ __global__ __launch_bounds__(THREADS) void grn_apply_kernel(float* __restrict__ 
     }
 }
 
+// EnhanceBlock gate as a flat elementwise pass (no row reduction is needed): thread i owns 16 B of the tensor, so every lane
+// is busy whatever the channel count (the row kernel idles 25 % of its lanes at c = 48 / 96); same arithmetic as SRC_GATE.
+__global__ __launch_bounds__(THREADS) void gate_flat_kernel(const RowArgs p, const unsigned n4, const unsigned nchunk) {
+    const float4 iw = *reinterpret_cast<const float4*>(p.in_w);
+    const float4 ib = *reinterpret_cast<const float4*>(p.in_b);
+    for (unsigned i = blockIdx.x * THREADS + threadIdx.x; i < n4; i += gridDim.x * THREADS) {
+        const unsigned row = i / nchunk;
+        const int c0 = (int)(i - row * nchunk) << 2;
+        const unsigned b = row / (unsigned)p.frames_in;
+        const float4 yraw = *reinterpret_cast<const float4*>(p.yi + (int64_t)row * 4);
+        const float4 mean = *reinterpret_cast<const float4*>(p.stats + b * 8);
+        const float4 istd = *reinterpret_cast<const float4*>(p.stats + b * 8 + 4);
+        const float y0 = (yraw.x - mean.x) * istd.x * iw.x + ib.x;
+        const float y1 = (yraw.y - mean.y) * istd.y * iw.y + ib.y;
+        const float y2 = (yraw.z - mean.z) * istd.z * iw.z + ib.z;
+        const float y3 = (yraw.w - mean.w) * istd.w * iw.w + ib.w;
+        const float4 xv = reinterpret_cast<const float4*>(p.x)[i];
+        const float4 gb = *reinterpret_cast<const float4*>(p.gate_b + c0);
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+        const float gbs[4] = {gb.x, gb.y, gb.z, gb.w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float4 gw = *reinterpret_cast<const float4*>(p.gate_w + (int64_t)(c0 + e) * 4);
+            const float g = gbs[e] + gw.x * y0 + gw.y * y1 + gw.z * y2 + gw.w * y3;
+            o[e] = xs[e] + g * xs[e];
+        }
+        reinterpret_cast<float4*>(p.y)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 inline unsigned stream_grid(int64_t work_items) {
     const int64_t blocks = ceil_div64(work_items, THREADS);
     return (unsigned)(blocks < 1 ? 1 : (blocks > 256 * 16 ? 256 * 16 : blocks));
@@ -354,6 +385,16 @@ int launch_rows(hipStream_t s, const RowArgs& r) {
     L3AC_ROWS_CASE(SRC_DWCONV7, NORM_LN);
     L3AC_ROWS_CASE(SRC_LERP, NORM_NONE);
     L3AC_ROWS_CASE(SRC_LERP, NORM_CN);
+    if (r.src == SRC_GATE && r.norm == NORM_NONE && r.frames_in == r.frames_out && r.batch * r.frames_out * (r.c / 4) < (1ll << 31)) {
+        const int64_t n4 = r.batch * r.frames_out * (r.c / 4);
+        if (n4 == 0) return L3AC_OK;
+        ProfScope prof(s, "gate_flat_kernel", 10.0 * n4 * 4, 32.0 * n4);
+        const int64_t blocks = ceil_div64(n4, THREADS);
+        hipLaunchKernelGGL(gate_flat_kernel, dim3((unsigned)(blocks > 256 * 64 ? 256 * 64 : blocks)), dim3(THREADS), 0, s, r, (unsigned)n4,
+                           (unsigned)(r.c / 4));
+        L3AC_LAUNCH_CHECK();
+        return L3AC_OK;
+    }
     L3AC_ROWS_CASE(SRC_GATE, NORM_NONE);
 #undef L3AC_ROWS_CASE
     l3ac_set_error("rows: unsupported (src=%d, norm=%d)", r.src, r.norm);
