@@ -85,6 +85,9 @@ def main():
                     help="host threads for the CPU baseline (32 measured fastest on the 256-thread GPU box; "
                          "torch's default of 128 is 3x slower: tools/experiments/cpu_threads.py)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph")
+    ap.add_argument("--pipeline-only", action="store_true",
+                    help="skip the stand-alone FSQ launch, the exact-route reference steps and the CPU baseline (profiling runs: "
+                         "keeps the kernel trace to the timed workload)")
     ap.add_argument("--gemm", choices=["split", "exact"], default="split",
                     help="split: large fp32 contractions as exact bf16x3 operand splits on the bf16 matrix cores (default); "
                          "exact: every product on the fp32 MFMA instruction")
@@ -145,7 +148,7 @@ def main():
 
     # the quantiser's stand-alone HBM roofline (its own large-N launch) is taken first, on an idle chip: after the MFMA-heavy
     # pipeline the same launch measures ~10 % lower while the clocks recover
-    fsq_line = fsq_microbench(codec, dev) if rank == 0 else None
+    fsq_line = fsq_microbench(codec, dev) if rank == 0 and not args.pipeline_only else None
     for _ in range(args.warmup):
         run()
     if world > 1:
@@ -198,10 +201,13 @@ def main():
         traffic, traffic_src = None, None
         tfile = REPO / "profiles" / "r01" / "traffic.json"
         if tfile.exists() and args.config == "1kbps" and b == 256 and samples == 16000:
-            pmc = {k.replace(" ", ""): v for k, v in json.load(open(tfile))["kernels"].items()}
-            hit = pmc.get(dom["name"].replace(" ", ""))
-            if hit:
-                traffic, traffic_src = hit["hbm_bytes_per_launch_corrected"], "profiles/r01/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+            # rocprofv3 names carry the template arguments (gemm_split_kernel<false>): match on the bare kernel name and
+            # average over its instantiations, weighted by launches
+            hits = [v for k, v in json.load(open(tfile))["kernels"].items() if k.split("<")[0].strip() == dom["name"].split("<")[0]]
+            if hits:
+                n = sum(h["launches"] for h in hits)
+                traffic = sum(h["hbm_bytes_per_launch_corrected"] * h["launches"] for h in hits) / n
+                traffic_src = "profiles/r01/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
         roof.update(frac=roof["achieved"] / roof["peak"], traffic=traffic, traffic_source=traffic_src,
                     algorithmic_bytes_per_launch=dom["bytes"] / dom["launches"], kernel=dom["name"],
                     launches_per_step=dom["launches"], avg_launch_ms=dom_ms, share_of_step=dom["ms_total"] / total_ms)
@@ -230,7 +236,7 @@ def main():
             "gemm_shapes": [{"name": e["name"], "launches": e["launches"], "ms": round(e["ms_total"], 4),
                              "tflops": round(e["flops"] / e["ms_total"] / 1e9, 2)} for e in shapes[:16]],
         }
-        if args.gemm == "split" and world == 1 and not args.graph:
+        if args.gemm == "split" and world == 1 and not args.graph and not args.pipeline_only:
             # the same step with every product on the exact fp32 MFMA instruction, for reference (5 steps, untimed above)
             l3ac_amd.set_gemm_split(False)
             for _ in range(2):
@@ -245,7 +251,7 @@ def main():
             out["exact_f32_mfma_route"] = {"ms_per_step": ex * 1e3, "value": b * samples / ex, "unit": "samples/s",
                                            "token_differences_vs_split_route": int((ind_x["indices"] != ind["indices"]).sum())}
         out["fsq_kernel"] = fsq_line
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and not args.pipeline_only:
             out["cpu_baseline"] = cpu_baseline(codec, audio, args.cpu_batch, ind, args.cpu_threads)
         print(json.dumps(out), flush=True)
     if world > 1:

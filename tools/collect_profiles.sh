@@ -4,7 +4,7 @@
 OUT=$GRAFT_REPO_ROOT/${1:-gpurun_out/prof}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+B="python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --pipeline-only"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B > $OUT/trace_bench.json 2> $OUT/trace_err.txt
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $B > /dev/null 2> $OUT/pmc_fetch_err.txt
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $B > /dev/null 2> $OUT/pmc_write_err.txt
