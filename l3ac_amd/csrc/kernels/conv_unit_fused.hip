@@ -14,8 +14,8 @@
 //     half h is row (r&3) + 8(r>>2) + 4h; the W2 fragment is fetched in the same order).  The hidden activations
 //     never leave registers: no LDS transpose, no HBM traffic.
 //   * C = 24 / 48: W1, W2 stay resident in LDS for the lifetime of a persistent workgroup and the waves never
-//     synchronise.  C = 96: the weights (295 KB) are streamed through LDS in chunks of HC hidden channels, L2-served,
-//     one block-wide barrier pair per chunk.
+//     synchronise.  C = 96: the weights (295 KB) are streamed through LDS in chunks of HC = 32 hidden channels, L2-served,
+//     double-buffered: chunk c+1 is fetched into registers while chunk c is multiplied, one block barrier per chunk.
 //   * lane (j, h) computes the depth-wise conv + LayerNorm of frame j for the channels k = 8q + 4h + {0..3} it
 //     later feeds to the MFMAs as the B operand, from a per-wave LDS copy of the 38 input rows (halo 3 + 3).
 //   * the first product of hidden tile nt+1 is issued before the activation of tile nt, so the MFMA pipe and the
@@ -44,16 +44,18 @@ struct Geo {
     static constexpr int W2S = HC + 4;
     static constexpr int ROWS = 38;           // 32 frames + 3 + 3 halo
     // LDS carve (floats)
+    static constexpr int NBUF = NCH == 1 ? 1 : 2;             // streamed weight chunks are double-buffered
     static constexpr int OFF_W1 = 0;                          // [HC][W1S]
     static constexpr int OFF_W2 = OFF_W1 + HC * W1S;          // [C + 1][W2S], last row all zeros (padding channels)
-    static constexpr int OFF_P = OFF_W2 + (C + 1) * W2S;      // alpha[H4], 1/alpha[H4], gamma[H4], beta[H4]
+    static constexpr int WBUF = HC * W1S + (C + 1) * W2S;     // floats per weight buffer
+    static constexpr int OFF_P = OFF_W1 + NBUF * WBUF;        // alpha[H4], 1/alpha[H4], gamma[H4], beta[H4]
     static constexpr int OFF_B1 = OFF_P + H4 * 4;
     static constexpr int OFF_B2 = OFF_B1 + H4;
     static constexpr int OFF_DW = OFF_B2 + 32 * CT;           // dw_w [7][C], dw_b, ln_w, ln_b
     static constexpr int OFF_XS = OFF_DW + 10 * C;
     static constexpr int xs_floats = ROWS * XS;
     static constexpr int lds_floats(int waves) { return OFF_XS + waves * xs_floats; }
-    static_assert(H4 % HC == 0 && HC % 32 == 0 && C % (8 * XH) == 0, "bad geometry");
+    static_assert(H4 % HC == 0 && HC % 32 == 0 && C % (8 * XH) == 0 && (NCH == 1 || NCH % 2 == 0), "bad geometry");
 };
 
 __device__ __forceinline__ int rowmap(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_unit_fused_kernel(const ConvU
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* xs = smem + G::OFF_XS + wave * G::xs_floats;
 
-    auto stage_weights = [&](int chunk) {  // hidden channels [chunk * HC, (chunk + 1) * HC)
+    auto stage_weights = [&](int chunk) {  // resident variant: hidden channels [chunk * HC, (chunk + 1) * HC), once
         for (int i = tid; i < HC * (C / 4); i += THREADS) {
             const int row = i / (C / 4), ch = i % (C / 4);
             *reinterpret_cast<float4*>(W1s + row * G::W1S + 4 * ch) =
@@ -87,6 +89,45 @@ __global__ __launch_bounds__(64 * WAVES) void conv_unit_fused_kernel(const ConvU
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row < C) v = *reinterpret_cast<const float4*>(w.w2 + (int64_t)row * G::H4 + chunk * HC + 4 * ch);
             *reinterpret_cast<float4*>(W2s + row * G::W2S + 4 * ch) = v;
+        }
+    };
+    // streamed variant: chunk c+1 travels global -> registers while chunk c is being multiplied, and is written to the
+    // OTHER LDS buffer after the products (one block barrier per chunk, no exposed L2 latency)
+    constexpr int N1 = (HC * (C / 4) + THREADS - 1) / THREADS;
+    constexpr int N2 = ((C + 1) * (HC / 4) + THREADS - 1) / THREADS;
+    float4 wpre[RESIDENT ? 1 : N1 + N2];
+    auto load_chunk = [&](int chunk) __attribute__((always_inline)) {
+        if constexpr (!RESIDENT) {
+#pragma unroll
+            for (int k = 0; k < N1; ++k) {
+                const int i = tid + THREADS * k;
+                const int row = i / (C / 4), ch = i % (C / 4);
+                wpre[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < HC * (C / 4)) wpre[k] = *reinterpret_cast<const float4*>(w.w1 + (int64_t)(chunk * HC + row) * C + 4 * ch);
+            }
+#pragma unroll
+            for (int k = 0; k < N2; ++k) {
+                const int i = tid + THREADS * k;
+                const int row = i / (HC / 4), ch = i % (HC / 4);
+                wpre[N1 + k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < C) wpre[N1 + k] = *reinterpret_cast<const float4*>(w.w2 + (int64_t)row * G::H4 + chunk * HC + 4 * ch);
+            }
+        }
+    };
+    auto store_chunk = [&](int buf) __attribute__((always_inline)) {
+        if constexpr (!RESIDENT) {
+            float* d1 = smem + G::OFF_W1 + buf * G::WBUF;
+            float* d2 = smem + G::OFF_W2 + buf * G::WBUF;
+#pragma unroll
+            for (int k = 0; k < N1; ++k) {
+                const int i = tid + THREADS * k;
+                if (i < HC * (C / 4)) *reinterpret_cast<float4*>(d1 + (i / (C / 4)) * G::W1S + 4 * (i % (C / 4))) = wpre[k];
+            }
+#pragma unroll
+            for (int k = 0; k < N2; ++k) {
+                const int i = tid + THREADS * k;
+                if (i < (C + 1) * (HC / 4)) *reinterpret_cast<float4*>(d2 + (i / (HC / 4)) * G::W2S + 4 * (i % (HC / 4))) = wpre[N1 + k];
+            }
         }
     };
 
@@ -105,7 +146,12 @@ __global__ __launch_bounds__(64 * WAVES) void conv_unit_fused_kernel(const ConvU
         DWs[8 * C + i] = w.ln_w[i];
         DWs[9 * C + i] = w.ln_b[i];
     }
-    if (RESIDENT) stage_weights(0);
+    if (RESIDENT) {
+        stage_weights(0);
+    } else {
+        load_chunk(0);
+        store_chunk(0);  // made visible by the barrier of chunk step 0
+    }
     __syncthreads();
 
     const int lj = lane & 31;  // frame within the tile (MFMA column) / weight row within a tile (A operand)
@@ -234,10 +280,13 @@ __global__ __launch_bounds__(64 * WAVES) void conv_unit_fused_kernel(const ConvU
 
 #pragma unroll 1
         for (int chunk = 0; chunk < G::NCH; ++chunk) {
+            const float* W1s = smem + G::OFF_W1 + (RESIDENT ? 0 : (chunk & 1) * G::WBUF);  // NCH is even: parity is periodic
+            const float* W2s = smem + G::OFF_W2 + (RESIDENT ? 0 : (chunk & 1) * G::WBUF);
             if (!RESIDENT) {
-                __syncthreads();  // every wave is done with the previous chunk's weights
-                stage_weights(chunk);
+                // this chunk's buffer is complete (written during the previous step) and every wave is done reading the
+                // other one, which the next chunk's rows (in flight from here on) will overwrite after the products
                 __syncthreads();
+                load_chunk(chunk + 1 < G::NCH ? chunk + 1 : 0);
             }
             const int n_base = chunk * HC;
             // X[n][m] = b1[n] + sum_k W1[n][k] a[m][k] for hidden tile ntl of this chunk
@@ -292,6 +341,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_unit_fused_kernel(const ConvU
                     }
                 }
             }
+            if (!RESIDENT) store_chunk((chunk + 1) & 1);
         }
 
         // ---- residual + store: lane (frame lj, half lh) owns channels 32 ct + 8 g + 4 lh + {0..3} -------
@@ -350,7 +400,7 @@ int launch_conv_unit_fused(hipStream_t s, const ConvUnitW& w, const float* x, fl
     switch (w.c) {
         case 24: return launch_fused<24, 8, 96, 1>(s, w, x, y, batch, frames, "conv_unit_fused_kernel<24>");
         case 48: return launch_fused<48, 8, 192, 1>(s, w, x, y, batch, frames, "conv_unit_fused_kernel<48>");
-        case 96: return launch_fused<96, 8, 96, 2>(s, w, x, y, batch, frames, "conv_unit_fused_kernel<96>");
+        case 96: return launch_fused<96, 8, 32, 2>(s, w, x, y, batch, frames, "conv_unit_fused_kernel<96>");
         default:
             l3ac_set_error("conv_unit_fused: C=%d not supported", w.c);
             return L3AC_EINVAL;
