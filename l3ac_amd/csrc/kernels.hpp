@@ -42,6 +42,15 @@ struct GemmArgs {
     const float* gamma = nullptr;      // GRN
     const float* beta = nullptr;
     int n_out = 0;                     // EPI_GEGLU: number of valid output columns (ff inner)
+    // optional EnhanceBlock gate applied to the A operand while it is staged (tconv/__init__.py:35-44, same arithmetic as
+    // the SRC_GATE row kernel): a'(m, k) = a + (gate_b[k] + gate_w[k][:] . instnorm(yi[m][:])) * a.  Plain A, k % 16 == 0.
+    const float* gate_yi = nullptr;     // raw branch signals [m][4]
+    const float* gate_stats = nullptr;  // [clip][8] = mean[4], 1/std[4]
+    const float* gate_in_w = nullptr;   // InstanceNorm affine [4]
+    const float* gate_in_b = nullptr;
+    const float* gate_w = nullptr;      // merge conv [k][4]
+    const float* gate_b = nullptr;      // [k]
+    int64_t gate_frames = 0;            // rows per clip
 };
 int launch_gemm(hipStream_t s, const GemmArgs& g);
 

@@ -37,8 +37,10 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
 
 // FULLK: k is a multiple of BK and A is plain rows -> the staging loads are unconditional (rows / columns past the
 // edge are clamped to row 0: they only feed accumulators that are never stored), no exec-mask branches in the loop.
-template <int NT, bool CONV, int BK, bool FULLK>
+// GATED: the EnhanceBlock gate is applied to A on its way to LDS (GemmArgs::gate_*), saving that tensor's own pass.
+template <int NT, bool CONV, int BK, bool FULLK, bool GATED = false>
 __global__ __launch_bounds__(THREADS, BK == 16 ? 3 : 2) void gemm_f32_kernel(const GemmArgs p) {
+    static_assert(!GATED || (FULLK && !CONV), "the gated A operand is implemented for plain full-k tiles");
     constexpr int BN = 32 * NT;
     constexpr int CPR = BK / 4;            // 16-B chunks per tile row
     constexpr int RP = THREADS / CPR;      // tile rows staged per pass
@@ -92,6 +94,22 @@ __global__ __launch_bounds__(THREADS, BK == 16 ? 3 : 2) void gemm_f32_kernel(con
     }
     const int half = p.taps >> 1;
 
+    float4 yn[GATED ? AP : 1];  // InstanceNorm'ed branch signals of this thread's rows
+    if constexpr (GATED) {
+        const float4 iw = *reinterpret_cast<const float4*>(p.gate_in_w);
+        const float4 ib = *reinterpret_cast<const float4*>(p.gate_in_b);
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            const int64_t m = m0 + r0 + RP * i;
+            const int64_t mm = m < p.m ? m : 0;
+            const float4 yraw = *reinterpret_cast<const float4*>(p.gate_yi + mm * 4);
+            const float* st = p.gate_stats + (mm / p.gate_frames) * 8;
+            const float4 mean = *reinterpret_cast<const float4*>(st);
+            const float4 istd = *reinterpret_cast<const float4*>(st + 4);
+            yn[i] = make_float4((yraw.x - mean.x) * istd.x * iw.x + ib.x, (yraw.y - mean.y) * istd.y * iw.y + ib.y,
+                                (yraw.z - mean.z) * istd.z * iw.z + ib.z, (yraw.w - mean.w) * istd.w * iw.w + ib.w);
+        }
+    }
     float4 a_reg[AP], w_reg[WP];
     auto load_tile = [&](int k_tile) {
         const int k = k_tile + 4 * cc;
@@ -109,6 +127,23 @@ __global__ __launch_bounds__(THREADS, BK == 16 ? 3 : 2) void gemm_f32_kernel(con
                 if (a_ok[i] && k_ok) v = *reinterpret_cast<const float4*>(a_row[i] + k);
             }
             a_reg[i] = v;
+        }
+        if constexpr (GATED) {
+            const float4 gb = *reinterpret_cast<const float4*>(p.gate_b + k);
+            const float4 g0 = *reinterpret_cast<const float4*>(p.gate_w + (int64_t)k * 4);
+            const float4 g1 = *reinterpret_cast<const float4*>(p.gate_w + (int64_t)k * 4 + 4);
+            const float4 g2 = *reinterpret_cast<const float4*>(p.gate_w + (int64_t)k * 4 + 8);
+            const float4 g3 = *reinterpret_cast<const float4*>(p.gate_w + (int64_t)k * 4 + 12);
+#pragma unroll
+            for (int i = 0; i < AP; ++i) {
+                const float4 y = yn[i];
+                const float e0 = gb.x + g0.x * y.x + g0.y * y.y + g0.z * y.z + g0.w * y.w;
+                const float e1 = gb.y + g1.x * y.x + g1.y * y.y + g1.z * y.z + g1.w * y.w;
+                const float e2 = gb.z + g2.x * y.x + g2.y * y.y + g2.z * y.z + g2.w * y.w;
+                const float e3 = gb.w + g3.x * y.x + g3.y * y.y + g3.z * y.z + g3.w * y.w;
+                a_reg[i] = make_float4(a_reg[i].x + e0 * a_reg[i].x, a_reg[i].y + e1 * a_reg[i].y, a_reg[i].z + e2 * a_reg[i].z,
+                                       a_reg[i].w + e3 * a_reg[i].w);
+            }
         }
 #pragma unroll
         for (int i = 0; i < WP; ++i) {
@@ -310,8 +345,8 @@ int launch_one(hipStream_t s, const GemmArgs& g) {
     if (dma_name)
         std::snprintf(name, sizeof(name), "gemm_f32_dma_kernel<%d> %lldx%dx%d e%d", NT, (long long)g.m, g.n, g.k, g.epi);
     else
-        std::snprintf(name, sizeof(name), "gemm_f32_kernel<%d,%s,%d,%s> %lldx%dx%d e%d", NT, CONV ? "true" : "false", BK,
-                      fullk ? "true" : "false", (long long)g.m, g.n, g.k, g.epi);
+        std::snprintf(name, sizeof(name), "gemm_f32_kernel<%d,%s,%d,%s%s> %lldx%dx%d e%d", NT, CONV ? "true" : "false", BK,
+                      fullk ? "true" : "false", g.gate_yi ? ",gated" : "", (long long)g.m, g.n, g.k, g.epi);
     const double a_elems = CONV ? (double)g.m * g.cin : (double)g.m * g.k;
     const double c_cols = g.epi == EPI_GEGLU ? (double)g.ldc : (double)g.n;
     ProfScope prof(s, name, 2.0 * (double)g.m * g.n * g.k,
@@ -324,6 +359,14 @@ int launch_one(hipStream_t s, const GemmArgs& g) {
         if (fullk && use_dma) {
             const size_t lds3 = (size_t)3 * (BM + BN) * BK * sizeof(float);
             hipLaunchKernelGGL((gemm_f32_dma_kernel<NT>), dim3((unsigned)blocks), dim3(THREADS), lds3, s, g);
+            L3AC_LAUNCH_CHECK();
+            return L3AC_OK;
+        }
+    }
+    if constexpr (!CONV && BK == 16) {
+        if (g.gate_yi) {
+            L3AC_REQUIRE(fullk, "gemm: the gated A operand needs k %% 16 == 0 (k=%d)", g.k);
+            hipLaunchKernelGGL((gemm_f32_kernel<NT, false, 16, true, true>), dim3((unsigned)blocks), dim3(THREADS), lds, s, g);
             L3AC_LAUNCH_CHECK();
             return L3AC_OK;
         }
@@ -347,7 +390,13 @@ int launch_gemm(hipStream_t s, const GemmArgs& g) {
     const bool conv = g.taps > 1;
     // bf16x3 split route (gemm_split.hip).  The choice depends on the WEIGHT's shape only, never on m: a clip must give
     // bit-identical tokens and samples whether it is coded alone or inside a batch (tests: test_full_batch_properties).
-    if (g.w_img && !conv && gemm_split_eligible(g.n, g.k) && gemm_split_enabled()) return launch_gemm_split(s, g);
+    if (g.gate_yi) {
+        L3AC_REQUIRE(!conv && g.gate_stats && g.gate_in_w && g.gate_in_b && g.gate_w && g.gate_b && g.gate_frames > 0 &&
+                         g.m % g.gate_frames == 0,
+                     "gemm: incomplete gate arguments");
+    } else if (g.w_img && !conv && gemm_split_eligible(g.n, g.k) && gemm_split_enabled()) {
+        return launch_gemm_split(s, g);
+    }
     if (conv) {
         L3AC_REQUIRE(g.cin > 0 && g.cin % 4 == 0 && g.k == g.taps * g.cin && g.frames > 0 && g.m % g.frames == 0,
                      "gemm: bad implicit-conv geometry (taps=%d cin=%d k=%d frames=%lld m=%lld)", g.taps, g.cin, g.k,
@@ -359,7 +408,7 @@ int launch_gemm(hipStream_t s, const GemmArgs& g) {
         const char* e = std::getenv("L3AC_GEMM_BK");
         return e ? std::atoi(e) : 0;
     }();
-    const int bk = bk_override == 16 || bk_override == 32 ? bk_override : 16;
+    const int bk = (bk_override == 16 || bk_override == 32) && !g.gate_yi ? bk_override : 16;  // the gated kernel exists for 16 only
 #define L3AC_GEMM_LAUNCH(NT_, CONV_) (bk == 16 ? launch_one<NT_, CONV_, 16>(s, g) : launch_one<NT_, CONV_, 32>(s, g))
     if (g.epi == EPI_GEGLU) {
         L3AC_REQUIRE(g.n % 64 == 0 && !conv, "gemm: GEGLU epilogue needs interleaved 64-column tiles");

@@ -620,6 +620,28 @@ int run_up(l3ac_ctx* ctx, hipStream_t s, const UpW& w, const float* x, float* tm
     return launch_rows(s, r);
 }
 
+// EnhanceBlock + UpLayer of one decoder stage: the gate is applied inside the up conv's A staging (no pass of its own).
+// x is left untouched; tmp holds the conv output at the input rate.
+int run_enhance_up(l3ac_ctx* ctx, hipStream_t s, const EnhW& e, const UpW& w, float* x, float* tmp, float* y, int batch, int frames) {
+    if (w.cin % 16 != 0 || e.c != w.cin) {  // geometry the gated GEMM does not cover: separate passes
+        L3AC_TRY(run_enhance(ctx, s, e, x, x, batch, frames));
+        return run_up(ctx, s, w, x, tmp, y, batch, frames);
+    }
+    Workspace& ws = ctx->ws;
+    L3AC_TRY(launch_enhance_branches(s, e.t, x, batch, frames, e.c, ws.yi));
+    L3AC_TRY(launch_enhance_stats(s, ws.yi, batch, frames, ws.stats));
+    GemmArgs g{};  // gate (tconv/__init__.py:35-44) + 1x1 conv (modules.py:161)
+    g.a = x; g.lda = w.cin; g.w = w.w; g.ldw = w.cin; g.c = tmp; g.ldc = w.cout; g.m = (int64_t)batch * frames; g.n = w.cout; g.k = w.cin;
+    g.bias = w.b; g.epi = EPI_BIAS;
+    g.gate_yi = ws.yi; g.gate_stats = ws.stats; g.gate_in_w = e.in_w; g.gate_in_b = e.in_b; g.gate_w = e.gate_w; g.gate_b = e.gate_b;
+    g.gate_frames = frames;
+    L3AC_TRY(launch_gemm(s, g));
+    RowArgs r{};  // Upsample(linear) + ChannelNorm (modules.py:162-163)
+    r.x = tmp; r.y = y; r.batch = batch; r.frames_in = frames; r.frames_out = (int64_t)frames * w.scale; r.c = w.cout;
+    r.src = SRC_LERP; r.scale = w.scale; r.norm = NORM_CN; r.nw = w.nw; r.nb = w.nb; r.eps = 1e-8f;
+    return launch_rows(s, r);
+}
+
 int run_last_block(l3ac_ctx* ctx, hipStream_t s, float* x, float* audio, int batch, int frames) {
     Workspace& ws = ctx->ws;
     const int64_t rows = (int64_t)batch * frames;
@@ -751,8 +773,7 @@ int run_decoder(l3ac_ctx* ctx, hipStream_t s, int batch, int frames, float** cur
     int f = frames;
     for (int i = 0; i + 1 < c.n_dec; ++i) {
         for (const ConvUnitW& u : ctx->dec_units[i]) L3AC_TRY(conv_unit_step(ctx, s, u, cur, alt, batch, f));
-        L3AC_TRY(run_enhance(ctx, s, ctx->dec_enh[i], *cur, *cur, batch, f));
-        L3AC_TRY(run_up(ctx, s, ctx->dec_up[i], *cur, *alt, *cur, batch, f));
+        L3AC_TRY(run_enhance_up(ctx, s, ctx->dec_enh[i], ctx->dec_up[i], *cur, *alt, *cur, batch, f));
         f *= c.decode_rates[i];
     }
     return run_last_block(ctx, s, *cur, audio, batch, f);

@@ -121,6 +121,7 @@ int run_down(l3ac_ctx* ctx, hipStream_t s, const DownW& w, const float* x, float
 int run_conv_k3(l3ac_ctx* ctx, hipStream_t s, const ConvK3W& w, const float* x, float* y, int batch, int frames);
 int run_enhance(l3ac_ctx* ctx, hipStream_t s, const EnhW& w, const float* x, float* y, int batch, int frames);  // x == y ok
 int run_up(l3ac_ctx* ctx, hipStream_t s, const UpW& w, const float* x, float* tmp, float* y, int batch, int frames);
+int run_enhance_up(l3ac_ctx* ctx, hipStream_t s, const EnhW& e, const UpW& w, float* x, float* tmp, float* y, int batch, int frames);
 int run_last_block(l3ac_ctx* ctx, hipStream_t s, float* x, float* audio, int batch, int frames);  // x is clobbered
 int run_local_trans(l3ac_ctx* ctx, hipStream_t s, const LocalTransW& w, float* x, int batch, int frames);  // in place
 
