@@ -20,9 +20,19 @@ namespace {
 constexpr int THREADS = 256;
 constexpr int MAX_CH = 2;  // chunks per lane
 
-__device__ __forceinline__ float group_sum(float v, int lpr) {
-    for (int mask = lpr >> 1; mask > 0; mask >>= 1) v += __shfl_xor(v, mask, 64);
-    return v;
+// sum over the lpr consecutive lanes of a row's group (pos = lane index inside the group).  Power-of-two groups use
+// the xor butterfly; other sizes (6 / 12 lanes for 24 / 48 / 96 channels: five or ten rows per wave instead of padding
+// every group to 8 / 16 lanes) a segmented shift-down reduction followed by a broadcast from the group's first lane.
+__device__ __forceinline__ float group_sum(float v, int lpr, int pos) {
+    if ((lpr & (lpr - 1)) == 0) {
+        for (int mask = lpr >> 1; mask > 0; mask >>= 1) v += __shfl_xor(v, mask, 64);
+        return v;
+    }
+    for (int d = 1; d < lpr; d <<= 1) {
+        const float o = __shfl_down(v, d, 64);
+        v += pos + d < lpr ? o : 0.f;
+    }
+    return __shfl(v, (int)(threadIdx.x & 63) - pos, 64);
 }
 
 __device__ __forceinline__ float4 f4_fma(float4 a, float4 b, float4 c) {
@@ -31,14 +41,18 @@ __device__ __forceinline__ float4 f4_fma(float4 a, float4 b, float4 c) {
 
 template <int SRC, int NORM>
 __global__ __launch_bounds__(THREADS) void row_kernel(const RowArgs p, const int lpr) {
-    const int groups_per_block = THREADS / lpr;
-    const int j = threadIdx.x % lpr;
+    // lane groups never straddle a wave: 64 / lpr groups per wave, the remaining lanes (4 of 64 for lpr = 6 / 12) idle
+    const int gpw = 64 / lpr;
+    const int lane = threadIdx.x & 63;
+    const int grp = lane / lpr;
+    const int j = lane - grp * lpr;
     const int64_t rows = p.batch * p.frames_out;
     const int nchunk = p.c >> 2;
+    const int64_t wave_id = (int64_t)blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6);
+    const int64_t row_step = (int64_t)gridDim.x * (THREADS / 64) * gpw;
     // grid-stride over rows: a block handles many (a launch of one 96-B row per lane group is dispatch-bound); whole lane
     // groups enter and leave the loop together, so the group shuffles stay inside active lanes
-    for (int64_t row = (int64_t)blockIdx.x * groups_per_block + threadIdx.x / lpr; row < rows;
-         row += (int64_t)gridDim.x * groups_per_block) {
+    for (int64_t row = grp < gpw ? wave_id * gpw + grp : rows; row < rows; row += row_step) {
     const bool row_ok = true;
     const int64_t b = row / p.frames_out;
     const int64_t t = row % p.frames_out;
@@ -111,7 +125,7 @@ __global__ __launch_bounds__(THREADS) void row_kernel(const RowArgs p, const int
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < MAX_CH; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);  // masked chunks hold zeros
-        const float mean = group_sum(s, lpr) / (float)p.c;
+        const float mean = group_sum(s, lpr, j) / (float)p.c;
         float q = 0.f;
 #pragma unroll
         for (int i = 0; i < MAX_CH; ++i) {
@@ -120,7 +134,7 @@ __global__ __launch_bounds__(THREADS) void row_kernel(const RowArgs p, const int
                 q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
             }
         }
-        const float var = group_sum(q, lpr) / (float)p.c;
+        const float var = group_sum(q, lpr, j) / (float)p.c;
         // LN: (x - mu) * rstd (F.layer_norm).  CN: the reference divides by sqrt(var + eps) (layers.py:54); one reciprocal
         // per row + a multiply per element differs from the per-element division by at most ~1 ulp
         const float rstd = 1.0f / sqrtf(var + p.eps);
@@ -209,7 +223,7 @@ __global__ __launch_bounds__(THREADS) void dwconv_ln_kernel(const RowArgs p, con
                 v[i] = ok[i] ? acc : make_float4(0.f, 0.f, 0.f, 0.f);
                 s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
             }
-            const float mean = group_sum(s, lpr) / (float)p.c;
+            const float mean = group_sum(s, lpr, j) / (float)p.c;
             float q = 0.f;
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
@@ -218,7 +232,7 @@ __global__ __launch_bounds__(THREADS) void dwconv_ln_kernel(const RowArgs p, con
                     q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
                 }
             }
-            const float rstd = 1.0f / sqrtf(group_sum(q, lpr) / (float)p.c + p.eps);
+            const float rstd = 1.0f / sqrtf(group_sum(q, lpr, j) / (float)p.c + p.eps);
             if (t < frames) {
 #pragma unroll
                 for (int i = 0; i < CH; ++i) {
@@ -254,7 +268,7 @@ int launch_dwconv_ln(hipStream_t s, const RowArgs& r, int lpr) {
 template <int SRC, int NORM>
 int launch_rows_t(hipStream_t s, const RowArgs& r, int lpr) {
     const int64_t rows = r.batch * r.frames_out;
-    int64_t blocks = ceil_div64(rows, THREADS / lpr);
+    int64_t blocks = ceil_div64(rows, (THREADS / 64) * (64 / lpr));
     if (blocks <= 0) return L3AC_OK;
     // the kernel strides over rows; measured: the upsample (many short output rows per input row, 2.3 -> 2.7 TB/s) gains from
     // fewer, longer-lived blocks, the 1:1 variants do not
@@ -373,15 +387,20 @@ inline unsigned stream_grid(int64_t work_items) {
 
 int launch_rows(hipStream_t s, const RowArgs& r) {
     L3AC_REQUIRE(r.x && r.y && r.c > 0 && r.c % 4 == 0, "rows: bad arguments (c=%d)", r.c);
-    int lpr = 1;
-    while (lpr * 4 < r.c && lpr < 64) lpr <<= 1;
-    L3AC_REQUIRE(r.c <= 4 * lpr * MAX_CH, "rows: c=%d too wide for the row kernel", r.c);
+    // lanes per row: the 16-B chunks of a row, two per lane once that keeps more lanes of a wave busy (24 chunks: 12 lanes
+    // x 5 rows instead of 24 x 2) or when the row is wider than a wave
+    const int nchunk = r.c / 4;
+    int lpr = nchunk <= 64 ? nchunk : 64;
+    if (nchunk > 16 && nchunk % 2 == 0 && (64 / (nchunk / 2)) * (nchunk / 2) > (64 / lpr) * lpr) lpr = nchunk / 2;
+    while (lpr * MAX_CH < nchunk) ++lpr;  // (very wide rows)
+    L3AC_REQUIRE(lpr <= 64 && r.c <= 4 * lpr * MAX_CH, "rows: c=%d too wide for the row kernel", r.c);
+    const int lpr_pow2 = [&] { int v = 1; while (v * 4 < r.c && v < 64) v <<= 1; return v; }();  // dwconv_ln_kernel's grouping
     if (r.norm != NORM_NONE) L3AC_REQUIRE(r.nw && r.nb, "rows: norm without affine parameters");
 #define L3AC_ROWS_CASE(S, N) \
     if (r.src == S && r.norm == N) return launch_rows_t<S, N>(s, r, lpr)
     L3AC_ROWS_CASE(SRC_PLAIN, NORM_LN);
     L3AC_ROWS_CASE(SRC_PLAIN, NORM_CN);
-    if (r.src == SRC_DWCONV7 && r.norm == NORM_LN && r.frames_in == r.frames_out) return launch_dwconv_ln(s, r, lpr);
+    if (r.src == SRC_DWCONV7 && r.norm == NORM_LN && r.frames_in == r.frames_out) return launch_dwconv_ln(s, r, lpr_pow2);
     L3AC_ROWS_CASE(SRC_DWCONV7, NORM_LN);
     L3AC_ROWS_CASE(SRC_LERP, NORM_NONE);
     L3AC_ROWS_CASE(SRC_LERP, NORM_CN);
