@@ -30,6 +30,7 @@ SOURCES = [
     "kernels/attention.hip",
     "kernels/fsq.hip",
     "kernels/conv_unit_fused.hip",
+    "kernels/conv_unit_split.hip",
     "kernels/last_block.hip",
     "kernels/bitpack.hip",
 ]

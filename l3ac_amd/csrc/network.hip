@@ -370,6 +370,15 @@ int network_build(l3ac_ctx* ctx, const l3ac_tensor* tensors, int n_tensors) {
             l.b2 = b.copy(p + ".3.bias", cl);
             ctx->legacy.push_back(l);
         }
+        if (b.err.empty()) {  // (the unit vectors no longer reallocate: the image targets stay valid)
+            for (auto* stages : {&ctx->enc_units, &ctx->dec_units})
+                for (auto& stage : *stages)
+                    for (ConvUnitW& u : stage)
+                        if (conv_unit_fused_supported(u.c)) {
+                            b.extra_imgs.push_back({conv_unit_w1_image(b.host_of(u.w1), u.c), &u.w1_img});
+                            b.extra_imgs.push_back({conv_unit_w2_image(b.host_of(u.w2), u.c), &u.w2_img});
+                        }
+        }
         if (b.err.empty() && last_block_fused_supported(cl, 9)) {  // (ctx->legacy no longer reallocates: the targets stay valid)
             for (LegacyW& l : ctx->legacy) {
                 b.extra_imgs.push_back({legacy_w1_image(b.host_of(l.w1), cl), &l.w1_img});
