@@ -59,7 +59,7 @@ struct SGeo {
 __device__ __forceinline__ int rowmap(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 
 template <int C, int WAVES, int HC, int XH>
-__global__ __launch_bounds__(64 * WAVES) void conv_unit_split_kernel(const ConvUnitW w, const float* __restrict__ x,
+__global__ __launch_bounds__(64 * WAVES, 2) void conv_unit_split_kernel(const ConvUnitW w, const float* __restrict__ x,
                                                                     float* __restrict__ y, int batch, int frames) {
     using G = SGeo<C, HC, XH>;
     constexpr bool RESIDENT = G::NCH == 1;
@@ -264,20 +264,27 @@ __global__ __launch_bounds__(64 * WAVES) void conv_unit_split_kernel(const ConvU
                 load_chunk(chunk + 1 < G::NCH ? chunk + 1 : 0);
             }
             const int n_base = chunk * HC;
-#pragma unroll 1
-            for (int ntl = 0; ntl < G::NTC; ++ntl) {
-                // X^T[n][m] = b1[n] + sum_k W1[n][k] a[m][k]
-                f32x16_t xacc;
+            // X^T[n][m] = b1[n] + sum_k W1[n][k] a[m][k] for hidden tile ntl of this chunk
+            auto first_product = [&](int ntl) __attribute__((always_inline)) -> f32x16_t {
+                f32x16_t acc;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) xacc[r] = B1s[n_base + 32 * ntl + rowmap(r, lh)];
+                for (int r = 0; r < 16; ++r) acc[r] = B1s[n_base + 32 * ntl + rowmap(r, lh)];
                 const unsigned char* w1p = wb + ntl * G::W1_TILE + w1_lane;
 #pragma unroll
                 for (int s = 0; s < G::NS1; ++s) {
                     bf16x8 wf[3];
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl) wf[pl] = *reinterpret_cast<const bf16x8*>(w1p + (s * 3 + pl) * 1024);
-                    xacc = mfma_split(wf, ap[s], xacc);
+                    acc = mfma_split(wf, ap[s], acc);
                 }
+                return acc;
+            };
+            // software pipeline inside a chunk: tile ntl+1's first product (MFMA pipe) beside tile ntl's activation (VALU)
+            f32x16_t xnext = first_product(0);
+#pragma unroll 1
+            for (int ntl = 0; ntl < G::NTC; ++ntl) {
+                f32x16_t xacc = xnext;
+                if (G::NTC > 1 && ntl + 1 < G::NTC) xnext = first_product(ntl + 1);
                 // snake + GRN (normaliser == 1) on the accumulator registers (layers.py:29-33, :112-115)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
