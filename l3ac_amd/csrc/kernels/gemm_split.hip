@@ -73,7 +73,7 @@ __global__ void split_image_kernel(const float* __restrict__ w, int64_t ldw, int
 // KTAIL: k % 32 != 0 (k % 8 == 0): the last tile's out-of-range 8-value groups re-read the row's last valid group —
 // finite numbers that meet the image's zero padding
 template <bool KTAIL>
-__global__ __launch_bounds__(THREADS, 3) void gemm_split_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(THREADS, 3) void gemm_split_kernel(const GemmArgs p, const int gp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_split[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -82,10 +82,11 @@ __global__ __launch_bounds__(THREADS, 3) void gemm_split_kernel(const GemmArgs p
     // XCD-aware tile order (gemm_f32.hip): all column tiles of one A row panel run on one XCD
     const int n_blocks = (p.n + BN - 1) / BN;
     const int64_t m_panels = (p.m + BM - 1) / BM;
-    const int64_t group = blockIdx.x / (8 * n_blocks);
-    const int64_t in_group = blockIdx.x % (8 * n_blocks);
-    const int64_t panels_here = (group * 8 + 8 <= m_panels) ? 8 : m_panels - group * 8;
-    const int64_t m0 = (group * 8 + in_group % panels_here) * BM;
+    const int GP = gp;  // row panels per group (a multiple of the 8 XCDs)
+    const int64_t group = blockIdx.x / (GP * n_blocks);
+    const int64_t in_group = blockIdx.x % (GP * n_blocks);
+    const int64_t panels_here = (group * GP + GP <= m_panels) ? GP : m_panels - group * GP;
+    const int64_t m0 = (group * GP + in_group % panels_here) * BM;
     const int n0 = (int)(in_group / panels_here) * BN;
     const int n_tiles = (p.k + BK - 1) / BK;
     const int last = n_tiles - 1;
@@ -245,10 +246,15 @@ int launch_gemm_split(hipStream_t s, const GemmArgs& g) {
     const double c_cols = g.epi == EPI_GEGLU ? (double)g.ldc : (double)g.n;
     ProfScope prof(s, name, 2.0 * (double)g.m * g.n * g.k,
                    4.0 * ((double)g.m * g.k + (double)g.m * c_cols * (g.epi == EPI_BIAS_RES ? 2.0 : 1.0)) + 6.0 * (double)g.n * g.k);
+    static const int gp_env = [] {
+        const char* e = std::getenv("L3AC_SPLIT_GP");
+        return e ? std::atoi(e) : 0;
+    }();
+    const int gp = gp_env > 0 ? gp_env : 8;
     if (g.k % BK == 0)
-        hipLaunchKernelGGL((gemm_split_kernel<false>), dim3((unsigned)blocks), dim3(THREADS), 2 * W_TILE, s, g);
+        hipLaunchKernelGGL((gemm_split_kernel<false>), dim3((unsigned)blocks), dim3(THREADS), 2 * W_TILE, s, g, gp);
     else
-        hipLaunchKernelGGL((gemm_split_kernel<true>), dim3((unsigned)blocks), dim3(THREADS), 2 * W_TILE, s, g);
+        hipLaunchKernelGGL((gemm_split_kernel<true>), dim3((unsigned)blocks), dim3(THREADS), 2 * W_TILE, s, g, gp);
     L3AC_LAUNCH_CHECK();
     return L3AC_OK;
 }
