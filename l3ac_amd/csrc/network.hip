@@ -581,8 +581,39 @@ static int run_conv_unit_rows(l3ac_ctx* ctx, hipStream_t s, const ConvUnitW& w, 
     return launch_gemm(s, g2);
 }
 
+static int conv_unit_group(const l3ac_ctx* ctx, const ConvUnitW& w, int batch, int frames);
+
+// All ConvUnits of one stage.  Wide (unfused) units run in place, so the clip-group loop can sit OUTSIDE the units: a
+// group's activations then stay in the Infinity Cache from one unit to the next as well.
+int run_conv_units(l3ac_ctx* ctx, hipStream_t s, const std::vector<ConvUnitW>& units, float** cur, float** alt, int batch,
+                   int frames) {
+    if (units.empty()) return L3AC_OK;
+    const bool fused = !ctx->cfg.grn_exact && conv_unit_fused_supported(units[0].c);
+    if (fused || units.size() == 1) {
+        for (const ConvUnitW& u : units) L3AC_TRY(conv_unit_step(ctx, s, u, cur, alt, batch, frames));
+        return L3AC_OK;
+    }
+    const int group = conv_unit_group(ctx, units[0], batch, frames);
+    for (int b0 = 0; b0 < batch; b0 += group) {
+        const int nb = std::min(group, batch - b0);
+        float* xg = *cur + (int64_t)b0 * frames * units[0].c;
+        for (const ConvUnitW& u : units) L3AC_TRY(run_conv_unit_rows(ctx, s, u, xg, xg, nb, frames));
+    }
+    return L3AC_OK;
+}
+
 int run_conv_unit(l3ac_ctx* ctx, hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames) {
     if (!ctx->cfg.grn_exact && x != y && conv_unit_fused_supported(w.c)) return launch_conv_unit_fused(s, w, x, y, batch, frames);
+    const int group = conv_unit_group(ctx, w, batch, frames);
+    for (int b0 = 0; b0 < batch; b0 += group) {
+        const int nb = std::min(group, batch - b0);
+        const int64_t off = (int64_t)b0 * frames * w.c;
+        L3AC_TRY(run_conv_unit_rows(ctx, s, w, x + off, y + off, nb, frames));
+    }
+    return L3AC_OK;
+}
+
+static int conv_unit_group(const l3ac_ctx* ctx, const ConvUnitW& w, int batch, int frames) {
     // Clips are independent, so the unit can run over groups of clips whose hidden tensor (4C floats per frame) stays in the
     // 256 MB Infinity Cache between the two products instead of making an HBM round trip (measured, 1kbps x 256: 19.15 ->
     // 18.65 ms per step at 192 MB; 96 MB and below lose more to the smaller launches than they save).  L3AC_UNIT_CHUNK_MB
@@ -594,12 +625,7 @@ int run_conv_unit(l3ac_ctx* ctx, hipStream_t s, const ConvUnitW& w, const float*
     const int64_t per_clip = (int64_t)frames * 4 * w.c * sizeof(float);
     int group = batch;
     if (chunk_mb > 0 && !ctx->cfg.grn_exact) group = (int)std::max<int64_t>(1, std::min<int64_t>(batch, (chunk_mb << 20) / per_clip));
-    for (int b0 = 0; b0 < batch; b0 += group) {
-        const int nb = std::min(group, batch - b0);
-        const int64_t off = (int64_t)b0 * frames * w.c;
-        L3AC_TRY(run_conv_unit_rows(ctx, s, w, x + off, y + off, nb, frames));
-    }
-    return L3AC_OK;
+    return group;
 }
 
 int run_down(l3ac_ctx* ctx, hipStream_t s, const DownW& w, const float* x, float* y, int batch, int frames) {
@@ -753,7 +779,7 @@ int run_encoder(l3ac_ctx* ctx, hipStream_t s, const float* audio, int64_t audio_
     L3AC_TRY(launch_first_block(s, ctx->first, audio, audio_stride, batch, samples, frames, *cur));
     int f = frames;
     for (int i = 0; i < c.n_enc; ++i) {
-        for (const ConvUnitW& u : ctx->enc_units[i]) L3AC_TRY(conv_unit_step(ctx, s, u, cur, alt, batch, f));
+        L3AC_TRY(run_conv_units(ctx, s, ctx->enc_units[i], cur, alt, batch, f));
         if (i + 1 < c.n_enc) {
             L3AC_TRY(run_down(ctx, s, ctx->enc_down[i], *cur, *alt, batch, f));
             swap_bufs(cur, alt);
@@ -803,7 +829,7 @@ int run_decoder(l3ac_ctx* ctx, hipStream_t s, int batch, int frames, float** cur
     swap_bufs(cur, alt);
     int f = frames;
     for (int i = 0; i + 1 < c.n_dec; ++i) {
-        for (const ConvUnitW& u : ctx->dec_units[i]) L3AC_TRY(conv_unit_step(ctx, s, u, cur, alt, batch, f));
+        L3AC_TRY(run_conv_units(ctx, s, ctx->dec_units[i], cur, alt, batch, f));
         L3AC_TRY(run_enhance_up(ctx, s, ctx->dec_enh[i], ctx->dec_up[i], *cur, *alt, *cur, batch, f));
         f *= c.decode_rates[i];
     }

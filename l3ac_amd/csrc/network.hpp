@@ -120,6 +120,8 @@ int launch_legacy_unit_fused(hipStream_t s, const LegacyW& w, const float* x, fl
 int launch_head_fused(hipStream_t s, const HeadW& w, const float* x, int batch, int frames, float* audio);
 // one ConvUnit of a stage on the ping-pong buffers: fused kernel (result in *alt, buffers swapped) or in place
 int conv_unit_step(l3ac_ctx* ctx, hipStream_t s, const ConvUnitW& w, float** cur, float** alt, int batch, int frames);
+// all ConvUnits of one stage (wide units: clip groups outside the units, see network.hip)
+int run_conv_units(l3ac_ctx* ctx, hipStream_t s, const std::vector<ConvUnitW>& units, float** cur, float** alt, int batch, int frames);
 
 // blocks (x may alias y where noted)
 int run_conv_unit(l3ac_ctx* ctx, hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames);  // x == y ok
