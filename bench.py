@@ -121,17 +121,34 @@ def main():
     audio = ((torch.rand(b, samples, generator=g) * 2 - 1) * 0.5).to(dev)
     codec.network.context().reserve(b, samples)
     n_tok = -(-samples // mc.hop_length)
-    gather = world > 1 and not args.no_gather
-    from l3ac_amd.dist import gather_batch
+    force_dist = world == 1 and os.environ.get("L3AC_BENCH_FORCE_DIST") == "1"  # test hook: 1-rank RCCL collectives
+    if force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+    gather = (world > 1 or force_dist) and not args.no_gather
+    from l3ac_amd.dist import gather_batch_async
+
+    pending = []  # all-gathers of the previous step, still in flight on RCCL's stream
 
     def step():
         q, ind = codec.encode_audio(audio)
         wave = codec.decode_audio(q)
-        if gather:  # the only exchange step of the path: outputs to every rank over xGMI
-            all_idx = gather_batch(ind["indices"], world * b)
-            all_wave = gather_batch(wave, world * b)
-            return {"indices": all_idx[rank * b:(rank + 1) * b]}, all_wave
+        if gather:
+            # the only exchange step of the path: outputs to every rank over xGMI.  The collectives are queued behind this
+            # step's kernels and overlap the NEXT step's encode; each step retires the previous step's pair.
+            now = (gather_batch_async(ind["indices"], world * b, force=force_dist),
+                   gather_batch_async(wave, world * b, force=force_dist))
+            while pending:
+                for h in pending.pop():
+                    h.wait()
+            pending.append(now)
         return ind, wave
+
+    def drain():
+        while pending:
+            for h in pending.pop():
+                h.wait()
 
     run = step
     if args.graph:
@@ -151,12 +168,14 @@ def main():
     fsq_line = fsq_microbench(codec, dev) if rank == 0 and not args.pipeline_only else None
     for _ in range(args.warmup):
         run()
+    drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ind, wave = run()
+    drain()  # the last step's gathers are part of the timed work
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -222,7 +241,7 @@ def main():
                            "all other products use v_mfma_f32_32x32x2_f32") if l3ac_amd.get_gemm_split() else
                           "fp32 everywhere: every product on v_mfma_f32_32x32x2_f32 (--gemm exact)",
             "config": {"workload": f"{args.config} config, {b} x {args.seconds:g} s 16 kHz clips per GPU, "
-                                   "encode_audio + decode_audio(q_feature)" + (", RCCL all-gather of indices+waveforms" if gather else ""),
+                                   "encode_audio + decode_audio(q_feature)" + (", RCCL all-gather of indices+waveforms (overlapping the next step)" if gather else ""),
                        "batch_per_gpu": b, "samples_per_clip": samples, "weights": "seeded synthetic (seed 0)",
                        "hipgraph": bool(args.graph)},
             "roofline": roof,
@@ -253,9 +272,15 @@ def main():
         out["fsq_kernel"] = fsq_line
         if not args.no_cpu_baseline and not args.pipeline_only:
             out["cpu_baseline"] = cpu_baseline(codec, audio, args.cpu_batch, ind, args.cpu_threads)
+        try:  # RCCL writes a version banner through C stdio: flush it first so that the JSON line is the last line of stdout
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

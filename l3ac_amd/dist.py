@@ -51,6 +51,35 @@ def gather_batch(local: torch.Tensor, total: int, group=None) -> torch.Tensor:
     return torch.cat(parts, dim=0)
 
 
+class PendingGather:
+    """Handle of an all-gather in flight on the process group's own stream (RCCL runs it beside the compute stream).
+    `wait()` makes the CURRENT stream wait for it and returns the gathered tensor; the shard stays referenced until then."""
+
+    def __init__(self, out: torch.Tensor, work=None, keep=None):
+        self.out, self.work, self.keep = out, work, keep
+
+    def wait(self) -> torch.Tensor:
+        if self.work is not None:
+            self.work.wait()
+            self.work = self.keep = None
+        return self.out
+
+
+def gather_batch_async(local: torch.Tensor, total: int, group=None, force: bool = False) -> PendingGather:
+    """`gather_batch` without blocking the compute stream: the collective is queued behind the work already on the current
+    stream and runs concurrently with whatever is launched next (e.g. the next batch's encode).  Equal shards only; ragged
+    batches fall back to the blocking path.  `force` issues the collective even in a world of one (tests)."""
+    world = dist.get_world_size(group)
+    if world == 1 and not force:
+        return PendingGather(local)
+    if total % world:
+        return PendingGather(gather_batch(local, total, group))
+    src = local.contiguous()
+    out = torch.empty((total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    work = dist.all_gather_into_tensor(out, src, group=group, async_op=True)
+    return PendingGather(out, work, src)
+
+
 class ShardedCodec:
     """Runs a codec (anything with `encode_audio` / `decode_audio`, e.g. `l3ac_amd.L3AC`) on this rank's slice of a
     batch that every rank holds, and returns the gathered full-batch outputs on every rank."""

@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from l3ac_amd.dist import ShardedCodec, gather_batch, shard_range
+from l3ac_amd.dist import ShardedCodec, gather_batch, gather_batch_async, shard_range
 
 
 def test_shard_ranges_partition_the_batch():
@@ -56,6 +56,11 @@ def _worker(rank, world, port, total, queue):
         start, stop = shard_range(total, rank, world)
         full = torch.arange(total * 3, dtype=torch.float32).reshape(total, 3)
         ok = ok and torch.equal(gather_batch(full[start:stop], total), full)
+        # non-blocking variant (what bench.py overlaps with the next step): two in flight, retired out of order
+        h1 = gather_batch_async(full[start:stop], total)
+        h2 = gather_batch_async((full * 2)[start:stop].to(torch.int64), total)
+        ok = ok and torch.equal(h2.wait(), (full * 2).to(torch.int64)) and torch.equal(h1.wait(), full)
+        ok = ok and torch.equal(h1.wait(), full)  # waiting twice is harmless
         queue.put((rank, bool(ok), tuple(idx.shape), tuple(wave.shape)))
     finally:
         dist.destroy_process_group()
