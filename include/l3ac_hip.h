@@ -146,6 +146,10 @@ int l3ac_op_enhance(l3ac_ctx* ctx, const char* block, const float* x, int32_t ba
                     void* stream);
 int l3ac_op_up_layer(l3ac_ctx* ctx, const char* block, const float* x, int32_t batch, int32_t frames, float* y,
                      void* stream);
+/* EnhanceBlock + up layer as the decoder pipeline runs them (the gate is applied to the 1x1 conv's A operand while it is
+ * staged, tconv/__init__.py:35-44 + modules.py:160-164): y [batch][frames * scale][cout] */
+int l3ac_op_enhance_up(l3ac_ctx* ctx, const char* enhance_block, const char* up_block, const float* x, int32_t batch,
+                       int32_t frames, float* y, void* stream);
 int l3ac_op_last_block(l3ac_ctx* ctx, const float* x, int32_t batch, int32_t frames, float* audio, void* stream);
 int l3ac_op_local_trans(l3ac_ctx* ctx, const char* block, const float* x, int32_t batch, int32_t frames, float* y,
                         void* stream);

@@ -61,6 +61,7 @@ SIGNATURES = {
     "l3ac_op_conv_k3": (C.c_int, [_P, C.c_char_p, _P, _I32, _I32, _P, _P]),
     "l3ac_op_enhance": (C.c_int, [_P, C.c_char_p, _P, _I32, _I32, _P, _P]),
     "l3ac_op_up_layer": (C.c_int, [_P, C.c_char_p, _P, _I32, _I32, _P, _P]),
+    "l3ac_op_enhance_up": (C.c_int, [_P, C.c_char_p, C.c_char_p, _P, _I32, _I32, _P, _P]),
     "l3ac_op_last_block": (C.c_int, [_P, _P, _I32, _I32, _P, _P]),
     "l3ac_op_local_trans": (C.c_int, [_P, C.c_char_p, _P, _I32, _I32, _P, _P]),
     "l3ac_op_encoder": (C.c_int, [_P, _P, _I32, _I32, _P, _P]),

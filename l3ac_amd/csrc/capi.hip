@@ -241,6 +241,18 @@ int l3ac_op_up_layer(l3ac_ctx* ctx, const char* block, const float* x, int32_t b
     return run_up(ctx, (hipStream_t)stream, *w, x, ctx->ws.a, y, batch, frames);
 }
 
+int l3ac_op_enhance_up(l3ac_ctx* ctx, const char* enhance_block, const char* up_block, const float* x, int32_t batch, int32_t frames,
+                       float* y, void* stream) {
+    L3AC_ENTER(ctx);
+    const EnhW* e = lookup(ctx->by_enh, enhance_block, "EnhanceBlock");
+    const UpW* w = lookup(ctx->by_up, up_block, "up-layer");
+    if (!e || !w) return L3AC_EINVAL;
+    L3AC_REQUIRE(e->c == w->cin, "enhance_up: blocks of different widths (%d vs %d)", e->c, w->cin);
+    L3AC_OP_SCRATCH(w->cin > w->cout ? w->cin : w->cout);
+    // the pipeline's fused form: gate applied inside the up conv's A staging; x is only read
+    return run_enhance_up(ctx, (hipStream_t)stream, *e, *w, const_cast<float*>(x), ctx->ws.a, y, batch, frames);
+}
+
 int l3ac_op_last_block(l3ac_ctx* ctx, const float* x, int32_t batch, int32_t frames, float* audio, void* stream) {
     L3AC_ENTER(ctx);
     const int c = ctx->head.c;

@@ -28,6 +28,15 @@ def op_block(ctx, fn_name, block, x_btc, out_shape):
     return y
 
 
+def op_block2(ctx, fn_name, block_a, block_b, x_btc, out_shape):
+    y = torch.empty(out_shape, dtype=torch.float32, device=x_btc.device)
+    b, frames = x_btc.shape[0], x_btc.shape[1]
+    fn = getattr(ctx.lib, fn_name)
+    _capi.check(fn(ctx.handle, block_a.encode(), block_b.encode(), x_btc.data_ptr(), b, frames, y.data_ptr(), _stream(x_btc.device)))
+    torch.cuda.synchronize()
+    return y
+
+
 def op_plain(ctx, fn_name, x, d1, d2, out_shape, out_dtype=torch.float32):
     y = torch.empty(out_shape, dtype=out_dtype, device=x.device)
     fn = getattr(ctx.lib, fn_name)

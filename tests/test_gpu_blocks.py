@@ -143,6 +143,12 @@ def test_enhance_and_up_layers(tiny, full):
             r = O.channel_norm_first(r, w[f"{ub}.2.weight"], w[f"{ub}.2.bias"])
             got = G.op_block(codec.network.context(), "l3ac_op_up_layer", ub, G.to_frames(x), (2, t * s, co))
             _close(ub, G.from_frames(got), r)
+            # the pipeline's fused pair: gate folded into the up conv's A operand
+            r = F.conv1d(ref, w[f"{ub}.0.weight"], w[f"{ub}.0.bias"])
+            r = F.interpolate(r, scale_factor=s, mode="linear", align_corners=False)
+            r = O.channel_norm_first(r, w[f"{ub}.2.weight"], w[f"{ub}.2.bias"])
+            got = G.op_block2(codec.network.context(), "l3ac_op_enhance_up", eb, ub, G.to_frames(x), (2, t * s, co))
+            _close(eb + "+" + ub, G.from_frames(got), r)
 
 
 def test_last_block(tiny, full):
