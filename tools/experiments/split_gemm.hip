@@ -526,6 +526,156 @@ float run_unused(const float* a, const uint16_t* wp, float* c, int64_t m, int n,
     return ms / iters;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// v5: k tile of 16 (one MFMA k step per barrier), W by LDS-DMA through THREE 12-KB stages two tiles ahead, 128 VGPRs ->
+// four blocks (16 waves) per CU.  Image: [n/128][k/16][plane][128 rows x 32 B], 16-B chunk c of row r stored at
+// c ^ ((r >> 3) & 1) (conflict-free b128 reads of 16 consecutive rows).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int V5_PLANE = 128 * 32;
+constexpr int V5_STAGE = 3 * V5_PLANE;  // 12 KB
+__device__ __host__ __forceinline__ int v5_off(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 3) & 1)) << 4); }
+
+__global__ void split_tiles16_kernel(const float* __restrict__ w, unsigned char* __restrict__ img, int n, int k) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 16-B chunk (8 k values of one row)
+    const int chunks_per_row = k / 8;
+    if (i >= (int64_t)n * chunks_per_row) return;
+    const int row = (int)(i / chunks_per_row), kc = (int)(i % chunks_per_row);
+    const float* src = w + (int64_t)row * k + 8 * kc;
+    unsigned p[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split2(src[2 * j], src[2 * j + 1], p[0][j], p[1][j], p[2][j]);
+    const int nb = row / 128, r = row % 128, kt = kc / 2, ch = kc % 2;
+    unsigned char* tile = img + ((int64_t)nb * (k / 16) + kt) * V5_STAGE;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+        *reinterpret_cast<u32x4*>(tile + pl * V5_PLANE + v5_off(r, ch)) = u32x4{p[pl][0], p[pl][1], p[pl][2], p[pl][3]};
+}
+
+#ifndef V5_OCC
+#define V5_OCC 4
+#endif
+__global__ __launch_bounds__(256, V5_OCC) void split_gemm_v5_kernel(const float* __restrict__ a, const unsigned char* __restrict__ wimg,
+                                                                  float* __restrict__ c, int64_t m, int n, int k) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_blocks = n / 128;
+    const int64_t m_panels = m / 128;
+    const int64_t group = blockIdx.x / (8 * n_blocks);
+    const int64_t in_group = blockIdx.x % (8 * n_blocks);
+    const int64_t panels_here = (group * 8 + 8 <= m_panels) ? 8 : m_panels - group * 8;
+    const int64_t m0 = (group * 8 + in_group % panels_here) * 128;
+    const int n0 = (int)(in_group / panels_here) * 128;
+    const int li = lane & 31, lh = lane >> 5;
+    const int n_tiles = k / 16;
+    const int last = n_tiles - 1;
+
+    const float* a_src = a + (m0 + 32 * wave + li) * k + 8 * lh;
+    // this wave's 3 KB slice of every 12-KB tile image
+    const unsigned char* w_src = wimg + (int64_t)(n0 / 128) * n_tiles * V5_STAGE + 3072 * wave + 16 * lane;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    auto dma16 = [&](const unsigned char* src, unsigned lds_byte) __attribute__((always_inline)) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(src), "s"(lds_byte)
+                     : "memory");
+    };
+    auto dma_w = [&](int kt, int stage) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            dma16(w_src + (int64_t)kt * V5_STAGE + 1024 * i,
+                  __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(stage * V5_STAGE + 3072 * wave + 1024 * i)));
+    };
+    float4 a_pre[2][2];
+    auto load_a = [&](int kt, float4 (&dst)[2]) __attribute__((always_inline)) {
+        const float* src = a_src + kt * 16;
+        dst[0] = *reinterpret_cast<const float4*>(src);
+        dst[1] = *reinterpret_cast<const float4*>(src + 4);
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    // prologue: W(0), W(1) in flight to stages 0, 1; A(0), A(1) in registers
+    dma_w(0, 0);
+    load_a(0, a_pre[0]);
+    dma_w(last < 1 ? last : 1, 1);
+    load_a(last < 1 ? last : 1, a_pre[1]);
+    int stage = 0;  // kt % 3
+    auto step = [&](int kt, float4 (&cur)[2]) __attribute__((always_inline)) {
+        // own pieces of W(kt) have landed: younger in the queue are A(kt) [2], W(kt+1) [3], A(kt+1) [2]
+        asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        __syncthreads();  // everybody's pieces of W(kt) landed; everybody is done with stage (kt + 2) % 3 (read at step kt - 1)
+        const int nstage = stage == 0 ? 2 : stage - 1;  // (kt + 2) % 3
+        dma_w(kt + 2 < last ? kt + 2 : last, nstage);
+        unsigned x0, x1, x2, y0, y1, y2, z0, z1, z2, u0, u1, u2;
+        split2(cur[0].x, cur[0].y, x0, x1, x2);
+        split2(cur[0].z, cur[0].w, y0, y1, y2);
+        split2(cur[1].x, cur[1].y, z0, z1, z2);
+        split2(cur[1].z, cur[1].w, u0, u1, u2);
+        const bf16x8 a0 = __builtin_bit_cast(bf16x8, u32x4{x0, y0, z0, u0});
+        const bf16x8 a1 = __builtin_bit_cast(bf16x8, u32x4{x1, y1, z1, u1});
+        const bf16x8 a2 = __builtin_bit_cast(bf16x8, u32x4{x2, y2, z2, u2});
+        load_a(kt + 2 < last ? kt + 2 : last, cur);
+        const unsigned char* ws = smem + stage * V5_STAGE;
+        bf16x8 bq[2][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bq[0][p] = *reinterpret_cast<const bf16x8*>(ws + p * V5_PLANE + v5_off(li, lh));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j + 1 < 4) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    bq[(j + 1) & 1][p] = *reinterpret_cast<const bf16x8*>(ws + p * V5_PLANE + v5_off(32 * (j + 1) + li, lh));
+            }
+            const bf16x8 b0 = bq[j & 1][0], b1 = bq[j & 1][1], b2 = bq[j & 1][2];
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[j], 0, 0, 0);
+        }
+        stage = stage == 2 ? 0 : stage + 1;
+    };
+    for (int kt = 0; kt < n_tiles; kt += 2) {
+        step(kt, a_pre[0]);
+        if (kt + 1 < n_tiles) step(kt + 1, a_pre[1]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped tail DMAs must not outlive the workgroup's LDS
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = n0 + 32 * j + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            c[row * n + col] = acc[j][r];
+        }
+    }
+}
+
+float run_v5(const float* a, const unsigned char* wimg, float* c, int64_t m, int n, int k, int iters) {
+    const unsigned grid = (unsigned)((m / 128) * (n / 128));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(split_gemm_v5_kernel, dim3(grid), dim3(256), 3 * V5_STAGE, 0, a, wimg, c, m, n, k);
+    CHECK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(split_gemm_v5_kernel, dim3(grid), dim3(256), 3 * V5_STAGE, 0, a, wimg, c, m, n, k);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    CHECK(hipGetLastError());
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / iters;
+}
+
 int main(int argc, char** argv) {
     struct Shape { int64_t m; int n, k; };
     const Shape shapes[] = {{230400, 1024, 256}, {230400, 256, 1024}, {46080, 2048, 512}, {46080, 512, 2048}, {46080, 768, 192}};
@@ -557,9 +707,13 @@ int main(int argc, char** argv) {
             hipLaunchKernelGGL(split_tiles_kernel, dim3((unsigned)((hw.size() / 8 + 255) / 256)), dim3(256), 0, 0, dw, dimg, n, k);
             CHECK(hipDeviceSynchronize());
             const uint16_t* dimg16 = reinterpret_cast<const uint16_t*>(dimg);
-            for (int mode = 2; mode < 3; ++mode) {
+            unsigned char* dimg5;
+            CHECK(hipMalloc(&dimg5, hw.size() * 2 * 3));
+            hipLaunchKernelGGL(split_tiles16_kernel, dim3((unsigned)((hw.size() / 8 + 255) / 256)), dim3(256), 0, 0, dw, dimg5, n, k);
+            CHECK(hipDeviceSynchronize());
+            for (int mode = 2; mode < 5; mode += 2) {
                 const int iters = 10;
-                const float ms = mode == 0 ? run<0>(da, dp, dc, m, n, k, iters) : mode == 1 ? run<1>(da, dp, dc, m, n, k, iters) : mode == 2 ? run_v2<0>(da, dimg16, dc, m, n, k, iters) : run_v3<0>(da, dimg16, dc, m, n, k, iters);
+                const float ms = mode == 0 ? run<0>(da, dp, dc, m, n, k, iters) : mode == 1 ? run<1>(da, dp, dc, m, n, k, iters) : mode == 2 ? run_v2<0>(da, dimg16, dc, m, n, k, iters) : mode == 3 ? run_v3<0>(da, dimg16, dc, m, n, k, iters) : run_v5(da, dimg5, dc, m, n, k, iters);
                 // error on sampled rows
                 const int rows = 48;
                 std::vector<float> hc((size_t)n);
@@ -591,14 +745,8 @@ int main(int argc, char** argv) {
                        std::sqrt(rms_chain / cnt));
                 fflush(stdout);
             }
-            if (dist == 0) {
-                printf("   v2 diag: noA %.3f  noSplit %.3f  noBread %.3f  noW %.3f  noStore %.3f  noA+noSplit+noW+noStore %.3f  all-off %.3f ms\n",
-                       run_v2<1>(da, dimg16, dc, m, n, k, 5), run_v2<2>(da, dimg16, dc, m, n, k, 5), run_v2<4>(da, dimg16, dc, m, n, k, 5),
-                       run_v2<8>(da, dimg16, dc, m, n, k, 5), run_v2<16>(da, dimg16, dc, m, n, k, 5), run_v2<27>(da, dimg16, dc, m, n, k, 5),
-                       run_v2<31>(da, dimg16, dc, m, n, k, 5));
-                fflush(stdout);
-            }
             CHECK(hipFree(dimg));
+            CHECK(hipFree(dimg5));
             CHECK(hipFree(da));
             CHECK(hipFree(dw));
             CHECK(hipFree(dp));
