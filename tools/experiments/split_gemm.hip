@@ -7,7 +7,15 @@
 //   each) per 32x32x16 block: 2.67x fewer matrix-core cycles.
 //
 // Measures (a) error against an fp64 reference next to the k-ordered fp32 fmaf chain (= v_mfma_f32_32x32x2_f32
-// numerics), (b) throughput on the dominant L3AC GEMM shapes.
+// numerics), (b) throughput on the dominant L3AC GEMM shapes, for several kernel structures (results: DESIGN.md §3.1):
+//   mode 0/1  both operands through LDS planes (256 x 128 tile, 8 waves); 1 = low-order products in their own accumulator
+//             (3x smaller error, not needed: mode 0 is already below the fp32 chain)
+//   mode 2    "v2" = the shipped kernel: A fragments straight from global memory, split in registers; tile-ordered W image
+//             through LDS, register-staged, double-buffered; compile-time DIAG bits switch single components off
+//   mode 3    "v3" = v2 with W staged by LDS-DMA (global_load_lds_dwordx4), no staging VGPRs
+//   mode 4    "v5" = k tile of 16, three DMA-fed LDS stages, 117 VGPRs -> four blocks per CU
+//   mode 5    "v6" = v5 with 64 rows per wave (half the LDS reads / W staging per MFMA), two waves per SIMD
+// All of 2..5 land within 3 % of each other (140-150 TFLOP/s fp32-equivalent); MFMA-only (DIAG 31) reaches 296.
 //
 //   hipcc -O3 --offload-arch=gfx950 tools/experiments/split_gemm.hip -o tools/experiments/_build/split_gemm
 #include <hip/hip_runtime.h>
