@@ -51,7 +51,7 @@ def _newest_header() -> float:
 def build_library(force: bool = False, verbose: bool = False) -> Path:
     OBJ_DIR.mkdir(parents=True, exist_ok=True)
     hipcc = _hipcc()
-    flags = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-Wall", "-Wno-unused-function",
+    flags = [*os.environ.get("L3AC_EXTRA_HIPCC_FLAGS", "").split(), "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-Wall", "-Wno-unused-function",
              f"-I{REPO / 'include'}", f"-I{CSRC}"]
     hdr_time = _newest_header()
     jobs = []
