@@ -218,6 +218,10 @@ constexpr int V2_STAGE = 3 * V2_W_PLANE;
 #endif
 constexpr int V2_T = 64 * V2_WAVES, V2_BM = 32 * V2_WAVES, V2_WLD = 1536 / V2_T;  // W chunks (16 B) per thread per tile
 
+// DIAG bit 32: s_memtime stamps per wave, summed into g_stamps: [0] A wait + split + load issue, [1] MFMA loop (incl. B reads
+// and the W store), [2] barrier, [3] epilogue, [4] whole wave, [5] waves
+__device__ unsigned long long* g_stamp_buf;  // [waves][5], plain stores (atomics on one word would perturb the run)
+
 template <int DIAG>  // diagnostic bits: 1 no A loads, 2 no split math, 4 no B fragment reads, 8 no W staging, 16 no C store
 __global__ __launch_bounds__(V2_T, V2_OCC) void split_gemm_v2_kernel(const float* __restrict__ a, const uint16_t* __restrict__ wp,
                                                                float* __restrict__ c, int64_t m, int n, int k) {
@@ -262,6 +266,8 @@ __global__ __launch_bounds__(V2_T, V2_OCC) void split_gemm_v2_kernel(const float
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
+    unsigned long long t_split = 0, t_mfma = 0, t_bar = 0, t_begin = 0;
+    if (DIAG & 32) t_begin = __builtin_amdgcn_s_memtime();
     const int n_tiles = k / 32;
     load_a(0, a_pre[0]);
     if (n_tiles > 1) load_a(1, a_pre[1]);
@@ -276,6 +282,8 @@ __global__ __launch_bounds__(V2_T, V2_OCC) void split_gemm_v2_kernel(const float
     auto step = [&](int kt, float4 (&cur)[4]) __attribute__((always_inline)) {
         const int buf = kt & 1;
         const int last = n_tiles - 1;
+        unsigned long long s0 = 0, s1 = 0, s2 = 0;
+        if (DIAG & 32) s0 = __builtin_amdgcn_s_memtime();
         if (!(DIAG & 8)) load_w(kt + 1 < last ? kt + 1 : last);
         u32x4 af[2][3];
 #pragma unroll
@@ -298,6 +306,10 @@ __global__ __launch_bounds__(V2_T, V2_OCC) void split_gemm_v2_kernel(const float
         if (!(DIAG & 1)) load_a(kt + 2 < last ? kt + 2 : last, cur);  // the registers are free again: two tiles ahead
         const unsigned char* ws = smem + buf * V2_STAGE;
         bf16x8 bq[2][3];
+        if (DIAG & 32) {
+            asm volatile("" : "+v"(af[0][0]), "+v"(af[1][2]));  // the split is done before the stamp
+            s1 = __builtin_amdgcn_s_memtime();
+        }
         read_b(ws, 0, 0, bq[0]);
 #ifdef V2_PRIO
         __builtin_amdgcn_s_setprio(V2_PRIO);
@@ -322,12 +334,24 @@ __global__ __launch_bounds__(V2_T, V2_OCC) void split_gemm_v2_kernel(const float
 #ifdef V2_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
+        if (DIAG & 32) {
+            asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));  // MFMAs retired
+            s2 = __builtin_amdgcn_s_memtime();
+        }
         __syncthreads();
+        if (DIAG & 32) {
+            const unsigned long long s3 = __builtin_amdgcn_s_memtime();
+            t_split += s1 - s0;
+            t_mfma += s2 - s1;
+            t_bar += s3 - s2;
+        }
     };
     for (int kt = 0; kt < n_tiles; kt += 2) {
         step(kt, a_pre[0]);
         if (kt + 1 < n_tiles) step(kt + 1, a_pre[1]);
     }
+    unsigned long long t_epi0 = 0;
+    if (DIAG & 32) t_epi0 = __builtin_amdgcn_s_memtime();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int col = n0 + 32 * j + li;
@@ -335,6 +359,18 @@ __global__ __launch_bounds__(V2_T, V2_OCC) void split_gemm_v2_kernel(const float
         for (int r = 0; r < 16; ++r) {
             const int64_t row = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (!(DIAG & 16) || acc[j][r] == 1234.5f) c[row * n + col] = acc[j][r];
+        }
+    }
+    if (DIAG & 32) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        if (lane == 0) {
+            unsigned long long* o = g_stamp_buf + ((int64_t)blockIdx.x * V2_WAVES + wave) * 5;
+            o[0] = t_split;
+            o[1] = t_mfma;
+            o[2] = t_bar;
+            o[3] = t_end - t_epi0;
+            o[4] = t_end - t_begin;
         }
     }
 }
@@ -888,6 +924,23 @@ int main(int argc, char** argv) {
                        " | fp32 fmaf chain max %.3e rms %.3e\n",
                        (long long)m, n, k, dist, mode, ms, 2.0 * m * n * k / ms * 1e-9, max_split, std::sqrt(rms_split / cnt), max_chain,
                        std::sqrt(rms_chain / cnt));
+                fflush(stdout);
+            }
+            if (dist == 0) {
+                const size_t nw = (size_t)(m / V2_BM) * (n / 128) * V2_WAVES;
+                unsigned long long* dbuf;
+                CHECK(hipMalloc(&dbuf, nw * 5 * sizeof(unsigned long long)));
+                CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &dbuf, sizeof(dbuf)));
+                const float ms = run_v2<32>(da, dimg16, dc, m, n, k, 5);
+                std::vector<unsigned long long> hb(nw * 5);
+                CHECK(hipMemcpy(hb.data(), dbuf, hb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+                CHECK(hipFree(dbuf));
+                double st[5] = {0, 0, 0, 0, 0};
+                for (size_t i = 0; i < nw; ++i)
+                    for (int q = 0; q < 5; ++q) st[q] += (double)hb[i * 5 + q];
+                const double w = (double)nw;
+                printf("   v2 stamps (%.3f ms with stamps; cycles per wave, %d k steps): A wait+split %.0f  MFMA loop %.0f  barrier %.0f  "
+                       "epilogue %.0f  whole wave %.0f\n", ms, k / 32, st[0] / w, st[1] / w, st[2] / w, st[3] / w, st[4] / w);
                 fflush(stdout);
             }
             CHECK(hipFree(dimg));
