@@ -15,7 +15,8 @@
 //   mode 3    "v3" = v2 with W staged by LDS-DMA (global_load_lds_dwordx4), no staging VGPRs
 //   mode 4    "v5" = k tile of 16, three DMA-fed LDS stages, 117 VGPRs -> four blocks per CU
 //   mode 5    "v6" = v5 with 64 rows per wave (half the LDS reads / W staging per MFMA), two waves per SIMD
-// All of 2..5 land within 3 % of each other (140-150 TFLOP/s fp32-equivalent); MFMA-only (DIAG 31) reaches 296.
+//   mode 6    "v7" = 64 rows per wave on the shipped k-32 image (three 24-KB DMA stages, A fetched in k-16 halves)
+// All of 2..6 land within a few % of each other (140-157 TFLOP/s fp32-equivalent); MFMA-only (DIAG 31) reaches 296.
 //
 //   hipcc -O3 --offload-arch=gfx950 tools/experiments/split_gemm.hip -o tools/experiments/_build/split_gemm
 #include <hip/hip_runtime.h>
@@ -857,6 +858,147 @@ float run_v6(const float* a, const unsigned char* wimg, float* c, int64_t m, int
     return ms / iters;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// v7: 64 rows per wave (256 x 128 tile, 4 waves) on the SHIPPED k-32 W image: W by LDS-DMA through three 24-KB stages two
+// k steps ahead (one barrier per k-32 step); A fragments are fetched and split in k-16 halves one k-32 step ahead, so
+// only 32 VGPRs of raw A are live.  Same per-element operation order as v2 -> bit-identical results.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void split_gemm_v7_kernel(const float* __restrict__ a, const uint16_t* __restrict__ wp,
+                                                              float* __restrict__ c, int64_t m, int n, int k) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_blocks = n / 128;
+    const int64_t m_panels = m / 256;
+    const int64_t group = blockIdx.x / (8 * n_blocks);
+    const int64_t in_group = blockIdx.x % (8 * n_blocks);
+    const int64_t panels_here = (group * 8 + 8 <= m_panels) ? 8 : m_panels - group * 8;
+    const int64_t m0 = (group * 8 + in_group % panels_here) * 256;
+    const int n0 = (int)(in_group / panels_here) * 128;
+    const int li = lane & 31, lh = lane >> 5;
+    const int n_tiles = k / 32;
+    const int last = n_tiles - 1;
+
+    const float* a_src = a + (m0 + 64 * wave + li) * k + 8 * lh;  // row tile 1: + 32 rows
+    const unsigned char* w_src = reinterpret_cast<const unsigned char*>(wp) + (int64_t)(n0 / 128) * n_tiles * V2_STAGE + 6144 * wave + 16 * lane;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    auto dma16 = [&](const unsigned char* src, unsigned lds_byte) __attribute__((always_inline)) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(src), "s"(lds_byte)
+                     : "memory");
+    };
+    auto dma_w = [&](int kt, int stage) __attribute__((always_inline)) {  // this wave's 6 KB of the 24-KB tile
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            dma16(w_src + (int64_t)kt * V2_STAGE + 1024 * i,
+                  __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(stage * V2_STAGE + 6144 * wave + 1024 * i)));
+    };
+    // raw A of one k-16 half for both row tiles: [half][row tile * 2 + quad]
+    float4 a_pre[2][4];
+    auto load_a = [&](int kt, int half, float4 (&dst)[4]) __attribute__((always_inline)) {
+        const float* src = a_src + kt * 32 + 16 * half;
+        dst[0] = *reinterpret_cast<const float4*>(src);
+        dst[1] = *reinterpret_cast<const float4*>(src + 4);
+        dst[2] = *reinterpret_cast<const float4*>(src + (int64_t)32 * k);
+        dst[3] = *reinterpret_cast<const float4*>(src + (int64_t)32 * k + 4);
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
+
+    // prologue.  Queue order per k step is always [W DMA x6][A half 0 x4][A half 1 x4].
+    dma_w(0, 0);
+    load_a(0, 0, a_pre[0]);
+    load_a(0, 1, a_pre[1]);
+    dma_w(last < 1 ? last : 1, 1);
+    int stage = 0;
+    for (int kt = 0; kt < n_tiles; ++kt) {
+        // own pieces of W(kt) have landed: younger than them are A(kt) [8] and W(kt+1) [6]
+        asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+        __syncthreads();  // everybody's pieces landed; everybody is done with stage (kt + 2) % 3 (read during step kt - 1)
+        const int nstage = stage == 0 ? 2 : stage - 1;
+        const unsigned char* ws = smem + stage * V2_STAGE;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float4(&cur)[4] = a_pre[s];
+            bf16x8 af[2][3];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                unsigned x0, x1, x2, y0, y1, y2, z0, z1, z2, u0, u1, u2;
+                split2(cur[2 * t].x, cur[2 * t].y, x0, x1, x2);
+                split2(cur[2 * t].z, cur[2 * t].w, y0, y1, y2);
+                split2(cur[2 * t + 1].x, cur[2 * t + 1].y, z0, z1, z2);
+                split2(cur[2 * t + 1].z, cur[2 * t + 1].w, u0, u1, u2);
+                af[t][0] = __builtin_bit_cast(bf16x8, u32x4{x0, y0, z0, u0});
+                af[t][1] = __builtin_bit_cast(bf16x8, u32x4{x1, y1, z1, u1});
+                af[t][2] = __builtin_bit_cast(bf16x8, u32x4{x2, y2, z2, u2});
+            }
+            if (s == 0) dma_w(kt + 2 < last ? kt + 2 : last, nstage);  // (after the barrier; keeps the queue order)
+            load_a(kt + 1 < last ? kt + 1 : last, s, cur);              // one k-32 step ahead
+            bf16x8 bq[2][3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bq[0][p] = *reinterpret_cast<const bf16x8*>(ws + p * V2_W_PLANE + tile_off(li, 2 * s + lh));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j + 1 < 4) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        bq[(j + 1) & 1][p] = *reinterpret_cast<const bf16x8*>(ws + p * V2_W_PLANE + tile_off(32 * (j + 1) + li, 2 * s + lh));
+                }
+                const bf16x8 b0 = bq[j & 1][0], b1 = bq[j & 1][1], b2 = bq[j & 1][2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t][2], b0, acc[t][j], 0, 0, 0);
+                    acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t][1], b1, acc[t][j], 0, 0, 0);
+                    acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t][0], b2, acc[t][j], 0, 0, 0);
+                    acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t][1], b0, acc[t][j], 0, 0, 0);
+                    acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t][0], b1, acc[t][j], 0, 0, 0);
+                    acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t][0], b0, acc[t][j], 0, 0, 0);
+                }
+            }
+        }
+        stage = stage == 2 ? 0 : stage + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped tail DMAs must not outlive the workgroup's LDS
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = n0 + 32 * j + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = m0 + 64 * wave + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                c[row * n + col] = acc[t][j][r];
+            }
+        }
+}
+
+float run_v7(const float* a, const uint16_t* wp, float* c, int64_t m, int n, int k, int iters) {
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(split_gemm_v7_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * V2_STAGE));
+    const unsigned grid = (unsigned)((m / 256) * (n / 128));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(split_gemm_v7_kernel, dim3(grid), dim3(256), 3 * V2_STAGE, 0, a, wp, c, m, n, k);
+    CHECK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(split_gemm_v7_kernel, dim3(grid), dim3(256), 3 * V2_STAGE, 0, a, wp, c, m, n, k);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    CHECK(hipGetLastError());
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / iters;
+}
+
 int main(int argc, char** argv) {
     struct Shape { int64_t m; int n, k; };
     const Shape shapes[] = {{230400, 1024, 256}, {230400, 256, 1024}, {46080, 2048, 512}, {46080, 512, 2048}, {46080, 768, 192}};
@@ -892,9 +1034,9 @@ int main(int argc, char** argv) {
             CHECK(hipMalloc(&dimg5, hw.size() * 2 * 3));
             hipLaunchKernelGGL(split_tiles16_kernel, dim3((unsigned)((hw.size() / 8 + 255) / 256)), dim3(256), 0, 0, dw, dimg5, n, k);
             CHECK(hipDeviceSynchronize());
-            for (int mode = 2; mode < 6; ++mode) { if (mode == 3) continue;
+            for (int mode = 2; mode < 7; ++mode) { if (mode == 3 || mode == 4) continue;
                 const int iters = 10;
-                const float ms = mode == 0 ? run<0>(da, dp, dc, m, n, k, iters) : mode == 1 ? run<1>(da, dp, dc, m, n, k, iters) : mode == 2 ? run_v2<0>(da, dimg16, dc, m, n, k, iters) : mode == 3 ? run_v3<0>(da, dimg16, dc, m, n, k, iters) : mode == 4 ? run_v5(da, dimg5, dc, m, n, k, iters) : run_v6(da, dimg5, dc, m, n, k, iters);
+                const float ms = mode == 0 ? run<0>(da, dp, dc, m, n, k, iters) : mode == 1 ? run<1>(da, dp, dc, m, n, k, iters) : mode == 2 ? run_v2<0>(da, dimg16, dc, m, n, k, iters) : mode == 3 ? run_v3<0>(da, dimg16, dc, m, n, k, iters) : mode == 4 ? run_v5(da, dimg5, dc, m, n, k, iters) : mode == 5 ? run_v6(da, dimg5, dc, m, n, k, iters) : run_v7(da, dimg16, dc, m, n, k, iters);
                 // error on sampled rows
                 const int rows = 48;
                 std::vector<float> hc((size_t)n);
