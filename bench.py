@@ -165,7 +165,7 @@ def main():
 
     # the quantiser's stand-alone HBM roofline (its own large-N launch) is taken first, on an idle chip: after the MFMA-heavy
     # pipeline the same launch measures ~10 % lower while the clocks recover
-    fsq_line = fsq_microbench(codec, dev) if rank == 0 and not args.pipeline_only else None
+    fsq_line = fsq_microbench(codec, dev) if rank == 0 and world == 1 and not args.pipeline_only else None
     for _ in range(args.warmup):
         run()
     drain()
@@ -270,7 +270,7 @@ def main():
             out["exact_f32_mfma_route"] = {"ms_per_step": ex * 1e3, "value": b * samples / ex, "unit": "samples/s",
                                            "token_differences_vs_split_route": int((ind_x["indices"] != ind["indices"]).sum())}
         out["fsq_kernel"] = fsq_line
-        if not args.no_cpu_baseline and not args.pipeline_only:
+        if not args.no_cpu_baseline and not args.pipeline_only and world == 1:  # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(codec, audio, args.cpu_batch, ind, args.cpu_threads)
         try:  # RCCL writes a version banner through C stdio: flush it first so that the JSON line is the last line of stdout
             import ctypes
