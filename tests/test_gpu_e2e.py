@@ -61,7 +61,10 @@ def test_submodules_against_oracle(tag, seed, batch, samples):
 
 @pytest.mark.parametrize("tag,seed,batch,samples", [("tiny", 3, 4, 250), ("1kbps", 0, 4, 16000), ("3kbps", 0, 3, 16000),
                                                     ("1kbps", 0, 2, 16001), ("1kbps", 0, 3, 100), ("0k75bps", 1, 2, 8000),
-                                                    ("1k5bps", 1, 2, 8000)])
+                                                    ("1k5bps", 1, 2, 8000),
+                                                    # ragged sizes: one sample, one short of / one past a hop, a tile-unfriendly length
+                                                    ("1kbps", 0, 1, 1), ("1kbps", 0, 2, 269), ("1kbps", 0, 1, 271), ("1kbps", 0, 5, 8191),
+                                                    ("3kbps", 0, 1, 97)])
 def test_encode_decode_against_oracle(tag, seed, batch, samples):
     codec = _codec(tag, seed)
     mc = codec.network.mc
