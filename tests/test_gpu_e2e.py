@@ -197,6 +197,26 @@ def test_full_batch_properties_1kbps():
     assert ok and n_bad <= 4
 
 
+def test_batch_2048_on_one_gpu():
+    """BASELINE config 4 moved onto one device (2048 x 1 s): workspace sizing, clip-group scheduling of the wide stages and
+    batch invariance at 8x the headline batch."""
+    codec = _codec("1kbps", 0)
+    mc = codec.network.mc
+    audio = seeded_audio(2048, 16000).cuda()
+    q, ind = codec.encode_audio(audio)
+    idx = ind["indices"]
+    assert idx.shape == (2048, 60) and int(idx.min()) >= 0 and int(idx.max()) < mc.codebook_size
+    wave = codec.decode_audio(q)
+    assert wave.shape == (2048, 16200) and torch.isfinite(wave).all()
+    for b in (0, 1023, 2047):  # any clip alone: identical tokens and samples
+        q1, ind1 = codec.encode_audio(audio[b:b + 1])
+        assert torch.equal(ind1["indices"], idx[b:b + 1])
+        assert torch.equal(codec.decode_audio(q1), wave[b:b + 1])
+    # the first 256 clips as their own batch (the headline shape) give the same results
+    q256, ind256 = codec.encode_audio(audio[:256])
+    assert torch.equal(ind256["indices"], idx[:256]) and torch.equal(codec.decode_audio(q256), wave[:256])
+
+
 def test_edge_cases():
     codec = _codec("1kbps", 0)
     mc = codec.network.mc
