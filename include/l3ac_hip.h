@@ -186,6 +186,10 @@ int l3ac_gemm_f32(const float* a, int64_t lda, const float* w, const float* bias
  * channel contractions use it by default; l3ac_set_gemm_split(0) (or L3AC_GEMM_SPLIT=0 in the environment) routes
  * every product through the exact v_mfma_f32_32x32x2_f32 kernel instead.  Process-wide switch.
  * (reference counterpart: none — torch.nn.functional.linear / conv1d on fp32 tensors.) */
+/* The split itself, on the HOST (no GPU needed; this is what builds the weight images): planes [3][n] bf16 bit patterns with
+ * x[i] == bf16(planes[0][i]) + bf16(planes[1][i]) + bf16(planes[2][i]) exactly for every finite fp32 x[i]
+ * (tests/test_host.py::test_bf16x3_split_is_exact). */
+void l3ac_split3_host(const float* x, int64_t n, uint16_t* planes);
 void l3ac_set_gemm_split(int32_t enable);
 int32_t l3ac_get_gemm_split(void);
 /* Weight image for l3ac_gemm_split_f32: w [n][k] fp32 -> `image` (device, l3ac_gemm_split_image_bytes(n, k) bytes;

@@ -5,6 +5,7 @@
 #include <string>
 
 #include "network.hpp"
+#include "kernels/split_bf16.hpp"
 
 static thread_local std::string g_last_error;
 
@@ -388,6 +389,16 @@ int l3ac_gemm_f32(const float* a, int64_t lda, const float* w, const float* bias
     GemmArgs g{};
     g.a = a; g.lda = lda; g.w = w; g.ldw = k; g.c = c; g.ldc = ldc; g.m = m; g.n = n; g.k = k; g.bias = bias; g.epi = EPI_BIAS;
     return launch_gemm((hipStream_t)stream, g);
+}
+
+void l3ac_split3_host(const float* x, int64_t n, uint16_t* planes) {
+    for (int64_t i = 0; i < n; ++i) {
+        uint16_t pl[3];
+        split3_host(x[i], pl);
+        planes[i] = pl[0];
+        planes[n + i] = pl[1];
+        planes[2 * n + i] = pl[2];
+    }
 }
 
 void l3ac_set_gemm_split(int32_t enable) { gemm_split_set_enabled(enable != 0); }

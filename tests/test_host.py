@@ -115,3 +115,38 @@ def test_library_exports_every_declared_symbol():
     # argument validation happens before any device work
     assert lib.l3ac_reserve(None, 1, 1) != 0 and b"null context" in lib.l3ac_last_error()
     assert lib.l3ac_hop_length(None) == 0
+
+
+def test_bf16x3_split_is_exact():
+    """The operand split of the bf16x3 kernels (include/l3ac_hip.h, kernels/split_bf16.hpp), evaluated by the library's
+    host routine that also builds the weight images — no GPU involved: three bf16 planes add back to the fp32 value
+    EXACTLY, each plane is the round-to-nearest-even bf16 of the residual before it, and the planes shrink by 2^-8 each
+    (which is what bounds the three dropped cross products by 2^-26 |a.w|)."""
+    import numpy as np
+
+    lib = _capi.load_library()
+    rng = np.random.default_rng(7)
+    x = np.concatenate([
+        rng.standard_normal(200_000).astype(np.float32),
+        (rng.standard_normal(100_000) * np.exp(rng.uniform(-30, 30, 100_000))).astype(np.float32),  # wide dynamic range
+        np.array([0.0, -0.0, 1.0, -1.0, 1.0 + 2.0 ** -23, 1.0 - 2.0 ** -24, 3.0e38, -3.0e38, 1e-30, 255.99998], np.float32),
+    ])
+    n = x.size
+    planes = np.zeros((3, n), np.uint16)
+    lib.l3ac_split3_host(x.ctypes.data_as(ctypes.c_void_p), n, planes.ctypes.data_as(ctypes.c_void_p))
+    p = (planes.astype(np.uint32) << 16).view(np.float32)  # bf16 bit patterns -> fp32 values
+
+    # exact reconstruction, summed smallest first in fp32 (each partial sum is itself exact)
+    back = (p[2] + p[1]) + p[0]
+    assert np.array_equal(back.view(np.uint32), x.view(np.uint32)) or np.array_equal(back, x)
+    assert np.array_equal(back, x)
+
+    def bf16_rne(v):  # numpy restatement of round-to-nearest-even to bf16
+        u = v.view(np.uint32).astype(np.uint64)
+        return (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16).astype(np.uint32).view(np.float32)
+
+    r1 = x - p[0]
+    r2 = r1 - p[1]
+    assert np.array_equal(p[0], bf16_rne(x)) and np.array_equal(p[1], bf16_rne(r1)) and np.array_equal(p[2], bf16_rne(r2))
+    ax = np.abs(x).astype(np.float64)
+    assert np.all(np.abs(p[1]) <= ax * 2.0 ** -8) and np.all(np.abs(p[2]) <= ax * 2.0 ** -16)
