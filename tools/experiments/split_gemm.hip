@@ -16,7 +16,8 @@
 //   mode 4    "v5" = k tile of 16, three DMA-fed LDS stages, 117 VGPRs -> four blocks per CU
 //   mode 5    "v6" = v5 with 64 rows per wave (half the LDS reads / W staging per MFMA), two waves per SIMD
 //   mode 6    "v7" = 64 rows per wave on the shipped k-32 image (three 24-KB DMA stages, A fetched in k-16 halves)
-// All of 2..6 land within a few % of each other (140-157 TFLOP/s fp32-equivalent); MFMA-only (DIAG 31) reaches 296.
+//   mode 7    "v8" = v2 made persistent: the next tile's first fetches are issued before the current tile's epilogue
+// All of 2..7 land within a few % of each other (140-157 TFLOP/s fp32-equivalent); MFMA-only (DIAG 31) reaches 296.
 //
 //   hipcc -O3 --offload-arch=gfx950 tools/experiments/split_gemm.hip -o tools/experiments/_build/split_gemm
 #include <hip/hip_runtime.h>
@@ -999,6 +1000,156 @@ float run_v7(const float* a, const uint16_t* wp, float* c, int64_t m, int n, int
     return ms / iters;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// v8: v2 made persistent — a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...; the next tile's first A / W
+// fetches are issued BEFORE the current tile's epilogue stores, so the prologue latency hides behind the epilogue.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 3) void split_gemm_v8_kernel(const float* __restrict__ a, const uint16_t* __restrict__ wp,
+                                                              float* __restrict__ c, int64_t m, int n, int k, int total_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int n_blocks = n / 128;
+    const int64_t m_panels = m / 128;
+    const int n_tiles = k / 32;
+    const int last = n_tiles - 1;
+
+    const float* a_src = nullptr;
+    const unsigned char* w_src = nullptr;
+    int64_t m0 = 0;
+    int n0 = 0;
+    auto locate = [&](int tile) __attribute__((always_inline)) {  // XCD-aware tile order, as v2
+        const int64_t group = tile / (8 * n_blocks);
+        const int64_t in_group = tile % (8 * n_blocks);
+        const int64_t panels_here = (group * 8 + 8 <= m_panels) ? 8 : m_panels - group * 8;
+        m0 = (group * 8 + in_group % panels_here) * 128;
+        n0 = (int)(in_group / panels_here) * 128;
+        a_src = a + (m0 + 32 * wave + li) * k + 8 * lh;
+        w_src = reinterpret_cast<const unsigned char*>(wp) + (int64_t)(n0 / 128) * n_tiles * V2_STAGE + 16 * tid;
+    };
+    float4 a_pre[2][4];
+    u32x4 w_reg[6];
+    auto load_a = [&](int kt, float4 (&dst)[4]) __attribute__((always_inline)) {
+        const float* src = a_src + kt * 32;
+        dst[0] = *reinterpret_cast<const float4*>(src);
+        dst[1] = *reinterpret_cast<const float4*>(src + 4);
+        dst[2] = *reinterpret_cast<const float4*>(src + 16);
+        dst[3] = *reinterpret_cast<const float4*>(src + 20);
+    };
+    auto load_w = [&](int kt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) w_reg[i] = *reinterpret_cast<const u32x4*>(w_src + (int64_t)kt * V2_STAGE + 4096 * i);
+    };
+    auto store_w = [&](int buf) __attribute__((always_inline)) {
+        unsigned char* base = smem + buf * V2_STAGE;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) *reinterpret_cast<u32x4*>(base + 16 * tid + 4096 * i) = w_reg[i];
+    };
+    auto read_b = [&](const unsigned char* ws, int s, int j, bf16x8 (&b)[3]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const bf16x8*>(ws + p * V2_W_PLANE + tile_off(32 * j + li, 2 * s + lh));
+    };
+    f32x16 acc[4];
+    auto step = [&](int kt, float4 (&cur)[4]) __attribute__((always_inline)) {
+        const int buf = kt & 1;
+        load_w(kt + 1 < last ? kt + 1 : last);
+        u32x4 af[2][3];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            unsigned x0, x1, x2, y0, y1, y2, z0, z1, z2, u0, u1, u2;
+            split2(cur[2 * s].x, cur[2 * s].y, x0, x1, x2);
+            split2(cur[2 * s].z, cur[2 * s].w, y0, y1, y2);
+            split2(cur[2 * s + 1].x, cur[2 * s + 1].y, z0, z1, z2);
+            split2(cur[2 * s + 1].z, cur[2 * s + 1].w, u0, u1, u2);
+            af[s][0] = u32x4{x0, y0, z0, u0};
+            af[s][1] = u32x4{x1, y1, z1, u1};
+            af[s][2] = u32x4{x2, y2, z2, u2};
+        }
+        load_a(kt + 2 < last ? kt + 2 : last, cur);
+        const unsigned char* ws = smem + buf * V2_STAGE;
+        bf16x8 bq[2][3];
+        read_b(ws, 0, 0, bq[0]);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int s = it >> 2, j = it & 3;
+            if (it + 1 < 8) read_b(ws, (it + 1) >> 2, (it + 1) & 3, bq[(it + 1) & 1]);
+            const bf16x8 a0 = __builtin_bit_cast(bf16x8, af[s][0]);
+            const bf16x8 a1 = __builtin_bit_cast(bf16x8, af[s][1]);
+            const bf16x8 a2 = __builtin_bit_cast(bf16x8, af[s][2]);
+            const bf16x8 b0 = bq[it & 1][0], b1 = bq[it & 1][1], b2 = bq[it & 1][2];
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[j], 0, 0, 0);
+            if (it == 3) store_w(buf ^ 1);
+        }
+        __syncthreads();
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= total_tiles) return;
+    locate(tile);
+    load_a(0, a_pre[0]);
+    load_a(last < 1 ? last : 1, a_pre[1]);
+    load_w(0);
+    while (true) {
+        store_w(0);  // (every wave passed the last barrier of the previous tile: both buffers are free)
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        for (int kt = 0; kt < n_tiles; kt += 2) {
+            step(kt, a_pre[0]);
+            if (kt + 1 < n_tiles) step(kt + 1, a_pre[1]);
+        }
+        // the tail steps re-fetched the last k tile into a_pre / w_reg (clamped indices): those registers are free now
+        const int64_t cm0 = m0;
+        const int cn0 = n0;
+        const int next = tile + gridDim.x;
+        const bool more = next < total_tiles;
+        if (more) {  // block-uniform
+            locate(next);
+            load_a(0, a_pre[0]);
+            load_a(last < 1 ? last : 1, a_pre[1]);
+            load_w(0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = cn0 + 32 * j + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = cm0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                c[row * n + col] = acc[j][r];
+            }
+        }
+        if (!more) break;
+        tile = next;
+    }
+}
+
+float run_v8(const float* a, const uint16_t* wp, float* c, int64_t m, int n, int k, int iters) {
+    const int total = (int)((m / 128) * (n / 128));
+    const unsigned grid = (unsigned)(total < 768 ? total : 768);
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(split_gemm_v8_kernel, dim3(grid), dim3(256), 2 * V2_STAGE, 0, a, wp, c, m, n, k, total);
+    CHECK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(split_gemm_v8_kernel, dim3(grid), dim3(256), 2 * V2_STAGE, 0, a, wp, c, m, n, k, total);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    CHECK(hipGetLastError());
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / iters;
+}
+
 int main(int argc, char** argv) {
     struct Shape { int64_t m; int n, k; };
     const Shape shapes[] = {{230400, 1024, 256}, {230400, 256, 1024}, {46080, 2048, 512}, {46080, 512, 2048}, {46080, 768, 192}};
@@ -1034,9 +1185,9 @@ int main(int argc, char** argv) {
             CHECK(hipMalloc(&dimg5, hw.size() * 2 * 3));
             hipLaunchKernelGGL(split_tiles16_kernel, dim3((unsigned)((hw.size() / 8 + 255) / 256)), dim3(256), 0, 0, dw, dimg5, n, k);
             CHECK(hipDeviceSynchronize());
-            for (int mode = 2; mode < 7; ++mode) { if (mode == 3 || mode == 4) continue;
+            for (int mode = 2; mode < 8; ++mode) { if (mode == 3 || mode == 4 || mode == 5) continue;
                 const int iters = 10;
-                const float ms = mode == 0 ? run<0>(da, dp, dc, m, n, k, iters) : mode == 1 ? run<1>(da, dp, dc, m, n, k, iters) : mode == 2 ? run_v2<0>(da, dimg16, dc, m, n, k, iters) : mode == 3 ? run_v3<0>(da, dimg16, dc, m, n, k, iters) : mode == 4 ? run_v5(da, dimg5, dc, m, n, k, iters) : mode == 5 ? run_v6(da, dimg5, dc, m, n, k, iters) : run_v7(da, dimg16, dc, m, n, k, iters);
+                const float ms = mode == 0 ? run<0>(da, dp, dc, m, n, k, iters) : mode == 1 ? run<1>(da, dp, dc, m, n, k, iters) : mode == 2 ? run_v2<0>(da, dimg16, dc, m, n, k, iters) : mode == 3 ? run_v3<0>(da, dimg16, dc, m, n, k, iters) : mode == 4 ? run_v5(da, dimg5, dc, m, n, k, iters) : mode == 5 ? run_v6(da, dimg5, dc, m, n, k, iters) : mode == 6 ? run_v7(da, dimg16, dc, m, n, k, iters) : run_v8(da, dimg16, dc, m, n, k, iters);
                 // error on sampled rows
                 const int rows = 48;
                 std::vector<float> hc((size_t)n);
