@@ -20,7 +20,13 @@
  *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); calls only enqueue
  *     work on it: no host synchronisation, and no allocation once l3ac_reserve() has sized the workspace,
  *     so a call sequence can be captured into a hipGraph.
- *   - one context per device; a context is not thread-safe.
+ *   - one context per device; a context is not thread-safe (one host thread at a time).
+ *   - a context owns ONE workspace that every encode / decode / op call reuses in place.  Calls may be issued on
+ *     different streams: each call makes its stream wait for the completion event of the context's previous call
+ *     when that ran on another stream, so pipelined callers (encode of batch n+1 on stream A, decode of batch n on
+ *     stream B) are serialised on the device instead of corrupting each other.  Two exceptions, both the caller's
+ *     to order: work captured into a hipGraph (no events are recorded or waited for during capture; keep a captured
+ *     sequence on one stream) and replays of such a graph.  For true overlap use one context per stream.
  */
 #ifndef L3AC_HIP_H
 #define L3AC_HIP_H

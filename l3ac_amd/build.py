@@ -44,8 +44,32 @@ def _hipcc() -> str:
 
 
 def _newest_header() -> float:
-    hdrs = list(CSRC.glob("*.hpp")) + list((REPO / "include").glob("*.h"))
+    """Newest header anywhere under csrc/ (kernels/*.hpp hold the split, epilogue and activation math shared by most
+    kernels) or include/: the fallback staleness test for objects that have no depfile yet."""
+    hdrs = list(CSRC.rglob("*.hpp")) + list(CSRC.rglob("*.h")) + list((REPO / "include").glob("*.h"))
     return max(h.stat().st_mtime for h in hdrs)
+
+
+def _depfile_newest(dep: Path) -> float:
+    """Newest mtime among the prerequisites hipcc recorded for one object (-MD -MF); inf when one has disappeared."""
+    text = dep.read_text().replace("\\\n", " ")
+    newest = 0.0
+    for tok in text.split(":", 1)[-1].split():
+        if tok.startswith("/opt/rocm") or tok.startswith("/usr/"):
+            continue  # toolchain headers: the flag stamp carries the hipcc version
+        f = Path(tok)
+        if not f.exists():
+            return float("inf")
+        newest = max(newest, f.stat().st_mtime)
+    return newest
+
+
+def _flag_stamp(hipcc: str, flags) -> str:
+    """Identity of everything that shapes an object besides its sources: the flag list (L3AC_EXTRA_HIPCC_FLAGS included)
+    and the compiler version.  A change forces a full rebuild."""
+    import hashlib
+    ver = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout
+    return hashlib.sha256(("\n".join(flags) + "\n" + ver).encode()).hexdigest()
 
 
 def build_library(force: bool = False, verbose: bool = False) -> Path:
@@ -54,14 +78,23 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
     flags = [*os.environ.get("L3AC_EXTRA_HIPCC_FLAGS", "").split(), "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-Wall", "-Wno-unused-function",
              f"-I{REPO / 'include'}", f"-I{CSRC}"]
     hdr_time = _newest_header()
+    stamp_file = OBJ_DIR / "flags.sha256"
+    stamp = _flag_stamp(hipcc, flags)
+    if not stamp_file.exists() or stamp_file.read_text().strip() != stamp:
+        force = True  # other flags or another compiler: every object is stale
     jobs = []
     objs = []
     for src in SOURCES:
         s = CSRC / src
         o = OBJ_DIR / (src.replace("/", "_") + ".o")
+        d = o.with_suffix(".d")
         objs.append(o)
-        if force or not o.exists() or o.stat().st_mtime < max(s.stat().st_mtime, hdr_time):
-            jobs.append([hipcc, *flags, "-c", str(s), "-o", str(o)])
+        stale = force or not o.exists()
+        if not stale:
+            newest = max(s.stat().st_mtime, _depfile_newest(d) if d.exists() else hdr_time)
+            stale = o.stat().st_mtime < newest
+        if stale:
+            jobs.append([hipcc, *flags, "-MD", "-MF", str(d), "-c", str(s), "-o", str(o)])
 
     def run(cmd):
         if verbose:
@@ -74,6 +107,7 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
 
     with ThreadPoolExecutor(max_workers=min(4, os.cpu_count() or 1)) as pool:
         list(pool.map(run, jobs))
+    stamp_file.write_text(stamp + "\n")
     if jobs or not LIB_PATH.exists():
         run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(LIB_PATH), *map(str, objs)])
     return LIB_PATH

@@ -42,6 +42,40 @@ struct DeviceGuard {  // make the context's device current for the duration of a
     DeviceGuard guard_((ctx)->device);                      \
     L3AC_REQUIRE(guard_.ok, "cannot select device %d", (ctx)->device)
 
+// The workspace (ws.x0 / x1 / a / h / yi / stats) is reused in place by every call of a context.  Calls issued on one stream
+// are ordered by the stream; a caller that pipelines encode(batch n+1) on stream A against decode(batch n) on stream B would
+// otherwise overwrite live activations silently.  Each workspace-using entry point holds one of these: on entry the call's
+// stream waits for the previous call's completion event when that call ran on another stream; on exit the event is
+// re-recorded.  Inside a stream capture nothing is recorded or waited for (events from outside a capture cannot be joined
+// into it): a captured sequence must stay on one stream per context, which hipGraph replay then preserves.
+struct WorkspaceOrder {
+    l3ac_ctx* ctx;
+    hipStream_t s;
+    bool capturing = false;
+    int rc = L3AC_OK;
+    WorkspaceOrder(l3ac_ctx* c, hipStream_t stream) : ctx(c), s(stream) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (s) (void)hipStreamIsCapturing(s, &st);
+        capturing = st != hipStreamCaptureStatusNone;
+        if (!capturing && ctx->ws_done_valid && ctx->ws_stream != s && hipStreamWaitEvent(s, ctx->ws_done, 0) != hipSuccess) {
+            l3ac_set_error("cannot order stream %p after the context's previous call on stream %p", (void*)s, (void*)ctx->ws_stream);
+            rc = L3AC_EHIP;
+        }
+    }
+    ~WorkspaceOrder() {
+        if (capturing || !ctx->ws_done) return;
+        if (hipEventRecord(ctx->ws_done, s) == hipSuccess) {
+            ctx->ws_stream = s;
+            ctx->ws_done_valid = true;
+        }
+    }
+};
+
+#define L3AC_ENTER_WS(ctx, stream)                          \
+    L3AC_ENTER(ctx);                                        \
+    WorkspaceOrder order_((ctx), (hipStream_t)(stream));    \
+    if (order_.rc != L3AC_OK) return order_.rc
+
 template <class Map>
 auto lookup(const Map& m, const char* name, const char* kind) -> decltype(m.begin()->second) {
     if (!name) {
@@ -75,7 +109,12 @@ int l3ac_create(const l3ac_config* cfg, const l3ac_tensor* tensors, int32_t n_te
     ctx->device = device;
     DeviceGuard guard(device);
     int rc = guard.ok ? network_build(ctx, tensors, n_tensors) : L3AC_EHIP;
+    if (rc == L3AC_OK && hipEventCreateWithFlags(&ctx->ws_done, hipEventDisableTiming) != hipSuccess) {
+        l3ac_set_error("hipEventCreate failed");
+        rc = L3AC_EHIP;
+    }
     if (rc != L3AC_OK) {
+        if (ctx->ws_done) (void)hipEventDestroy(ctx->ws_done);
         network_free(ctx);
         delete ctx;
         return rc;
@@ -88,6 +127,7 @@ void l3ac_destroy(l3ac_ctx* ctx) {
     if (!ctx) return;
     DeviceGuard guard(ctx->device);
     (void)hipDeviceSynchronize();
+    if (ctx->ws_done) (void)hipEventDestroy(ctx->ws_done);
     network_free(ctx);
     delete ctx;
 }
@@ -103,7 +143,7 @@ int32_t l3ac_hop_length(const l3ac_ctx* ctx) { return ctx ? ctx->hop : 0; }
 
 int l3ac_encode(l3ac_ctx* ctx, const float* audio, int32_t batch, int32_t samples, int64_t audio_stride,
                 float* q_feature, int32_t* indices, float* level_indices, void* stream) {
-    L3AC_ENTER(ctx);
+    L3AC_ENTER_WS(ctx, stream);
     L3AC_REQUIRE(audio && q_feature && indices, "l3ac_encode: null buffer");
     L3AC_REQUIRE(batch > 0 && batch <= 65535 && samples > 0 && audio_stride >= samples, "l3ac_encode: bad shape");
     hipStream_t s = (hipStream_t)stream;
@@ -124,7 +164,7 @@ int l3ac_encode(l3ac_ctx* ctx, const float* audio, int32_t batch, int32_t sample
 
 int l3ac_decode(l3ac_ctx* ctx, const float* q_feature, const int32_t* indices, int32_t batch, int32_t n_tok,
                 float* audio_out, void* stream) {
-    L3AC_ENTER(ctx);
+    L3AC_ENTER_WS(ctx, stream);
     L3AC_REQUIRE((q_feature || indices) && audio_out, "l3ac_decode: null buffer");
     L3AC_REQUIRE(batch > 0 && batch <= 65535 && n_tok > 0, "l3ac_decode: bad shape");
     hipStream_t s = (hipStream_t)stream;
@@ -190,7 +230,7 @@ int l3ac_vq_argmin(const float* queries, int64_t n, const float* codebook, int32
 
 // ---- per-block parity entry points --------------------------------------------------------------------
 int l3ac_op_first_block(l3ac_ctx* ctx, const float* audio, int32_t batch, int32_t samples, float* y, void* stream) {
-    L3AC_ENTER(ctx);
+    L3AC_ENTER_WS(ctx, stream);
     return launch_first_block((hipStream_t)stream, ctx->first, audio, samples, batch, samples, samples, y);
 }
 
@@ -201,7 +241,7 @@ int l3ac_op_first_block(l3ac_ctx* ctx, const float* audio, int32_t batch, int32_
 
 int l3ac_op_conv_unit(l3ac_ctx* ctx, const char* block, const float* x, int32_t batch, int32_t frames, float* y,
                       void* stream) {
-    L3AC_ENTER(ctx);
+    L3AC_ENTER_WS(ctx, stream);
     const ConvUnitW* w = lookup(ctx->by_unit, block, "ConvUnit");
     if (!w) return L3AC_EINVAL;
     L3AC_OP_SCRATCH(w->c);
@@ -210,7 +250,7 @@ int l3ac_op_conv_unit(l3ac_ctx* ctx, const char* block, const float* x, int32_t 
 
 int l3ac_op_down_layer(l3ac_ctx* ctx, const char* block, const float* x, int32_t batch, int32_t frames, float* y,
                        void* stream) {
-    L3AC_ENTER(ctx);
+    L3AC_ENTER_WS(ctx, stream);
     const DownW* w = lookup(ctx->by_down, block, "down-layer");
     if (!w) return L3AC_EINVAL;
     return run_down(ctx, (hipStream_t)stream, *w, x, y, batch, frames);
@@ -218,7 +258,7 @@ int l3ac_op_down_layer(l3ac_ctx* ctx, const char* block, const float* x, int32_t
 
 int l3ac_op_conv_k3(l3ac_ctx* ctx, const char* block, const float* x, int32_t batch, int32_t frames, float* y,
                     void* stream) {
-    L3AC_ENTER(ctx);
+    L3AC_ENTER_WS(ctx, stream);
     const ConvK3W* w = lookup(ctx->by_k3, block, "Conv1d(k3)");
     if (!w) return L3AC_EINVAL;
     return run_conv_k3(ctx, (hipStream_t)stream, *w, x, y, batch, frames);
@@ -226,7 +266,7 @@ int l3ac_op_conv_k3(l3ac_ctx* ctx, const char* block, const float* x, int32_t ba
 
 int l3ac_op_enhance(l3ac_ctx* ctx, const char* block, const float* x, int32_t batch, int32_t frames, float* y,
                     void* stream) {
-    L3AC_ENTER(ctx);
+    L3AC_ENTER_WS(ctx, stream);
     const EnhW* w = lookup(ctx->by_enh, block, "EnhanceBlock");
     if (!w) return L3AC_EINVAL;
     L3AC_OP_SCRATCH(w->c);
@@ -235,7 +275,7 @@ int l3ac_op_enhance(l3ac_ctx* ctx, const char* block, const float* x, int32_t ba
 
 int l3ac_op_up_layer(l3ac_ctx* ctx, const char* block, const float* x, int32_t batch, int32_t frames, float* y,
                      void* stream) {
-    L3AC_ENTER(ctx);
+    L3AC_ENTER_WS(ctx, stream);
     const UpW* w = lookup(ctx->by_up, block, "up-layer");
     if (!w) return L3AC_EINVAL;
     L3AC_OP_SCRATCH(w->cout);
@@ -244,7 +284,7 @@ int l3ac_op_up_layer(l3ac_ctx* ctx, const char* block, const float* x, int32_t b
 
 int l3ac_op_enhance_up(l3ac_ctx* ctx, const char* enhance_block, const char* up_block, const float* x, int32_t batch, int32_t frames,
                        float* y, void* stream) {
-    L3AC_ENTER(ctx);
+    L3AC_ENTER_WS(ctx, stream);
     const EnhW* e = lookup(ctx->by_enh, enhance_block, "EnhanceBlock");
     const UpW* w = lookup(ctx->by_up, up_block, "up-layer");
     if (!e || !w) return L3AC_EINVAL;
@@ -255,7 +295,7 @@ int l3ac_op_enhance_up(l3ac_ctx* ctx, const char* enhance_block, const char* up_
 }
 
 int l3ac_op_last_block(l3ac_ctx* ctx, const float* x, int32_t batch, int32_t frames, float* audio, void* stream) {
-    L3AC_ENTER(ctx);
+    L3AC_ENTER_WS(ctx, stream);
     const int c = ctx->head.c;
     L3AC_OP_SCRATCH(c);
     hipStream_t s = (hipStream_t)stream;
@@ -265,7 +305,7 @@ int l3ac_op_last_block(l3ac_ctx* ctx, const float* x, int32_t batch, int32_t fra
 
 int l3ac_op_local_trans(l3ac_ctx* ctx, const char* block, const float* x, int32_t batch, int32_t frames, float* y,
                         void* stream) {
-    L3AC_ENTER(ctx);
+    L3AC_ENTER_WS(ctx, stream);
     const LocalTransW* w = lookup(ctx->by_trans, block, "LocalTrans");
     if (!w) return L3AC_EINVAL;
     const int dim = ctx->cfg.feature_dim;
@@ -278,7 +318,7 @@ int l3ac_op_local_trans(l3ac_ctx* ctx, const char* block, const float* x, int32_
 }
 
 int l3ac_op_encoder(l3ac_ctx* ctx, const float* audio, int32_t batch, int32_t samples, float* feature, void* stream) {
-    L3AC_ENTER(ctx);
+    L3AC_ENTER_WS(ctx, stream);
     L3AC_REQUIRE(samples % ctx->enc_rate == 0, "op_encoder: samples must be a multiple of prod(compress_rates)");
     hipStream_t s = (hipStream_t)stream;
     L3AC_TRY(workspace_ensure_clip(ctx, batch, samples, s));
@@ -291,7 +331,7 @@ int l3ac_op_encoder(l3ac_ctx* ctx, const float* audio, int32_t batch, int32_t sa
 }
 
 int l3ac_op_en_encoder(l3ac_ctx* ctx, const float* feature, int32_t batch, int32_t frames, float* tokens, void* stream) {
-    L3AC_ENTER(ctx);
+    L3AC_ENTER_WS(ctx, stream);
     hipStream_t s = (hipStream_t)stream;
     L3AC_TRY(workspace_ensure_clip(ctx, batch, frames * ctx->enc_rate, s));
     float* cur = ctx->ws.x0;
@@ -305,7 +345,7 @@ int l3ac_op_en_encoder(l3ac_ctx* ctx, const float* feature, int32_t batch, int32
 }
 
 int l3ac_op_en_decoder(l3ac_ctx* ctx, const float* tokens, int32_t batch, int32_t n_tok, float* feature, void* stream) {
-    L3AC_ENTER(ctx);
+    L3AC_ENTER_WS(ctx, stream);
     hipStream_t s = (hipStream_t)stream;
     L3AC_TRY(workspace_ensure_clip(ctx, batch, n_tok * ctx->hop, s));
     float* cur = ctx->ws.x0;
@@ -318,7 +358,7 @@ int l3ac_op_en_decoder(l3ac_ctx* ctx, const float* tokens, int32_t batch, int32_
 }
 
 int l3ac_op_decoder(l3ac_ctx* ctx, const float* feature, int32_t batch, int32_t frames, float* audio, void* stream) {
-    L3AC_ENTER(ctx);
+    L3AC_ENTER_WS(ctx, stream);
     hipStream_t s = (hipStream_t)stream;
     L3AC_TRY(workspace_ensure_clip(ctx, batch, frames * ctx->enc_rate, s));
     float* cur = ctx->ws.x0;

@@ -96,6 +96,11 @@ struct l3ac_ctx {
     std::map<std::string, const LocalTransW*> by_trans;
 
     Workspace ws;
+    // Cross-stream ordering of the (single, in-place) workspace: every call that touches `ws` records `ws_done` on its stream
+    // when it has enqueued its last kernel, and a later call on a DIFFERENT stream first makes that stream wait for it.
+    hipEvent_t ws_done = nullptr;
+    hipStream_t ws_stream = nullptr;
+    bool ws_done_valid = false;
 };
 
 int network_build(l3ac_ctx* ctx, const l3ac_tensor* tensors, int n_tensors);
