@@ -119,6 +119,14 @@ int l3ac_fsq_forward(const float* x, int64_t n, int32_t feat, const int32_t* lev
                      const float* w_in, const float* b_in, const float* w_out, const float* b_out,
                      float* q_feature, int32_t* indices, float* level_indices, float* latents, void* stream);
 
+/* The rounding half of the quantiser on its own: SuperFSQ.quantize_act_value (vq/fsq.py:56-65) ->
+ * level_indices_to_indices (:67-68) -> inv_act (:21) -> project_out (vq/__init__.py:29).  act [n][n_levels] holds the
+ * activation values in [0, 1], i.e. what tanh_act (vq/fsq_act.py:38-39) returns, so no transcendental sits between the
+ * input and the rounding: exact k + 0.5 products and their one-ulp neighbours can be presented bit for bit. */
+int l3ac_fsq_quantize_act(const float* act, int64_t n, int32_t feat, const int32_t* levels, int32_t n_levels,
+                          const float* w_out, const float* b_out, float* q_feature, int32_t* indices,
+                          float* level_indices, void* stream);
+
 /* VQEmbed.to_features (vq/__init__.py:20-23): indices [n] -> q_feature [n][feat]. */
 int l3ac_fsq_decode(const int32_t* indices, int64_t n, int32_t feat, const int32_t* levels, int32_t n_levels,
                     const float* w_out, const float* b_out, float* q_feature, void* stream);
@@ -164,6 +172,15 @@ int l3ac_op_encoder(l3ac_ctx* ctx, const float* audio, int32_t batch, int32_t sa
 int l3ac_op_en_encoder(l3ac_ctx* ctx, const float* feature, int32_t batch, int32_t frames, float* tokens, void* stream);
 int l3ac_op_en_decoder(l3ac_ctx* ctx, const float* tokens, int32_t batch, int32_t n_tok, float* feature, void* stream);
 int l3ac_op_decoder(l3ac_ctx* ctx, const float* feature, int32_t batch, int32_t frames, float* audio, void* stream);
+
+/* snake activation on its own (layers.py:29-33): y = x + (alpha + 1e-8)^-1 * sin(alpha * x)^2 for x [rows][c], alpha [c]
+ * (device pointers).  mode bit 0: evaluate the two-elements-per-lane form the GEMM epilogues and the fused units use;
+ * mode bit 1: y = sin(x)^2 alone (the kernels' own sine; alpha is not used).
+ * A test entry (it synchronises and allocates): the pipeline applies snake inside its GEMM / unit kernels. */
+int l3ac_op_snake(const float* x, float* y, int64_t rows, int32_t c, const float* alpha, int32_t mode, void* stream);
+/* Test hook, process-wide: while enabled the output head (modules.py:192-194) stores the Conv1d(c -> 1, k7) result BEFORE
+ * the final tanh, so that decoder parity can be checked where tanh's saturation does not hide it. */
+void l3ac_set_head_pretanh(int32_t enable);
 
 /* ---- per-launch profile (measurement aid; reference has no counterpart) -------------------------------
  * Between l3ac_profile_begin() and l3ac_profile_end() every kernel launched by the calling thread is bracketed

@@ -265,14 +265,21 @@ def get_model(config_name, model_dir=None, synthetic_seed: Optional[int] = None)
     return codec
 
 
-def get_model_info(model, sample_rate: int = 16000) -> dict:
-    """Geometry facts of reference l3ac/__init__.py:28-51 (the ptflops MAC count is out of scope)."""
+def get_model_info(model, eval_flops_seconds=10, sample_rate: int = 16000) -> dict:
+    """reference l3ac/__init__.py:28-51.  ``model`` is ``codec.network`` (as in example.py:11) or the codec.  The reference
+    traces the model with ptflops on ``eval_flops_seconds`` of audio; here ``macs`` is the analytic multiply-accumulate
+    count of the same input (l3ac_amd/macs.py: every conv / linear product plus the local-attention products, which
+    ptflops does not see), ``macs_breakdown`` its parts, and ``params`` the exact parameter count of the five modules."""
+    from .macs import path_macs
     mc = model.mc if hasattr(model, "mc") else model.network.mc
     compress_rate = mc.hop_length
     codebook_size = mc.codebook_size
     frame_rate = sample_rate / compress_rate
     params = sum(int(math.prod(shape)) for m in _weights.MODULE_NAMES for _, shape in _weights.raw_keys(mc, m))
+    macs = path_macs(mc, int(eval_flops_seconds * sample_rate))
     return {
+        "macs": macs["total"],
+        "macs_breakdown": macs,
         "params": params,
         "codebook_size": codebook_size,
         "frame_rate": frame_rate,

@@ -3,6 +3,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "network.hpp"
 #include "kernels/split_bf16.hpp"
@@ -17,6 +18,10 @@ void l3ac_set_error(const char* fmt, ...) {
     va_end(ap);
     g_last_error = buf;
 }
+
+#include <atomic>
+static std::atomic<int> g_head_pretanh{0};
+bool head_pretanh_enabled() { return g_head_pretanh.load(std::memory_order_relaxed) != 0; }
 
 static thread_local Profiler* g_profiler = nullptr;
 Profiler* l3ac_current_profiler() { return g_profiler; }
@@ -196,6 +201,18 @@ int l3ac_fsq_forward(const float* x, int64_t n, int32_t feat, const int32_t* lev
     for (int d = 0; d < n_levels; ++d) f.levels[d] = levels[d];
     f.w_in = w_in; f.b_in = b_in; f.w_out = w_out; f.b_out = b_out;
     f.q_feature = q_feature; f.indices = indices; f.level_indices = level_indices; f.latents = latents;
+    return launch_fsq((hipStream_t)stream, f);
+}
+
+int l3ac_fsq_quantize_act(const float* act, int64_t n, int32_t feat, const int32_t* levels, int32_t n_levels, const float* w_out,
+                          const float* b_out, float* q_feature, int32_t* indices, float* level_indices, void* stream) {
+    L3AC_REQUIRE(act && levels && n_levels >= 1 && n_levels <= L3AC_MAX_LEVELS, "fsq_quantize_act: bad arguments");
+    FsqArgs f{};
+    f.n = n; f.feat = feat; f.n_levels = n_levels;
+    for (int d = 0; d < n_levels; ++d) f.levels[d] = levels[d];
+    f.w_out = w_out; f.b_out = b_out; f.q_feature = q_feature; f.indices = indices; f.level_indices = level_indices;
+    f.latents = const_cast<float*>(act);  // read only in this mode
+    f.act_in = true;
     return launch_fsq((hipStream_t)stream, f);
 }
 
@@ -439,6 +456,28 @@ void l3ac_split3_host(const float* x, int64_t n, uint16_t* planes) {
         planes[n + i] = pl[1];
         planes[2 * n + i] = pl[2];
     }
+}
+
+void l3ac_set_head_pretanh(int32_t enable) { g_head_pretanh.store(enable != 0, std::memory_order_relaxed); }
+
+int l3ac_op_snake(const float* x, float* y, int64_t rows, int32_t c, const float* alpha, int32_t mode, void* stream) {
+    L3AC_REQUIRE(x && y && alpha && rows >= 0 && c > 0 && c % 4 == 0 && c <= 4096 && mode >= 0 && mode <= 3, "op_snake: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    float* inv = nullptr;  // 1 / (alpha + 1e-8), evaluated in fp32 as layers.py:32 does
+    std::vector<float> ha((size_t)c), hi((size_t)c);
+    L3AC_HIP_CHECK(hipMemcpyAsync(ha.data(), alpha, (size_t)c * sizeof(float), hipMemcpyDeviceToHost, s));
+    L3AC_HIP_CHECK(hipStreamSynchronize(s));
+    for (int i = 0; i < c; ++i) hi[i] = 1.0f / (ha[i] + 1e-8f);
+    L3AC_HIP_CHECK(hipMalloc((void**)&inv, (size_t)c * sizeof(float)));
+    int rc = L3AC_OK;
+    if (hipMemcpyAsync(inv, hi.data(), (size_t)c * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess) {
+        l3ac_set_error("op_snake: upload failed");
+        rc = L3AC_EHIP;
+    }
+    if (rc == L3AC_OK) rc = launch_snake(s, x, y, rows, c, alpha, inv, mode);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(inv);
+    return rc;
 }
 
 void l3ac_set_gemm_split(int32_t enable) { gemm_split_set_enabled(enable != 0); }

@@ -101,7 +101,9 @@ int launch_rows(hipStream_t s, const RowArgs& r);
 
 // elementwise
 int launch_snake(hipStream_t s, const float* x, float* y, int64_t rows, int c, const float* alpha,
-                 const float* inv_alpha);
+                 const float* inv_alpha, int mode = 0);  // mode: see snake_kernel
+// test hook (l3ac_set_head_pretanh): the output head stores the Conv1d(c -> 1, k7) result BEFORE the final tanh
+bool head_pretanh_enabled();
 int launch_geglu(hipStream_t s, const float* h, int64_t ldh, float* y, int64_t ldy, int64_t rows, int inner);
 int launch_grn_sumsq(hipStream_t s, const float* h, int64_t batch, int64_t per_clip, float* sumsq);
 int launch_grn_apply(hipStream_t s, float* h, int64_t batch, int64_t frames, int c, const float* sumsq,
@@ -151,6 +153,7 @@ struct FsqArgs {
     int32_t* indices = nullptr;
     float* level_indices = nullptr;
     float* latents = nullptr;
+    bool act_in = false;              // x == idx_in == null and `latents` holds act = (tanh(lat) + 1) / 2 (vq/fsq.py:56)
 };
 int launch_fsq(hipStream_t s, const FsqArgs& a);
 // token bit stream (kernels/bitpack.hip)

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(1024) void enhance_stats_kernel(const float* __rest
 // head: x [batch][frames][c] (already snake-activated) -> audio [batch][frames]
 __global__ __launch_bounds__(TILE) void head_kernel(const float* __restrict__ x, int frames, int c,
                                                    const float* __restrict__ w, const float* __restrict__ bias,
-                                                   float* __restrict__ audio) {
+                                                   float* __restrict__ audio, const int pretanh) {
     const int b = blockIdx.y;
     const int t = blockIdx.x * TILE + threadIdx.x;
     if (t >= frames) return;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(TILE) void head_kernel(const float* __restrict__ x,
             acc = fmaf(wv.w, xv.w, acc);
         }
     }
-    audio[(int64_t)b * frames + t] = tanhf(acc);
+    audio[(int64_t)b * frames + t] = pretanh ? acc : tanhf(acc);
 }
 
 }  // namespace
@@ -180,7 +180,7 @@ int launch_head(hipStream_t s, const float* x, int batch, int frames, int c, con
     L3AC_REQUIRE(c % 4 == 0 && batch <= 65535, "head: bad shape");
     ProfScope prof(s, "head_kernel", 14.0 * c * batch * frames, 4.0 * (c + 1.0) * batch * frames);
     hipLaunchKernelGGL(head_kernel, dim3((unsigned)ceil_div64(frames, TILE), (unsigned)batch), dim3(TILE), 0, s, x, frames, c,
-                       w, b, audio);
+                       w, b, audio, head_pretanh_enabled() ? 1 : 0);
     L3AC_LAUNCH_CHECK();
     return L3AC_OK;
 }

@@ -37,6 +37,7 @@ struct FsqDev {
     int32_t* indices;
     float* level_indices;
     float* latents;
+    int act_in;  // the `latents` input already holds act = (tanh(lat) + 1) / 2 (SuperFSQ.quantize_act_value's argument)
 };
 
 // streamed once: non-temporal accesses keep the rows out of the way of L2 / MALL residents
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(THREADS) void fsq_kernel(const FsqDev p, const int 
         }
     };
     auto quantise = [&](float lat, int d) -> float {
-        const float act = (tanhf(lat) + 1.0f) * 0.5f;                 // fsq_act.py:39
+        const float act = p.act_in ? lat : (tanhf(lat) + 1.0f) * 0.5f;  // fsq_act.py:39
         return rintf(__fmul_rn(act, (float)(p.levels[d] - 1)));       // vq/fsq.py:59 (half-to-even)
     };
     fetch(g_begin);
@@ -284,6 +285,8 @@ int launch_fsq(hipStream_t s, const FsqArgs& a) {
     L3AC_REQUIRE(basis < (1 << 24), "fsq: codebook size %lld exceeds the exact fp32 index range", (long long)basis);
     p.w_in = a.w_in; p.b_in = a.b_in; p.w_out = a.w_out; p.b_out = a.b_out; p.idx_in = a.idx_in;
     p.q_feature = a.q_feature; p.indices = a.indices; p.level_indices = a.level_indices; p.latents = a.latents;
+    p.act_in = a.act_in ? 1 : 0;
+    if (a.act_in) L3AC_REQUIRE(!a.x && !a.idx_in && a.latents, "fsq: act_in needs the activation values in `latents` and no other input");
     switch (a.n_levels) {
         case 1: return launch_fsq_t<1>(s, p);
         case 2: return launch_fsq_t<2>(s, p);

@@ -383,7 +383,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void legacy_unit_split_kernel(const 
 // head: audio[t] = tanh(b + sum_{tap,c} w[tap][c] snake(x[t + tap - 3][c]))
 template <int C>
 __global__ __launch_bounds__(FRAMES) void head_fused_kernel(const HeadW w, const float* __restrict__ x, int frames,
-                                                           float* __restrict__ audio) {
+                                                           float* __restrict__ audio, const int pretanh) {
     constexpr int SS = C + 4;
     __shared__ __attribute__((aligned(16))) float Ss[(FRAMES + 6) * SS];
     __shared__ __attribute__((aligned(16))) float Ws[7 * C];
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(FRAMES) void head_fused_kernel(const HeadW w, const
             acc = fmaf(wv.w, sv.w, acc);
         }
     }
-    audio[(int64_t)b * frames + t] = tanhf(acc);
+    audio[(int64_t)b * frames + t] = pretanh ? acc : tanhf(acc);
 }
 
 template <int C>
@@ -460,7 +460,7 @@ int launch_head_t(hipStream_t s, const HeadW& w, const float* x, int batch, int 
     const double rows = (double)batch * frames;
     ProfScope prof(s, "head_fused_kernel", rows * (14.0 * C + 20.0 * C), rows * (4.0 * C + 4.0));
     hipLaunchKernelGGL((head_fused_kernel<C>), dim3((unsigned)ceil_div64(frames, FRAMES), (unsigned)batch), dim3(FRAMES), 0, s, w,
-                       x, frames, audio);
+                       x, frames, audio, head_pretanh_enabled() ? 1 : 0);
     L3AC_LAUNCH_CHECK();
     return L3AC_OK;
 }

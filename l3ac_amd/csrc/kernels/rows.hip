@@ -286,16 +286,34 @@ int launch_rows_t(hipStream_t s, const RowArgs& r, int lpr) {
 }
 
 // ---- elementwise -------------------------------------------------------------------------------
+// mode bit 0: evaluate with the two-elements-per-lane form (snake_act2 / sin_squared2) the GEMM epilogues and the fused
+// units use; bit 1: y = sin(x)^2 alone (alpha unused) instead of snake(x)
 __global__ __launch_bounds__(THREADS) void snake_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                        int64_t n4, int c4, const float* __restrict__ alpha,
-                                                       const float* __restrict__ inv_alpha) {
+                                                       const float* __restrict__ inv_alpha, const int mode) {
     for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * THREADS) {
         const int c0 = (int)(i % c4) << 2;
         const float4 v = reinterpret_cast<const float4*>(x)[i];
-        const float4 a = *reinterpret_cast<const float4*>(alpha + c0);
-        const float4 ia = *reinterpret_cast<const float4*>(inv_alpha + c0);
-        const float4 o = make_float4(snake_act(v.x, a.x, ia.x), snake_act(v.y, a.y, ia.y), snake_act(v.z, a.z, ia.z),
-                                     snake_act(v.w, a.w, ia.w));
+        float4 o;
+        if (mode & 2) {
+            if (mode & 1) {
+                const f32x2 lo = sin_squared2(f32x2{v.x, v.y}), hi = sin_squared2(f32x2{v.z, v.w});
+                o = make_float4(lo.x, lo.y, hi.x, hi.y);
+            } else {
+                o = make_float4(sin_squared(v.x), sin_squared(v.y), sin_squared(v.z), sin_squared(v.w));
+            }
+        } else {
+            const float4 a = *reinterpret_cast<const float4*>(alpha + c0);
+            const float4 ia = *reinterpret_cast<const float4*>(inv_alpha + c0);
+            if (mode & 1) {
+                const f32x2 lo = snake_act2(f32x2{v.x, v.y}, f32x2{a.x, a.y}, f32x2{ia.x, ia.y});
+                const f32x2 hi = snake_act2(f32x2{v.z, v.w}, f32x2{a.z, a.w}, f32x2{ia.z, ia.w});
+                o = make_float4(lo.x, lo.y, hi.x, hi.y);
+            } else {
+                o = make_float4(snake_act(v.x, a.x, ia.x), snake_act(v.y, a.y, ia.y), snake_act(v.z, a.z, ia.z),
+                                snake_act(v.w, a.w, ia.w));
+            }
+        }
         reinterpret_cast<float4*>(y)[i] = o;
     }
 }
@@ -421,12 +439,12 @@ int launch_rows(hipStream_t s, const RowArgs& r) {
 }
 
 int launch_snake(hipStream_t s, const float* x, float* y, int64_t rows, int c, const float* alpha,
-                 const float* inv_alpha) {
+                 const float* inv_alpha, int mode) {
     L3AC_REQUIRE(c % 4 == 0, "snake: c=%d must be a multiple of 4", c);
     const int64_t n4 = rows * (c / 4);
     if (n4 == 0) return L3AC_OK;
     ProfScope prof(s, "snake_kernel", 16.0 * n4, 32.0 * n4);
-    hipLaunchKernelGGL(snake_kernel, dim3(stream_grid(n4)), dim3(THREADS), 0, s, x, y, n4, c / 4, alpha, inv_alpha);
+    hipLaunchKernelGGL(snake_kernel, dim3(stream_grid(n4)), dim3(THREADS), 0, s, x, y, n4, c / 4, alpha, inv_alpha, mode);
     L3AC_LAUNCH_CHECK();
     return L3AC_OK;
 }

@@ -80,6 +80,30 @@ def gather_batch_async(local: torch.Tensor, total: int, group=None, force: bool 
     return PendingGather(out, work, src)
 
 
+class PendingGathers:
+    """The overlap loop of a stream of batches: each step pushes the gathers it has just issued and retires the ones of the
+    step before, so an exchange is in flight while the next batch is being encoded and at most one step's outputs wait.
+    `drain()` retires whatever is left (end of the stream, or before timing stops).  `results` keeps the last retired
+    step's gathered tensors."""
+
+    def __init__(self):
+        self._steps: list[tuple[PendingGather, ...]] = []
+        self.results: tuple[torch.Tensor, ...] = ()
+        self.retired = 0
+
+    def push(self, *handles: PendingGather) -> None:
+        self.drain()
+        self._steps.append(tuple(handles))
+
+    def drain(self) -> None:
+        while self._steps:
+            self.results = tuple(h.wait() for h in self._steps.pop(0))
+            self.retired += 1
+
+    def __len__(self) -> int:
+        return len(self._steps)
+
+
 class ShardedCodec:
     """Runs a codec (anything with `encode_audio` / `decode_audio`, e.g. `l3ac_amd.L3AC`) on this rank's slice of a
     batch that every rank holds, and returns the gathered full-batch outputs on every rank."""

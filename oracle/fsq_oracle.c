@@ -32,6 +32,25 @@ void fsq_oracle_quantize(const float* z, int64_t n, int32_t d, const int32_t* le
     }
 }
 
+/* the rounding half alone, from act = (tanh(z) + 1) / 2 (SuperFSQ.quantize_act_value, l3ac/vq/fsq.py:56-65, then :67-68, :21) */
+void fsq_oracle_quantize_act(const float* act, int64_t n, int32_t d, const int32_t* levels, float* q, int32_t* idx,
+                             float* level_indices) {
+    for (int64_t i = 0; i < n; ++i) {
+        float sum = 0.0f;
+        float basis = 1.0f;
+        for (int32_t k = 0; k < d; ++k) {
+            const float lm1 = (float)(levels[k] - 1);
+            const float li = rintf(act[i * d + k] * lm1);
+            const float q_act = li / lm1;
+            q[i * d + k] = q_act * 2.0f - 1.0f;
+            level_indices[i * d + k] = li;
+            sum += li * basis;
+            basis *= (float)levels[k];
+        }
+        idx[i] = (int32_t)sum;
+    }
+}
+
 void fsq_oracle_indices_to_codes(const int32_t* idx, int64_t n, int32_t d, const int32_t* levels, float* codes) {
     for (int64_t i = 0; i < n; ++i) {
         int32_t basis = 1;

@@ -324,18 +324,23 @@ def fsq_levels_basis(levels):
     return lv, basis
 
 
-def fsq_quantize(z, levels):
-    """vq/fsq.py:30-68 in eval mode (noise_rate -> 0).  z: (..., D) latents.
+def fsq_quantize_act(act, levels):
+    """vq/fsq.py:56-68 + :21 from the activation values: act (..., D) in [0, 1] (what tanh_act returns).
     Returns (q_z, indices int32, level_indices fp32)."""
     lv, basis = fsq_levels_basis(levels)
-    shape = z.shape
-    z = z.reshape(-1, shape[-1])
-    act = (torch.tanh(z) + 1) / 2  # fsq_act.py:38-39
+    shape = act.shape
+    act = act.reshape(-1, shape[-1])
     li = (act * (lv - 1)).round()  # :59 special_edge; torch.round = half-to-even
     q_act = li / (lv - 1)  # :60
     idx = (li * basis).sum(dim=-1).to(torch.int32)  # :67-68
     q_z = q_act * 2 - 1  # :21
     return q_z.reshape(shape), idx.reshape(shape[:-1]), li.reshape(shape)
+
+
+def fsq_quantize(z, levels):
+    """vq/fsq.py:30-68 in eval mode (noise_rate -> 0).  z: (..., D) latents.
+    Returns (q_z, indices int32, level_indices fp32)."""
+    return fsq_quantize_act((torch.tanh(z) + 1) / 2, levels)  # fsq_act.py:38-39
 
 
 def fsq_indices_to_codes(indices, levels):

@@ -221,10 +221,59 @@ def make_fsq_kat():
     print("[fsq_kat] written")
 
 
+@torch.inference_mode()
+def make_fsq_boundary_kat():
+    """Rounding-boundary known answers from the reference's own ``SuperFSQ.quantize_act_value`` (vq/fsq.py:56-65),
+    ``level_indices_to_indices`` (:67-68) and ``inv_act`` (:21), fed with activation values in [0, 1] (i.e. after
+    ``tanh_act``, fsq_act.py:38-39, so that no transcendental sits between the constructed input and the rounding):
+    for every level count L of a level set, every dimension and every k in [0, L-2], the fp32 value nearest to
+    (k + 0.5) / (L - 1) and its +-1 and +-2 ulp neighbours, all other dimensions held at a generic value.  The products
+    act * (L - 1) land exactly on k + 0.5 for some of them (torch.round goes half-to-even there) and one ulp to either
+    side for the rest."""
+    from l3ac.vq.fsq import SuperFSQ  # reference
+    out = {}
+    for tag, levels in (("l7", [7] * 6), ("l9977", [9, 9, 9, 7, 7, 7]), ("even", [2, 4, 6, 8]), ("tiny", [5, 3, 4])):
+        fsq = SuperFSQ(levels=levels).eval()
+        d = len(levels)
+        rows = []
+        for dim, L in enumerate(levels):
+            for k in range(L - 1):
+                centre = np.float32((k + 0.5) / (L - 1))
+                cand = [centre]
+                lo = hi = centre
+                for _ in range(2):
+                    lo = np.nextafter(lo, np.float32(-1.0), dtype=np.float32)
+                    hi = np.nextafter(hi, np.float32(2.0), dtype=np.float32)
+                    cand += [lo, hi]
+                for c in cand:
+                    row = np.full(d, 0.3137, dtype=np.float32)
+                    row[dim] = c
+                    rows.append(row)
+        act = torch.from_numpy(np.stack(rows))
+        q_act, li = fsq.quantize_act_value(act)
+        idx = fsq.level_indices_to_indices(li)
+        q = fsq.inv_act(q_act)
+        prod = act * (fsq.levels - 1)
+        n_tie = int(((prod - prod.floor()) == 0.5).any(dim=1).sum())
+        print(f"[fsq_boundary {tag}] {act.shape[0]} rows, {n_tie} with an exact k+0.5 product")
+        assert n_tie > 0
+        out[f"{tag}_levels"] = np.array(levels, dtype=np.int32)
+        out[f"{tag}_act"] = act.numpy()
+        out[f"{tag}_level_indices"] = li.numpy()
+        out[f"{tag}_indices"] = idx.numpy()
+        out[f"{tag}_q"] = q.numpy()
+    np.savez_compressed(HERE / "fsq_boundary_kat.npz", **out)
+    print("[fsq_boundary_kat] written")
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if "--boundary-only" in sys.argv:
+        make_fsq_boundary_kat()
+        sys.exit(0)
     make_fsq_kat()
+    make_fsq_boundary_kat()
     make_model_fixtures("tiny", HERE / "tiny.toml", seed=3, batch=2, samples=250, full_tensors=True)
     make_model_fixtures("1kbps", resolve_config_file("1kbps"), seed=0, batch=2, samples=16000, full_tensors=False)
     make_model_fixtures("3kbps", resolve_config_file("3kbps"), seed=0, batch=2, samples=16000, full_tensors=False)

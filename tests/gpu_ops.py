@@ -70,6 +70,22 @@ def fsq_forward(x, levels, w_in, b_in, w_out, b_out, latents_in=None, want_laten
     return q, idx, li, lat
 
 
+def fsq_quantize_act(act, levels, w_out, b_out):
+    """SuperFSQ.quantize_act_value onwards (vq/fsq.py:56-68), from activation values in [0, 1]."""
+    lib = _capi.load_library()
+    dev = w_out.device
+    feat, d = w_out.shape[0], len(levels)
+    act = act.reshape(-1, d).contiguous()
+    n = act.shape[0]
+    q = torch.empty((n, feat), dtype=torch.float32, device=dev)
+    idx = torch.empty((n,), dtype=torch.int32, device=dev)
+    li = torch.empty((n, d), dtype=torch.float32, device=dev)
+    _capi.check(lib.l3ac_fsq_quantize_act(act.data_ptr(), n, feat, (C.c_int32 * d)(*levels), d, w_out.data_ptr(), b_out.data_ptr(),
+                                          q.data_ptr(), idx.data_ptr(), li.data_ptr(), _stream(dev)))
+    torch.cuda.synchronize()
+    return q, idx, li
+
+
 def fsq_decode(indices, levels, w_out, b_out):
     lib = _capi.load_library()
     dev = w_out.device
@@ -119,3 +135,13 @@ def gemm_split(a, w, bias):
                                         c.data_ptr(), n, m, n, k, _stream(a.device)))
     torch.cuda.synchronize()
     return c
+
+
+def snake(x, alpha, mode=0):
+    """l3ac_op_snake: x [rows][c], alpha [c]; mode bit 0 = packed form, bit 1 = sin(x)^2 only."""
+    lib = _capi.load_library()
+    rows, c = x.shape
+    y = torch.empty_like(x)
+    _capi.check(lib.l3ac_op_snake(x.data_ptr(), y.data_ptr(), rows, c, alpha.data_ptr(), mode, _stream(x.device)))
+    torch.cuda.synchronize()
+    return y

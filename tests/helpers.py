@@ -54,3 +54,31 @@ def index_mismatch_report(idx, idx_ref, latents_ref, levels, tau):
             if abs(li[d] - li_ref[d]) != 1 or margin[d] > tau:
                 ok = False
     return int(bad.size), ok
+
+
+def index_agreement(idx, idx_ref, latents_ref, levels):
+    """Full accounting of quantiser-index agreement against the oracle: every token compared, and for every mismatch
+    the distance of the responsible latent from its rounding boundary, |frac(act * (L - 1)) - 0.5| in level units
+    (evaluated in fp64 from the ORACLE's latents).  `single_step` is False if any mismatching token differs by more than
+    one level in some dimension."""
+    idx = np.asarray(idx).reshape(-1).astype(np.int64)
+    idx_ref = np.asarray(idx_ref).reshape(-1).astype(np.int64)
+    lv = np.asarray(levels, dtype=np.int64)
+    basis = np.concatenate([[1], np.cumprod(lv[:-1])])
+    lat = np.asarray(latents_ref, dtype=np.float64).reshape(-1, len(lv))
+    bad = np.nonzero(idx != idx_ref)[0]
+    max_margin, single = 0.0, True
+    for r in bad:
+        li = (idx[r] // basis) % lv
+        li_ref = (idx_ref[r] // basis) % lv
+        scaled = (np.tanh(lat[r]) + 1) / 2 * (lv - 1)
+        margin = np.abs(np.abs(scaled - np.floor(scaled)) - 0.5)
+        for d in np.nonzero(li != li_ref)[0]:
+            single = single and abs(int(li[d]) - int(li_ref[d])) == 1
+            max_margin = max(max_margin, float(margin[d]))
+    # how close the batch's latents come to a boundary at all (context for the mismatch count)
+    scaled = (np.tanh(lat) + 1) / 2 * (lv - 1)
+    margins = np.abs(np.abs(scaled - np.floor(scaled)) - 0.5)
+    return {"tokens": int(idx.size), "mismatches": int(bad.size), "max_margin_of_mismatches": max_margin,
+            "single_step": bool(single), "decisions_within_1e-4": int((margins < 1e-4).sum()),
+            "decisions_within_1e-5": int((margins < 1e-5).sum()), "min_margin": float(margins.min())}

@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from l3ac_amd.dist import ShardedCodec, gather_batch, gather_batch_async, shard_range
+from l3ac_amd.dist import PendingGathers, ShardedCodec, gather_batch, gather_batch_async, shard_range
 
 
 def test_shard_ranges_partition_the_batch():
@@ -61,6 +61,16 @@ def _worker(rank, world, port, total, queue):
         h2 = gather_batch_async((full * 2)[start:stop].to(torch.int64), total)
         ok = ok and torch.equal(h2.wait(), (full * 2).to(torch.int64)) and torch.equal(h1.wait(), full)
         ok = ok and torch.equal(h1.wait(), full)  # waiting twice is harmless
+        # bench.py's overlap loop: every step pushes its two gathers and retires the previous step's pair; drain at the end
+        if total % world == 0:
+            pend = PendingGathers()
+            for step in range(4):
+                pend.push(gather_batch_async(full[start:stop] + step, total), gather_batch_async((full[start:stop] * step).to(torch.int32), total))
+                ok = ok and len(pend) == 1 and pend.retired == step
+                if step:
+                    ok = ok and torch.equal(pend.results[0], full + (step - 1)) and torch.equal(pend.results[1], (full * (step - 1)).to(torch.int32))
+            pend.drain()
+            ok = ok and len(pend) == 0 and pend.retired == 4 and torch.equal(pend.results[0], full + 3)
         queue.put((rank, bool(ok), tuple(idx.shape), tuple(wave.shape)))
     finally:
         dist.destroy_process_group()

@@ -82,6 +82,84 @@ def test_gemm_split_accuracy():
         assert es.pow(2).mean().sqrt().item() <= 1.05 * ef.pow(2).mean().sqrt().item() + 1e-9
 
 
+def test_gemm_split_cancellation_and_underflow():
+    """Adversarial operands for the bf16x3 split GEMM, with an ABSOLUTE bound per output: |err| <= 2^-23 * sum|a.w|
+    (what a k-ordered fp32 chain guarantees for these lengths), plus — only where operands sit within 2^16 of the bottom of
+    the fp32 range, so that their lower planes leave the bf16 normal range — K * 2^-126 * max|w|.
+      * cancellation: every dot product is ~0 while its terms are O(1): pairs (k, k + K/2) cancel to the last bit or two;
+      * mixed magnitudes: a few O(1e4) terms over a floor of O(1e-4) ones;
+      * small operands: a ~ 1e-30 (all three planes still normal bf16 numbers: exact) and a ~ 1e-37 (x1 / x2 planes are
+        bf16 subnormals or zero)."""
+    g = torch.Generator().manual_seed(21)
+    cases = []
+    m, n, k = 512, 256, 1024
+    w = torch.randn(n, k, generator=g) * 0.1
+    a = torch.randn(m, k, generator=g)
+    # cancellation is per (row, column) pair, so build it on the weights: w[:, k + K/2] = -w[:, k] and a[:, k + K/2] ~ a[:, k]
+    wc = w.clone()
+    wc[:, k // 2:] = -wc[:, :k // 2]
+    ac = a.clone()
+    ac[:, k // 2:] = ac[:, :k // 2] * (1 + 2.0 ** -20 * torch.randn(m, k // 2, generator=g))
+    cases.append(("cancellation", ac, wc, 0.0))
+    am = torch.randn(m, k, generator=g) * 1e-4
+    am[:, ::97] = torch.randn(m, len(range(0, k, 97)), generator=g) * 1e4
+    cases.append(("mixed magnitudes", am, w, 0.0))
+    cases.append(("a ~ 1e-30", a * 1e-30, w, 0.0))
+    cases.append(("a ~ 1e-37", a * 1e-37, w, k * 2.0 ** -126 * float(w.abs().max())))
+    cases.append(("w ~ 1e-30", a, w * 1e-30, 0.0))
+    for name, aa, ww, floor in cases:
+        ref = aa.double() @ ww.double().T
+        mag = aa.abs().double() @ ww.abs().double().T
+        got = G.gemm_split(aa.cuda(), ww.cuda(), None).cpu().double()
+        got_f = G.gemm(aa.cuda(), ww.cuda(), None).cpu().double()
+        err, err_f = (got - ref).abs(), (got_f - ref).abs()
+        bound = 2.0 ** -23 * mag + floor
+        print(f"[gemm_split {name}] max err/bound {float((err / bound.clamp_min(1e-300)).max()):.3f} "
+              f"(fp32 mfma: {float((err_f / bound.clamp_min(1e-300)).max()):.3f}); max|ref|/max mag {float(ref.abs().max() / mag.max()):.2e}")
+        assert torch.isfinite(got).all()
+        assert (err <= bound).all(), name
+
+
+def test_sin_squared_range():
+    """The kernels' own sin^2 (device_math.hpp) against fp64: |err| <= 2e-7 for |u| <= 1e5 in both the scalar and the
+    packed form; beyond that the argument is clamped (documented guard): the value stays in [0, 1] and snake(x) is within
+    1e-5 relative of the exact activation; NaN stays NaN, no integer overflow garbage."""
+    g = torch.Generator().manual_seed(31)
+    u = torch.cat([torch.linspace(-40, 40, 20000), torch.logspace(-6, 5, 40000), -torch.logspace(-6, 5, 40000),
+                   (torch.rand(100000, generator=g) * 2 - 1) * 1e5, torch.tensor([0.0, 1e5, -1e5, 99999.99, 3.14159274, 1.57079637])])
+    u = u[: u.numel() // 4 * 4].reshape(-1, 4).float().contiguous()
+    alpha = torch.ones(4).cuda()
+    ref = torch.sin(u.double()).pow(2)
+    for mode in (2, 3):
+        got = G.snake(u.cuda(), alpha, mode).cpu().double()
+        err = (got - ref).abs().max().item()
+        print(f"[sin^2 mode {mode}] max |err| vs fp64 over |u| <= 1e5: {err:.3e}")
+        assert err <= 2e-7
+    # beyond the range: bounded, finite, and harmless for the activation
+    big = torch.tensor([1.0001e5, 3e5, 1e7, 2.6e7, 1e9, 3e9, 1e20, 3.4e38, -1e6, -5e9, -3.4e38, 123456.789]).reshape(-1, 4).float()
+    for mode in (2, 3):
+        got = G.snake(big.cuda(), alpha, mode).cpu()
+        assert torch.isfinite(got).all() and (got >= 0).all() and (got <= 1).all()
+    a = torch.tensor([0.5, 1.0, 2.7, 10.0])
+    big = big.clamp(-1e30, 1e30)  # keep alpha * x finite
+    for mode in (0, 1):
+        got = G.snake(big.cuda(), a.cuda(), mode).cpu().double()
+        exact = big.double() + (a + 1e-8).reciprocal().double() * torch.sin((a * big).double()).pow(2)
+        rel = ((got - exact).abs() / exact.abs()).max().item()
+        print(f"[snake mode {mode}] max relative error beyond the guard: {rel:.3e}")
+        assert rel <= 1e-5
+    nan = torch.tensor([float("nan"), float("inf"), -float("inf"), 1.0]).reshape(1, 4)
+    for mode in (0, 1):
+        got = G.snake(nan.cuda(), alpha, mode).cpu()
+        assert torch.isnan(got[0, 0]) and torch.isinf(got[0, 1]) and torch.isinf(got[0, 2]) and torch.isfinite(got[0, 3])
+    # ordinary activations: snake itself against the oracle's formula, both forms
+    x = _rand((4096, 64), 77, 3.0)
+    al = (torch.rand(64, generator=g) * 3 + 0.05)
+    ref = O.snake(x, al)
+    for mode in (0, 1):
+        _close(f"snake mode {mode}", G.snake(x.cuda(), al.cuda(), mode).cpu(), ref, atol=1e-6, rtol=1e-6)
+
+
 def test_first_block(tiny, full):
     for codec, mc, w in (tiny, full):
         x = seeded_audio(2, 1000)
@@ -203,6 +281,21 @@ def test_fsq_known_answers_and_exactness():
         ref = codes @ w_out.cpu().T + b_out.cpu()
         got = G.fsq_decode(sel.cuda(), levels, w_out, b_out)
         _close(f"fsq_decode {tag}", got.cpu(), ref, atol=1e-6, rtol=1e-6)
+    # rounding boundaries themselves, with no transcendental in between (tests/golden/fsq_boundary_kat.npz, reference answers from
+    # SuperFSQ.quantize_act_value): products exactly k + 0.5 and their +-1 / +-2 ulp neighbours must agree BIT FOR BIT
+    bk = np.load(GOLDEN / "fsq_boundary_kat.npz")
+    for tag, feat in (("l7", 128), ("l9977", 128), ("even", 16), ("tiny", 16)):
+        levels = bk[f"{tag}_levels"].tolist()
+        d = len(levels)
+        g = torch.Generator().manual_seed(6)
+        w_out = (torch.rand(feat, d, generator=g) - 0.5).cuda()
+        b_out = (torch.rand(feat, generator=g) - 0.5).cuda()
+        act = torch.from_numpy(bk[f"{tag}_act"])
+        q, idx, li = G.fsq_quantize_act(act.cuda(), levels, w_out, b_out)
+        np.testing.assert_array_equal(li.cpu().numpy(), bk[f"{tag}_level_indices"])
+        np.testing.assert_array_equal(idx.cpu().numpy(), bk[f"{tag}_indices"])
+        ref_q = torch.from_numpy(bk[f"{tag}_q"]) @ w_out.cpu().T + b_out.cpu()
+        _close(f"fsq boundary q_feature {tag}", q.cpu(), ref_q, atol=1e-6, rtol=1e-6)
     # exact ties: tanh(0) = 0 -> 0.5, 1.5, 2.5, 3.5 round half-to-even to 0, 2, 2, 4 (torch.round semantics)
     w_out = torch.zeros(8, 4).cuda()
     b_out = torch.zeros(8).cuda()

@@ -8,11 +8,11 @@ import l3ac_amd
 from l3ac_amd import weights as W
 from oracle import l3ac_oracle as O
 from tests import gpu_ops as G
-from tests.helpers import GOLDEN, index_mismatch_report, load_case, seeded_audio, strided
+from tests.helpers import GOLDEN, index_agreement, index_mismatch_report, load_case, seeded_audio, strided
 
 pytestmark = pytest.mark.gpu
 
-TAU = 2e-3        # a flipped index must come from a latent within TAU of a rounding boundary (in level units)
+TAU = 1e-4        # a flipped index must come from a latent within TAU of a rounding boundary (in level units)
 WAVE_ATOL = 2e-3  # waveform tolerance (tanh output in [-1, 1]) for the decoder given identical indices
 FEAT_ATOL = 5e-4  # encoder / transformer feature tolerance, activations O(1)
 
@@ -82,7 +82,7 @@ def test_encode_decode_against_oracle(tag, seed, batch, samples):
     total = batch * n_tok
     print(f"[{tag} B={batch} T={samples}] index mismatches vs oracle: {n_bad}/{total}")
     assert ok, "an index differs by more than one level or away from a rounding boundary"
-    assert n_bad <= max(1, total // 50)
+    assert n_bad <= 1  # observed on every case: 0
     # decoder, given the ORACLE's indices: waveform within tolerance
     wave_ref = O.decode_audio(w, mc, indices=ind_ref["indices"])
     wave = codec.decode_audio(indices=ind_ref["indices"].cuda())
@@ -115,7 +115,7 @@ def test_against_committed_reference_vectors(tag, gemm_mode):
     lat = O.encode_audio(w, mc, audio, taps=(taps := {})) and taps["latents"]
     n_bad, ok = index_mismatch_report(ind["indices"].cpu().numpy(), e2e["indices"], lat.numpy(), mc.levels, TAU)
     print(f"[{tag}] index mismatches vs reference vectors: {n_bad}/{e2e['indices'].size}")
-    assert ok and n_bad <= max(1, e2e["indices"].size // 50)
+    assert ok and n_bad <= 1  # observed: 0
     wave = codec.decode_audio(indices=torch.from_numpy(e2e["indices"]).cuda()).cpu()
     if tag == "tiny":
         np.testing.assert_allclose(wave.numpy(), e2e["wave"], atol=WAVE_ATOL)
@@ -194,7 +194,99 @@ def test_full_batch_properties_1kbps():
     taps = {}
     _, ind_ref = O.encode_audio(w, mc, audio[sel].cpu(), taps=taps)
     n_bad, ok = index_mismatch_report(idx[sel].cpu().numpy(), ind_ref["indices"].numpy(), taps["latents"].numpy(), mc.levels, TAU)
-    assert ok and n_bad <= 4
+    assert ok and n_bad <= 1  # observed: 0
+
+
+ORACLE_CHUNK = 32  # clips per oracle call (host memory: the unfused CPU path holds ~25 MB per clip-second)
+
+
+def _oracle_indices(w, mc, audio):
+    idx, lat = [], []
+    for b0 in range(0, audio.shape[0], ORACLE_CHUNK):
+        taps = {}
+        _, ind = O.encode_audio(w, mc, audio[b0:b0 + ORACLE_CHUNK], taps=taps)
+        idx.append(ind["indices"])
+        lat.append(taps["latents"])
+    return torch.cat(idx), torch.cat(lat)
+
+
+# mismatches observed on the MI355X for these exact batches (seed 1234, synthetic weights seed 0), both GEMM routes
+OBSERVED_FULL_BATCH_MISMATCHES = {"1kbps": 0, "3kbps": 0}
+
+
+@pytest.mark.parametrize("tag", ["1kbps", "3kbps"])
+def test_index_agreement_full_batch(tag):
+    """Every token of the BASELINE batches (config 2: 1kbps 256 x 1 s = 15 360 tokens; config 3: 3kbps 256 x 1 s = 42 752
+    tokens) against the oracle, on both GEMM routes.  A mismatch is tolerated only as a single-level flip of a latent within
+    TAU = 1e-4 level units of its rounding boundary, and the count may not exceed the observed one by more than 1."""
+    codec = _codec(tag, 0)
+    mc = codec.network.mc
+    w = W.folded_weights(codec.network.state_dicts())
+    audio = seeded_audio(256, 16000)
+    idx_ref, lat_ref = _oracle_indices(w, mc, audio)
+    before = l3ac_amd.get_gemm_split()
+    try:
+        for route in (True, False):
+            l3ac_amd.set_gemm_split(route)
+            _, ind = codec.encode_audio(audio.cuda())
+            rep = index_agreement(ind["indices"].cpu().numpy(), idx_ref.numpy(), lat_ref.numpy(), mc.levels)
+            print(f"[index agreement {tag} {'split' if route else 'exact'}] {rep}")
+            assert rep["tokens"] == 256 * (-(-16000 // mc.hop_length))
+            assert rep["single_step"] and rep["max_margin_of_mismatches"] < TAU
+            assert rep["mismatches"] <= OBSERVED_FULL_BATCH_MISMATCHES[tag] + 1
+    finally:
+        l3ac_amd.set_gemm_split(before)
+
+
+def test_batch_invariance_3kbps_256():
+    """3kbps at the BASELINE batch: the clip-group scheduling of the wide stages depends on the geometry (T = 167 / 668 /
+    2672 frames), so batch invariance is asserted here as well as for 1kbps."""
+    codec = _codec("3kbps", 0)
+    mc = codec.network.mc
+    audio = seeded_audio(256, 16000).cuda()
+    q, ind = codec.encode_audio(audio)
+    idx = ind["indices"]
+    assert idx.shape == (256, 167) and int(idx.min()) >= 0 and int(idx.max()) < mc.codebook_size
+    wave = codec.decode_audio(q)
+    assert wave.shape == (256, 16032) and torch.isfinite(wave).all() and float(wave.abs().max()) <= 1.0
+    for b in (0, 51, 52, 130, 255):  # clips on both sides of the clip-group boundaries
+        q1, ind1 = codec.encode_audio(audio[b:b + 1])
+        assert torch.equal(ind1["indices"], idx[b:b + 1]) and torch.equal(q1, q[b:b + 1])
+        assert torch.equal(codec.decode_audio(q1), wave[b:b + 1])
+    q64, ind64 = codec.encode_audio(audio[64:128])
+    assert torch.equal(ind64["indices"], idx[64:128]) and torch.equal(codec.decode_audio(q64), wave[64:128])
+
+
+def test_decoder_before_tanh_full_size():
+    """The tanh output saturates with the synthetic weights (|wave| reaches 1.0), which hides pre-tanh error.  With the
+    l3ac_set_head_pretanh test hook the head stores the Conv1d(24 -> 1, k7) result itself: compared here at full clip size
+    against the oracle's pre-tanh value, relative to the size of the signal."""
+    from l3ac_amd import _capi
+    codec = _codec("1kbps", 0)
+    mc = codec.network.mc
+    w = W.folded_weights(codec.network.state_dicts())
+    audio = seeded_audio(4, 16000)
+    _, ind_ref = O.encode_audio(w, mc, audio)
+    wave_ref = O.decode_audio(w, mc, indices=ind_ref["indices"]).double()
+    clipped = wave_ref.abs() > 0.999
+    pre_ref = torch.atanh(wave_ref.clamp(-0.999, 0.999))  # where the oracle's tanh has not saturated, atanh recovers its input
+    lib = _capi.load_library()
+    lib.l3ac_set_head_pretanh(1)
+    try:
+        pre = codec.decode_audio(indices=ind_ref["indices"].cuda()).cpu().double()
+    finally:
+        lib.l3ac_set_head_pretanh(0)
+    wave = codec.decode_audio(indices=ind_ref["indices"].cuda()).cpu().double()
+    assert torch.equal(torch.tanh(pre.float()).double(), wave) or (torch.tanh(pre) - wave).abs().max() < 1e-6
+    ok = ~clipped
+    err = (pre - pre_ref)[ok].abs()
+    scale = pre_ref[ok].abs().clamp_min(1.0)
+    print(f"[pre-tanh] unsaturated samples {int(ok.sum())}/{ok.numel()}, max|pre|={float(pre.abs().max()):.2f}, "
+          f"max err {float(err.max()):.3e}, max err/scale {float((err / scale).max()):.3e}, rms {float(err.pow(2).mean().sqrt()):.3e}")
+    assert ok.float().mean() > 0.5
+    assert float((err / scale).max()) < 2e-3
+    # saturated samples: the pre-tanh value must be large with the right sign
+    assert (pre[clipped].sign() == wave_ref[clipped].sign()).all() and (pre[clipped].abs() > 3.0).all()
 
 
 def test_batch_2048_on_one_gpu():
@@ -227,7 +319,7 @@ def test_edge_cases():
     _, ind_ref = O.encode_audio(w, mc, silent, taps=taps)
     q, ind = codec.encode_audio(silent.cuda())
     n_bad, ok = index_mismatch_report(ind["indices"].cpu().numpy(), ind_ref["indices"].numpy(), taps["latents"].numpy(), mc.levels, TAU)
-    assert ok and n_bad <= 1
+    assert ok and n_bad <= 1  # observed: 0
     wave = codec.decode_audio(indices=ind_ref["indices"].cuda())
     assert _err("silence wave", wave, O.decode_audio(w, mc, indices=ind_ref["indices"])) < WAVE_ATOL
     # full-scale input, and a non-contiguous view
@@ -236,7 +328,7 @@ def test_edge_cases():
     taps = {}
     _, ind_ref = O.encode_audio(w, mc, loud, taps=taps)
     n_bad, ok = index_mismatch_report(ind["indices"].cpu().numpy(), ind_ref["indices"].numpy(), taps["latents"].numpy(), mc.levels, TAU)
-    assert ok and n_bad <= 2
+    assert ok and n_bad <= 1  # observed: 0
     big = seeded_audio(4, 6001).cuda()
     view = big[::2, 1:6001]
     qa, ia = codec.encode_audio(view)
@@ -274,7 +366,7 @@ def test_long_clip_multi_window_attention():
     n_bad, ok = index_mismatch_report(ind["indices"].cpu().numpy(), ind_ref["indices"].numpy(), taps["latents"].numpy(),
                                       mc.levels, TAU)
     print(f"[long clip] index mismatches vs oracle: {n_bad}/{ind_ref['indices'].numel()}")
-    assert ok and n_bad <= 8
+    assert ok and n_bad <= 1  # observed: 0
     wave = codec.decode_audio(indices=ind_ref["indices"].cuda())
     assert _err("long clip wave", wave, O.decode_audio(w, mc, indices=ind_ref["indices"])) < WAVE_ATOL
 

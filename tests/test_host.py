@@ -150,3 +150,44 @@ def test_bf16x3_split_is_exact():
     assert np.array_equal(p[0], bf16_rne(x)) and np.array_equal(p[1], bf16_rne(r1)) and np.array_equal(p[2], bf16_rne(r2))
     ax = np.abs(x).astype(np.float64)
     assert np.all(np.abs(p[1]) <= ax * 2.0 ** -8) and np.all(np.abs(p[2]) <= ax * 2.0 ** -16)
+
+
+def test_macs_match_the_survey_and_model_info_reports_them():
+    """SURVEY.md Appendix A (probed on the reference): 3 831.3 MMAC conv/linear per 1 s clip at 1kbps, 3 365.8 at 3kbps;
+    get_model_info (reference l3ac/__init__.py:28-51) carries the count for its 10 s default."""
+    import l3ac_amd
+    from l3ac_amd.config import L3ACConfig, resolve_config_file
+    from l3ac_amd.macs import path_macs
+    for tag, mmac in (("1kbps", 3831.3), ("3kbps", 3365.8)):
+        mc = L3ACConfig(config_file=resolve_config_file(tag)).network_config
+        m = path_macs(mc, 16000)
+        assert abs(m["conv_linear"] / 1e6 - mmac) < 0.06, (tag, m)
+        assert m["total"] == m["conv_linear"] + m["transformer_linear"] + m["attention"]
+    codec = l3ac_amd.get_model("1kbps", synthetic_seed=0)
+    info = l3ac_amd.get_model_info(codec.network)
+    assert set(info) >= {"macs", "params", "codebook_size", "frame_rate", "bps", "receptive_field"}
+    assert info["macs"] == path_macs(codec.network.mc, 160000)["total"]
+    assert info["codebook_size"] == 117649 and abs(info["bps"] - 998.2) < 0.1 and abs(info["frame_rate"] - 59.26) < 0.01
+    assert info["macs"] == l3ac_amd.get_model_info(codec)["macs"]  # the codec itself is accepted too
+
+
+def test_traffic_summary_is_tied_to_the_kernel_sources(tmp_path):
+    """bench.py attaches profiles/*/traffic.json only when it was collected on this build's kernel sources."""
+    import json
+
+    import bench
+    roof = {"kernel": "gemm_split_kernel"}
+    t = {"source_sha256": bench.source_fingerprint(), "workload": "1kbps b256 s16000 split",
+         "kernels": {"gemm_split_kernel<false>": {"launches": 2, "hbm_bytes_per_launch_corrected": 100.0},
+                     "gemm_split_kernel<true>": {"launches": 2, "hbm_bytes_per_launch_corrected": 300.0}}}
+    (tmp_path / "traffic.json").write_text(json.dumps(t))
+    bench.attach_traffic(roof, tmp_path, "1kbps b256 s16000 split")
+    assert roof["traffic"] == 200.0 and roof["traffic_stale"] is False
+    t["source_sha256"] = "0" * 16
+    (tmp_path / "traffic.json").write_text(json.dumps(t))
+    roof = {"kernel": "gemm_split_kernel"}
+    bench.attach_traffic(roof, tmp_path, "1kbps b256 s16000 split")
+    assert roof["traffic"] is None and roof["traffic_stale"] is True and roof["traffic_of_stale_profile"] == 200.0
+    roof = {"kernel": "gemm_split_kernel"}
+    bench.attach_traffic(roof, tmp_path, "3kbps b256 s16000 split")  # another workload: not attached at all
+    assert roof["traffic"] is None and "traffic_stale" not in roof

@@ -52,6 +52,23 @@ def test_c_fsq_matches_reference_vectors(lib):
     assert li.tolist() == [[0.0, 2.0, 2.0, 4.0]] and idx.tolist() == [212]
 
 
+def test_c_fsq_rounding_boundaries_bit_exact(lib):
+    """tests/golden/fsq_boundary_kat.npz: exact k + 0.5 products and their +-1 / +-2 ulp neighbours, answers from the
+    reference's SuperFSQ.quantize_act_value.  No transcendental is involved, so the C restatement must agree bit for bit."""
+    kat = np.load(GOLDEN / "fsq_boundary_kat.npz")
+    for tag in ("l7", "l9977", "even", "tiny"):
+        levels = kat[f"{tag}_levels"].tolist()
+        act = np.ascontiguousarray(kat[f"{tag}_act"], dtype=np.float32)
+        n, d = act.shape
+        q, li = np.empty_like(act), np.empty_like(act)
+        idx = np.empty(n, dtype=np.int32)
+        lib.fsq_oracle_quantize_act(act.ctypes.data_as(C.c_void_p), C.c_int64(n), d, (C.c_int32 * d)(*levels),
+                                    q.ctypes.data_as(C.c_void_p), idx.ctypes.data_as(C.c_void_p), li.ctypes.data_as(C.c_void_p))
+        np.testing.assert_array_equal(li, kat[f"{tag}_level_indices"])
+        np.testing.assert_array_equal(idx, kat[f"{tag}_indices"])
+        np.testing.assert_array_equal(q, kat[f"{tag}_q"])
+
+
 def test_c_argmin_agrees_with_closed_form(lib):
     levels = [5, 3, 4]
     g = torch.Generator().manual_seed(3)

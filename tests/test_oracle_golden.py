@@ -7,7 +7,7 @@ from oracle import l3ac_oracle as O
 from tests.helpers import GOLDEN, index_mismatch_report, load_case, seeded_audio, strided
 
 ATOL, RTOL = 2e-5, 2e-5  # fp32 conv stacks on a different host CPU may pick other mkldnn kernels
-TAU = 1e-3
+TAU = 1e-4  # level units; a flipped index must come from a latent this close to its rounding boundary
 
 
 def _check(name, got, fx, full):
@@ -33,7 +33,7 @@ def test_conv_stacks_and_quantizer_match_reference(tag):
         q_feat, ind, lat = O.quantizer(w, mc, feature.permute(0, 2, 1))
         _check("latents", lat, conv, full)
         n_bad, ok = index_mismatch_report(ind["indices"], conv["indices"], conv["latents"] if full else lat, mc.levels, TAU)
-        assert ok and n_bad <= 2, f"{n_bad} index mismatches"
+        assert ok and n_bad <= 1, f"{n_bad} index mismatches"  # observed in the build container: 0
         if n_bad == 0:
             np.testing.assert_array_equal(ind["level_indices"].numpy(), conv["level_indices"])
             _check("q_feat", q_feat, conv, full)
@@ -75,7 +75,7 @@ def test_end_to_end_wiring_matches_reference(tag):
     _check("trans", taps["en_encoder.out"], e2e, full)
     _check("latents", taps["latents"], e2e, full)
     n_bad, ok = index_mismatch_report(ind["indices"], e2e["indices"], taps["latents"], mc.levels, TAU)
-    assert ok and n_bad <= 2
+    assert ok and n_bad <= 1  # observed in the build container: 0
     wave = O.decode_audio(w, mc, indices=torch.from_numpy(e2e["indices"]))
     _check("wave", wave, e2e, full)
     if n_bad == 0:
@@ -115,3 +115,17 @@ def test_fsq_known_answers():
     # half-to-even at exact ties: tanh(0) = 0 -> act = 0.5 -> 0.5, 1.5, 2.5, 3.5 -> 0, 2, 2, 4
     _, _, li = O.fsq_quantize(torch.zeros(1, 4), [2, 4, 6, 8])
     assert li.tolist() == [[0.0, 2.0, 2.0, 4.0]]
+
+
+def test_fsq_rounding_boundaries():
+    """Exact k + 0.5 products and their +-1 / +-2 ulp neighbours (reference answers: SuperFSQ.quantize_act_value)."""
+    kat = np.load(GOLDEN / "fsq_boundary_kat.npz")
+    for tag in ("l7", "l9977", "even", "tiny"):
+        levels = kat[f"{tag}_levels"].tolist()
+        q, idx, li = O.fsq_quantize_act(torch.from_numpy(kat[f"{tag}_act"]), levels)
+        np.testing.assert_array_equal(li.numpy(), kat[f"{tag}_level_indices"])
+        np.testing.assert_array_equal(idx.numpy(), kat[f"{tag}_indices"])
+        np.testing.assert_array_equal(q.numpy(), kat[f"{tag}_q"])
+        # the fixture really sits on the boundaries: some products are exactly k + 0.5, and both roundings occur
+        prod = kat[f"{tag}_act"] * (np.asarray(levels, dtype=np.float32) - 1)
+        assert ((prod - np.floor(prod)) == 0.5).any()

@@ -9,4 +9,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B > $OUT/
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $B > /dev/null 2> $OUT/pmc_fetch_err.txt
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $B > /dev/null 2> $OUT/pmc_write_err.txt
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_sq -- $B > /dev/null 2> $OUT/pmc_sq_err.txt
+python3 -c "import sys; sys.path.insert(0, '$GRAFT_REPO_ROOT'); from bench import source_fingerprint; print(source_fingerprint())" > $OUT/source_sha256.txt
 find $OUT -name "*.csv" | head -20

@@ -7,7 +7,10 @@
                        /opt/skills/guides/MI355X_MICROARCH.md §HBM prescribes; WRITE_SIZE is exact)
     mfma_util.json     per kernel: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles), effective clock
 
-usage: tools/summarize_profiles.py gpurun_out/prof2 profiles/r01
+traffic.json is stamped with the fingerprint of the kernel sources it was collected on (bench.py: source_fingerprint) and
+the workload key; bench.py attaches it as roofline.traffic only while both still match, and says `traffic_stale` otherwise.
+
+usage: tools/summarize_profiles.py gpurun_out/prof2 profiles/r02 ["1kbps b256 s16000 split"]
 """
 import collections
 import csv
@@ -27,8 +30,12 @@ def load(pattern):
     return list(csv.DictReader(open(files[0]))) if files else []
 
 
-def main(src, dst):
+def main(src, dst, workload="1kbps b256 s16000 split"):
     src, dst = Path(src), Path(dst)
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    from bench import source_fingerprint
+    fp_file = src / "source_sha256.txt"  # written on the GPU box by collect_profiles.sh (same snapshot as the run)
+    fingerprint = fp_file.read_text().strip() if fp_file.exists() else source_fingerprint()
     dst.mkdir(parents=True, exist_ok=True)
     stats = glob.glob(str(src / "trace/*/*_kernel_stats.csv"))
     if stats:
@@ -55,7 +62,7 @@ def main(src, dst):
         traffic[name] = dict(launches=k["launches"], fetch_size_bytes_per_launch=fetch, write_size_bytes_per_launch=write,
                              hbm_bytes_per_launch_corrected=2 * fetch + write)
     json.dump(dict(note="FETCH_SIZE doubled (gfx950 wide-read correction), WRITE_SIZE as reported; averages per launch",
-                   kernels=traffic), open(dst / "traffic.json", "w"), indent=1)
+                   source_sha256=fingerprint, workload=workload, kernels=traffic), open(dst / "traffic.json", "w"), indent=1)
     sq = collections.defaultdict(lambda: collections.defaultdict(float))
     for r in load(str(src / "pmc_sq/*/*_counter_collection.csv")):
         d = sq[short(r["Kernel_Name"])]
@@ -80,4 +87,4 @@ def main(src, dst):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(*sys.argv[1:4])
