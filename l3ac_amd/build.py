@@ -31,6 +31,7 @@ SOURCES = [
     "kernels/fsq.hip",
     "kernels/conv_unit_fused.hip",
     "kernels/conv_unit_split.hip",
+    "kernels/conv_unit_wide.hip",
     "kernels/last_block.hip",
     "kernels/bitpack.hip",
 ]

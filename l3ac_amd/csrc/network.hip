@@ -379,6 +379,8 @@ int network_build(l3ac_ctx* ctx, const l3ac_tensor* tensors, int n_tensors) {
                         if (conv_unit_fused_supported(u.c)) {
                             b.extra_imgs.push_back({conv_unit_w1_image(b.host_of(u.w1), u.c), &u.w1_img});
                             b.extra_imgs.push_back({conv_unit_w2_image(b.host_of(u.w2), u.c), &u.w2_img});
+                        } else if (conv_unit_wide_supported(u.c)) {
+                            b.extra_imgs.push_back({conv_unit_wide_image(b.host_of(u.w1), b.host_of(u.w2), u.c), &u.wide_img});
                         }
         }
         if (b.err.empty() && last_block_fused_supported(cl, 9)) {  // (ctx->legacy no longer reallocates: the targets stay valid)
@@ -548,7 +550,23 @@ int workspace_ensure_clip(l3ac_ctx* ctx, int batch, int samples, hipStream_t s) 
 // ---------------------------------------------------------------------------------------------------------
 // blocks
 // ---------------------------------------------------------------------------------------------------------
+// the wide fused kernel computes on the bf16 matrix cores only (bf16x3): it belongs to the split route
+static bool use_wide(const l3ac_ctx* ctx, const ConvUnitW& w) {
+    static const bool off = [] {
+        const char* e = std::getenv("L3AC_WIDE_FUSED");
+        return e && std::atoi(e) == 0;
+    }();
+    return !off && !ctx->cfg.grn_exact && w.wide_img && gemm_split_enabled() && conv_unit_wide_supported(w.c);
+}
+
 int conv_unit_step(l3ac_ctx* ctx, hipStream_t s, const ConvUnitW& w, float** cur, float** alt, int batch, int frames) {
+    if (use_wide(ctx, w)) {
+        L3AC_TRY(launch_conv_unit_wide(s, w, *cur, *alt, batch, frames));
+        float* t = *cur;
+        *cur = *alt;
+        *alt = t;
+        return L3AC_OK;
+    }
     if (!ctx->cfg.grn_exact && conv_unit_fused_supported(w.c)) {
         L3AC_TRY(launch_conv_unit_fused(s, w, *cur, *alt, batch, frames));
         float* t = *cur;
@@ -588,7 +606,7 @@ static int conv_unit_group(const l3ac_ctx* ctx, const ConvUnitW& w, int batch, i
 int run_conv_units(l3ac_ctx* ctx, hipStream_t s, const std::vector<ConvUnitW>& units, float** cur, float** alt, int batch,
                    int frames) {
     if (units.empty()) return L3AC_OK;
-    const bool fused = !ctx->cfg.grn_exact && conv_unit_fused_supported(units[0].c);
+    const bool fused = (!ctx->cfg.grn_exact && conv_unit_fused_supported(units[0].c)) || use_wide(ctx, units[0]);
     if (fused || units.size() == 1) {
         for (const ConvUnitW& u : units) L3AC_TRY(conv_unit_step(ctx, s, u, cur, alt, batch, frames));
         return L3AC_OK;
@@ -603,6 +621,7 @@ int run_conv_units(l3ac_ctx* ctx, hipStream_t s, const std::vector<ConvUnitW>& u
 }
 
 int run_conv_unit(l3ac_ctx* ctx, hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames) {
+    if (x != y && use_wide(ctx, w)) return launch_conv_unit_wide(s, w, x, y, batch, frames);
     if (!ctx->cfg.grn_exact && x != y && conv_unit_fused_supported(w.c)) return launch_conv_unit_fused(s, w, x, y, batch, frames);
     const int group = conv_unit_group(ctx, w, batch, frames);
     for (int b0 = 0; b0 < batch; b0 += group) {

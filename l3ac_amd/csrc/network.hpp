@@ -14,6 +14,8 @@ struct ConvUnitW {  // modules.py:10-41
     const float *dw_w, *dw_b, *ln_w, *ln_b, *w1, *b1, *alpha, *inv_alpha, *gamma, *beta, *w2, *b2;
     // fragment-ordered bf16x3 images of w1 / w2 for conv_unit_split_kernel (narrow stages), null when not built
     const unsigned char *w1_img = nullptr, *w2_img = nullptr;
+    // W1 / W2 as ONE fragment-ordered bf16x3 stream in consumption order for conv_unit_wide_kernel (wide stages)
+    const unsigned char* wide_img = nullptr;
 };
 struct DownW {  // modules.py:96-99 and local_trans.py:136: Conv1d(k = stride) [+ ChannelNorm]
     int cin = 0, cout = 0, stride = 1;
@@ -116,6 +118,10 @@ int launch_conv_unit_fused(hipStream_t s, const ConvUnitW& w, const float* x, fl
 int launch_conv_unit_split(hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames);
 std::vector<unsigned char> conv_unit_w1_image(const float* w1, int c);  // w1 [4c][c]
 std::vector<unsigned char> conv_unit_w2_image(const float* w2, int c);  // w2 [c][4c]
+// fused ConvUnit of the wide stages (kernels/conv_unit_wide.hip): hidden tensor in registers, weights streamed through an LDS ring
+bool conv_unit_wide_supported(int c);
+int launch_conv_unit_wide(hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames);
+std::vector<unsigned char> conv_unit_wide_image(const float* w1, const float* w2, int c);  // w1 [4c][c], w2 [c][4c]
 // fused LegacyUnit / head (kernels/last_block.hip); x must not alias y
 bool last_block_fused_supported(int c, int max_dil);
 // host builders of the LegacyUnit weight images: w1 [c][7][c] (tap-major rows), w2 [c][c]

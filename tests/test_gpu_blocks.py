@@ -83,9 +83,11 @@ def test_gemm_split_accuracy():
 
 
 def test_gemm_split_cancellation_and_underflow():
-    """Adversarial operands for the bf16x3 split GEMM, with an ABSOLUTE bound per output: |err| <= 2^-23 * sum|a.w|
-    (what a k-ordered fp32 chain guarantees for these lengths), plus — only where operands sit within 2^16 of the bottom of
-    the fp32 range, so that their lower planes leave the bf16 normal range — K * 2^-126 * max|w|.
+    """Adversarial operands for the bf16x3 split GEMM, with an ABSOLUTE bound per output: |err| <= 2^-22 * sum|a.w| (twice the
+    unit roundoff of ONE fp32 product times the magnitude sum; the k-ordered fp32 MFMA chain itself reaches ~1.8 x 2^-23 on
+    these K = 1024 shapes — its own ratio is printed next to the split kernel's, and the split kernel must also stay within
+    1.05 x of it), plus — only where operands sit within 2^16 of the bottom of the fp32 range, so that their lower planes
+    leave the bf16 normal range — K * 2^-126 * max|w|.
       * cancellation: every dot product is ~0 while its terms are O(1): pairs (k, k + K/2) cancel to the last bit or two;
       * mixed magnitudes: a few O(1e4) terms over a floor of O(1e-4) ones;
       * small operands: a ~ 1e-30 (all three planes still normal bf16 numbers: exact) and a ~ 1e-37 (x1 / x2 planes are
@@ -113,11 +115,12 @@ def test_gemm_split_cancellation_and_underflow():
         got = G.gemm_split(aa.cuda(), ww.cuda(), None).cpu().double()
         got_f = G.gemm(aa.cuda(), ww.cuda(), None).cpu().double()
         err, err_f = (got - ref).abs(), (got_f - ref).abs()
-        bound = 2.0 ** -23 * mag + floor
-        print(f"[gemm_split {name}] max err/bound {float((err / bound.clamp_min(1e-300)).max()):.3f} "
-              f"(fp32 mfma: {float((err_f / bound.clamp_min(1e-300)).max()):.3f}); max|ref|/max mag {float(ref.abs().max() / mag.max()):.2e}")
+        bound = 2.0 ** -22 * mag + floor
+        worst, worst_f = float((err / bound.clamp_min(1e-300)).max()), float((err_f / bound.clamp_min(1e-300)).max())
+        print(f"[gemm_split {name}] max err/bound {worst:.3f} (fp32 mfma: {worst_f:.3f}); max|ref|/max mag {float(ref.abs().max() / mag.max()):.2e}")
         assert torch.isfinite(got).all()
         assert (err <= bound).all(), name
+        assert worst <= 1.05 * worst_f + 0.05, name
 
 
 def test_sin_squared_range():
@@ -185,6 +188,38 @@ def test_conv_units(tiny, full):
         ref = O.conv_unit(w, block, x)
         got = G.op_block(codec.network.context(), "l3ac_op_conv_unit", block, G.to_frames(x), (2, t, c))
         _close(block, G.from_frames(got), ref, atol=5e-5, rtol=5e-5)
+
+
+def test_conv_units_wide_fused(full):
+    """conv_unit_wide_kernel (C = 192 / 256: hidden tensor in registers, weights streamed through the LDS ring) against the
+    oracle on shapes that exercise what the small cases above do not: clip boundaries inside a 32-row tile (frames % 32 != 0),
+    a ragged last tile, one frame per clip, and enough rows for several passes per workgroup (the weight ring wraps around
+    and is re-entered: 36 000 rows > 256 workgroups x 128 rows)."""
+    codec, mc, w = full
+    for block, c, b, t in (("decoder.blocks.4.1.module", 256, 3, 900), ("encoder.blocks.7.0.module", 192, 5, 180),
+                           ("decoder.blocks.4.2.module", 256, 7, 1), ("encoder.blocks.7.1.module", 192, 2, 33),
+                           ("decoder.blocks.4.0.module", 256, 40, 900), ("encoder.blocks.7.1.module", 192, 200, 180)):
+        x = _rand((b, c, t), 200 + c + t)
+        ref = O.conv_unit(w, block, x)
+        got = G.op_block(codec.network.context(), "l3ac_op_conv_unit", block, G.to_frames(x), (b, t, c))
+        _close(f"{block} B={b} T={t}", G.from_frames(got), ref, atol=5e-5, rtol=5e-5)
+    # the same unit through the unfused route (dwconv+LN, two split GEMMs): the fused kernel may not be the less accurate one
+    x = _rand((4, 256, 450), 999)
+    block = "decoder.blocks.4.1.module"
+    ref64 = O.conv_unit({k: v.double() for k, v in w.items() if k.startswith(block)}, block, x.double())
+    fused = G.from_frames(G.op_block(codec.network.context(), "l3ac_op_conv_unit", block, G.to_frames(x), (4, 450, 256))).double()
+    xin = G.to_frames(x)
+    y = xin.clone()  # x == y: the in-place call takes the unfused route
+    from l3ac_amd import _capi
+    _capi.check(codec.network.context().lib.l3ac_op_conv_unit(codec.network.context().handle, block.encode(), y.data_ptr(), 4, 450,
+                                                                y.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    unfused = G.from_frames(y).double()
+    e_f, e_u = (fused - ref64).abs(), (unfused - ref64).abs()
+    print(f"[wide fused vs unfused, fp64 reference] fused max {float(e_f.max()):.3e} rms {float(e_f.pow(2).mean().sqrt()):.3e} | "
+          f"unfused max {float(e_u.max()):.3e} rms {float(e_u.pow(2).mean().sqrt()):.3e}")
+    assert float(e_f.pow(2).mean().sqrt()) <= 1.25 * float(e_u.pow(2).mean().sqrt()) + 1e-9
+    assert float(e_f.max()) <= 2.0 * float(e_u.max()) + 1e-7
 
 
 def test_down_and_k3_layers(tiny, full):
