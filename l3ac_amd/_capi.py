@@ -5,7 +5,10 @@ from __future__ import annotations
 import ctypes as C
 from pathlib import Path
 
-LIB_PATH = Path(__file__).resolve().parent / "libl3ac_hip.so"
+import os
+
+# L3AC_LIB_PATH: load another build of the same library (experiment builds under tools/experiments/_build); default in-tree
+LIB_PATH = Path(os.environ.get("L3AC_LIB_PATH") or Path(__file__).resolve().parent / "libl3ac_hip.so")
 ABI_VERSION = 1
 MAX_STAGES = 8
 MAX_LEVELS = 8
