@@ -120,7 +120,8 @@ std::vector<unsigned char> conv_unit_w1_image(const float* w1, int c);  // w1 [4
 std::vector<unsigned char> conv_unit_w2_image(const float* w2, int c);  // w2 [c][4c]
 // fused ConvUnit of the wide stages (kernels/conv_unit_wide.hip): hidden tensor in registers, weights streamed through an LDS ring
 bool conv_unit_wide_supported(int c);
-int launch_conv_unit_wide(hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames);
+size_t conv_unit_wide_scratch_bytes(int c, int64_t rows);
+int launch_conv_unit_wide(hipStream_t s, const ConvUnitW& w, const float* x, float* y, unsigned char* planes, int batch, int frames);
 std::vector<unsigned char> conv_unit_wide_image(const float* w1, const float* w2, int c);  // w1 [4c][c], w2 [c][4c]
 // fused LegacyUnit / head (kernels/last_block.hip); x must not alias y
 bool last_block_fused_supported(int c, int max_dil);
