@@ -438,7 +438,10 @@ def other_configs(dev, args):
     codebook = O.codebook(levels).to(dev).contiguous()
     idx = torch.empty(n, dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
-    call = lambda: _capi.check(lib.l3ac_vq_argmin(queries.data_ptr(), n, codebook.data_ptr(), k, len(levels), idx.data_ptr(), stream))
+    nbytes = lib.l3ac_vq_argmin_scratch_bytes(n, k)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    call = lambda: _capi.check(lib.l3ac_vq_argmin(queries.data_ptr(), n, codebook.data_ptr(), k, len(levels), idx.data_ptr(),
+                                                  scratch.data_ptr(), nbytes, stream))
     steps = 5
     dt, _ = time_steps(call, steps, 2)
     _, idx_ref, _ = O.fsq_quantize(z, levels)

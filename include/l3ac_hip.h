@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define L3AC_ABI_VERSION 1
+#define L3AC_ABI_VERSION 2
 #define L3AC_MAX_STAGES 8
 #define L3AC_MAX_LEVELS 8
 
@@ -133,9 +133,12 @@ int l3ac_fsq_decode(const int32_t* indices, int64_t n, int32_t feat, const int32
 
 /* Explicit-codebook nearest neighbour (the search FSQ is the closed form of):
  * queries [n][dim] (= tanh(latents)), codebook [k][dim] (= indices_to_codes(arange(k)), vq/fsq.py:80-81);
- * out_idx[i] = argmin_k ||q_i - c_k||^2, lowest k on exact ties.  dim <= 8. */
-int l3ac_vq_argmin(const float* queries, int64_t n, const float* codebook, int32_t k, int32_t dim,
-                   int32_t* out_idx, void* stream);
+ * out_idx[i] = argmin_k ||q_i - c_k||^2, lowest k on exact ties.  dim <= 8.
+ * `scratch` is a caller-owned device buffer of at least l3ac_vq_argmin_scratch_bytes(n, k) bytes (partial minima of the
+ * codebook slices): the call allocates nothing and can be captured into a hipGraph. */
+int64_t l3ac_vq_argmin_scratch_bytes(int64_t n, int32_t k);
+int l3ac_vq_argmin(const float* queries, int64_t n, const float* codebook, int32_t k, int32_t dim, int32_t* out_idx,
+                   void* scratch, int64_t scratch_bytes, void* stream);
 
 /* ---- token wire format (no reference counterpart: the reference keeps int32 indices, vq/fsq.py:68) ---------------
  * Per clip, token t occupies bits [t*bits, (t+1)*bits) of a little-endian bit stream, zero-padded to whole 32-bit

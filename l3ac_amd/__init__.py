@@ -25,10 +25,11 @@ import torch
 
 from . import _capi
 from . import weights as _weights
+from .chunking import ChunkData, plan as _chunk_plan
 from .config import CONFIG_DIR, L3ACConfig, ModelConfig, list_models, resolve_config_file
 
 __all__ = ["set_gemm_split", "get_gemm_split", "list_models", "get_model", "get_model_info", "L3AC", "L3ACConfig", "ModelConfig", "Network",
-           "bits_per_token", "pack_indices", "unpack_indices"]
+           "bits_per_token", "pack_indices", "unpack_indices", "ChunkData"]
 __version__ = "0.1.0"
 
 log = logging.getLogger("L3AC")
@@ -203,6 +204,61 @@ class L3AC:
             _capi.check(ctx.lib.l3ac_decode(ctx.handle, f_ptr, i_ptr, b, n_tok, audio.data_ptr(), stream))
         del keep
         return audio
+
+
+    # ---- long audio (reference l3ac/codec.py:124-156, corrected: see l3ac_amd/chunking.py) ---------------------------
+    def _batched(self, fn, chunks):
+        """Run `fn` on chunks grouped by length: equal-length chunks (all the middle ones) go through ONE call as a batch."""
+        out = [None] * len(chunks)
+        by_len = {}
+        for i, c in enumerate(chunks):
+            by_len.setdefault(c.shape[-1] if c.dim() == 1 else c.shape[0], []).append(i)
+        for idxs in by_len.values():
+            res = fn(torch.stack([chunks[i] for i in idxs]))
+            for k, i in enumerate(idxs):
+                out[i] = res[k]
+        return out
+
+    @torch.no_grad()
+    def extract_unit(self, audio_data: torch.Tensor, process_window: int = 10 * 16000, prefix_tokens: Optional[int] = None):
+        """Encode a clip of any length window by window: (1, T) audio -> (ChunkData of indices, ChunkData of q_feature), the
+        return structure of reference ``Codec.extract_unit`` (codec.py:124-147).  Unlike the reference, every chunk goes
+        through the whole encode path (``en_encoder`` included) and overlaps its predecessor by ``prefix_tokens`` tokens
+        (default: the local attention's window, i.e. its look-back) instead of one hop; equal-length chunks are batched
+        through one ``encode_audio`` call.  ``.data`` of either result is the merged token stream."""
+        assert audio_data.dim() == 2 and len(audio_data) == 1, "Only support batch size 1"  # codec.py:133
+        mc = self.network.mc
+        hop = mc.hop_length
+        prefix_tokens = mc.en_coder_window_size if prefix_tokens is None else int(prefix_tokens)
+        audio, _ = self.network.preprocess(audio_data)  # right zero-pad to a hop multiple (codec.py:79-84)
+        chunk_len, prefix_len = _chunk_plan(hop, process_window, prefix_tokens)
+        chunks = ChunkData(chunk_len=chunk_len, prefix_len=prefix_len, original_data=audio[0]).chunk_data
+        idx, feat = [None] * len(chunks), [None] * len(chunks)
+
+        def run(batch):
+            q, ind = self.encode_audio(batch)
+            return list(zip(ind["indices"], q))
+        for i, (ix, q) in enumerate(self._batched(run, chunks)):
+            idx[i], feat[i] = ix, q
+        return (ChunkData(chunk_len=chunk_len // hop, prefix_len=prefix_tokens, chunk_data=idx),
+                ChunkData(chunk_len=chunk_len // hop, prefix_len=prefix_tokens, chunk_data=feat))
+
+    @torch.no_grad()
+    def decode_unit(self, chunk_indices: Optional[ChunkData] = None, chunk_q_feature: Optional[ChunkData] = None,
+                    audio_length: Optional[int] = None) -> torch.Tensor:
+        """Decode what ``extract_unit`` returned, chunk by chunk (each with its overlap tokens as left context, equal-length
+        chunks batched), and merge the waveforms: reference ``Codec.decode_unit`` (codec.py:149-156) -> (1, T) audio,
+        trimmed to ``audio_length`` when given."""
+        src = chunk_q_feature if chunk_q_feature is not None else chunk_indices
+        if src is None:
+            raise ValueError("decode_unit needs chunk_indices or chunk_q_feature")
+        hop = self.network.mc.hop_length
+        if chunk_q_feature is not None:
+            waves = self._batched(lambda b: list(self.decode_audio(b)), src.chunk_data)
+        else:
+            waves = self._batched(lambda b: list(self.decode_audio(indices=b)), src.chunk_data)
+        merged = ChunkData(chunk_len=src.chunk_len * hop, prefix_len=src.prefix_len * hop, chunk_data=waves).data[None, :]
+        return merged if audio_length is None else merged[:, :audio_length]
 
 
 def set_gemm_split(enable: bool) -> None:

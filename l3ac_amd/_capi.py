@@ -9,7 +9,7 @@ import os
 
 # L3AC_LIB_PATH: load another build of the same library (experiment builds under tools/experiments/_build); default in-tree
 LIB_PATH = Path(os.environ.get("L3AC_LIB_PATH") or Path(__file__).resolve().parent / "libl3ac_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_STAGES = 8
 MAX_LEVELS = 8
 
@@ -58,7 +58,8 @@ SIGNATURES = {
     "l3ac_fsq_forward": (C.c_int, [_P, _I64, _I32, C.POINTER(_I32), _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "l3ac_fsq_quantize_act": (C.c_int, [_P, _I64, _I32, C.POINTER(_I32), _I32, _P, _P, _P, _P, _P, _P]),
     "l3ac_fsq_decode": (C.c_int, [_P, _I64, _I32, C.POINTER(_I32), _I32, _P, _P, _P, _P]),
-    "l3ac_vq_argmin": (C.c_int, [_P, _I64, _P, _I32, _I32, _P, _P]),
+    "l3ac_vq_argmin_scratch_bytes": (_I64, [_I64, _I32]),
+    "l3ac_vq_argmin": (C.c_int, [_P, _I64, _P, _I32, _I32, _P, _P, _I64, _P]),
     "l3ac_op_first_block": (C.c_int, [_P, _P, _I32, _I32, _P, _P]),
     "l3ac_op_conv_unit": (C.c_int, [_P, C.c_char_p, _P, _I32, _I32, _P, _P]),
     "l3ac_op_down_layer": (C.c_int, [_P, C.c_char_p, _P, _I32, _I32, _P, _P]),

@@ -226,23 +226,16 @@ int l3ac_fsq_decode(const int32_t* indices, int64_t n, int32_t feat, const int32
     return launch_fsq((hipStream_t)stream, f);
 }
 
+int64_t l3ac_vq_argmin_scratch_bytes(int64_t n, int32_t k) { return (n > 0 && k > 0) ? (int64_t)vq_argmin_scratch_bytes(n, k) : 0; }
+
 int l3ac_vq_argmin(const float* queries, int64_t n, const float* codebook, int32_t k, int32_t dim, int32_t* out_idx,
-                   void* stream) {
+                   void* scratch, int64_t scratch_bytes, void* stream) {
     L3AC_REQUIRE(queries && codebook && out_idx, "vq_argmin: null buffer");
     if (n == 0) return L3AC_OK;
-    // enough codebook slices to fill the chip: blocks = ceil(n / 256) * parts >= ~1024
-    const int64_t qblocks = ceil_div64(n, 256);
-    int parts = (int)ceil_div64(1024, qblocks);
-    const int shards = (int)ceil_div64(k, 2048);
-    if (parts > shards) parts = shards;
-    if (parts < 1) parts = 1;
-    hipStream_t s = (hipStream_t)stream;
-    float* part_dist = nullptr;
-    L3AC_HIP_CHECK(hipMallocAsync((void**)&part_dist, (size_t)parts * n * 2 * sizeof(float), s));
-    int32_t* part_idx = reinterpret_cast<int32_t*>(part_dist + (size_t)parts * n);
-    int rc = launch_vq_argmin_parts(s, queries, n, codebook, k, dim, parts, part_dist, part_idx, out_idx);
-    (void)hipFreeAsync(part_dist, s);
-    return rc;
+    L3AC_REQUIRE(scratch && k > 0 && scratch_bytes >= (int64_t)vq_argmin_scratch_bytes(n, k),
+                 "vq_argmin: scratch of %lld bytes needed (l3ac_vq_argmin_scratch_bytes), %lld given",
+                 (long long)(k > 0 ? vq_argmin_scratch_bytes(n, k) : 0), (long long)scratch_bytes);
+    return launch_vq_argmin((hipStream_t)stream, queries, n, codebook, k, dim, scratch, out_idx);
 }
 
 // ---- per-block parity entry points --------------------------------------------------------------------

@@ -159,6 +159,7 @@ int launch_fsq(hipStream_t s, const FsqArgs& a);
 // token bit stream (kernels/bitpack.hip)
 int launch_pack_indices(hipStream_t s, const int32_t* idx, int batch, int n_tok, int bits, uint32_t* out, int words_per_clip);
 int launch_unpack_indices(hipStream_t s, const uint32_t* in, int batch, int n_tok, int bits, int words_per_clip, int32_t* idx);
-// `parts` codebook slices are searched by separate blocks; part_dist / part_idx are [parts][n] scratch
-int launch_vq_argmin_parts(hipStream_t s, const float* queries, int64_t n, const float* codebook, int k, int dim,
-                           int parts, float* part_dist, int32_t* part_idx, int32_t* out_idx);
+// explicit-codebook L2 argmin (kernels/fsq.hip): scratch = vq_argmin_scratch_bytes(n, k) bytes, caller-provided
+size_t vq_argmin_scratch_bytes(int64_t n, int k);
+int launch_vq_argmin(hipStream_t s, const float* queries, int64_t n, const float* codebook, int k, int dim, void* scratch,
+                     int32_t* out_idx);

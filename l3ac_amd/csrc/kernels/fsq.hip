@@ -12,9 +12,8 @@
 // holds identical latents and finishes its own 8 output channels.  Everything after tanh is exact IEEE arithmetic,
 // so indices are bit-identical to the reference for identical activations.
 //
-// vq_argmin_kernel — the explicit-codebook nearest-neighbour search FSQ is the closed form of: one
-// query per lane in registers, codebook shards staged through LDS and read as wave-wide broadcasts, partial
-// (distance, index) minima per shard combined by a second pass; lowest index wins exact ties.
+// vq_scan_kernel / vq_wave_kernel — the explicit-codebook nearest-neighbour search FSQ is the closed form of:
+// see "explicit codebook search" below; lowest index wins exact ties.
 #include "../kernels.hpp"
 
 namespace {
@@ -197,53 +196,119 @@ int launch_fsq_t(hipStream_t s, const FsqDev& p) {
 }
 
 // ---- explicit codebook search ----------------------------------------------------------------------
-constexpr int SHARD = 2048;  // codes per LDS shard (2048 * 8 floats = 64 KiB)
-
-template <int D>  // D = dim padded to 4 or 8 (padding coordinates are 0 on both sides)
-__global__ __launch_bounds__(THREADS) void vq_argmin_kernel(const float* __restrict__ queries, int64_t n, int dim,
-                                                           const float* __restrict__ codebook, int k, int shards_per_block,
-                                                           float* __restrict__ part_dist, int32_t* __restrict__ part_idx) {
-    __shared__ __attribute__((aligned(16))) float cs[SHARD * 8];
-    const int64_t qi = (int64_t)blockIdx.x * THREADS + threadIdx.x;
-    const bool ok = qi < n;
-    float q[8];
+// Brute-force L2 nearest neighbour, dist = sum_d (q_d - c_d)^2 accumulated with fmaf in dimension order, strict '<' while
+// the codes are visited in increasing index (the lowest index wins an exact tie): 3 D N K algorithmic FLOP, fp32-VALU-bound.
+// Two forms, both specialised on the true dimension (no padded FMAs) and both splitting the codebook into `parts` index
+// ranges whose (distance, index) minima a small second kernel combines in index order:
+//   vq_scan_kernel  (many queries)  QPL queries per lane in registers; the code coordinates are wave-uniform, so they come
+//                   through the SCALAR unit (s_load) and enter the VALU instructions as SGPR operands: no LDS staging, no
+//                   barrier, nothing but 2 D + 3 vector instructions per (query, code) pair.
+//   vq_wave_kernel  (few queries: a streaming chunk has 60)  the codebook slice is dealt over the 64 LANES, QW queries per
+//                   wave held wave-uniform; every lane keeps a running minimum over its codes and the wave then reduces
+//                   (distance, index) pairs by xor-butterfly, the lower index winning ties — so even one query fills a
+//                   wave, and 60 of them the chip.
+template <int D, int QPL>
+__global__ __launch_bounds__(256) void vq_scan_kernel(const float* __restrict__ queries, int64_t n, const float* __restrict__ codebook,
+                                                     int k, int k_per_part, float* __restrict__ part_dist, int32_t* __restrict__ part_idx) {
+    const int64_t q0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 * QPL) + (threadIdx.x & 63);
+    float q[QPL][D];
+    float best[QPL];
+    int best_i[QPL];
 #pragma unroll
-    for (int d = 0; d < 8; ++d) q[d] = (ok && d < dim) ? queries[qi * dim + d] : 0.f;
-    float best = INFINITY;
-    int best_i = 0x7fffffff;
-    const int k_begin = blockIdx.y * shards_per_block * SHARD;
-    const int k_end = min(k, k_begin + shards_per_block * SHARD);
-    for (int s0 = k_begin; s0 < k_end; s0 += SHARD) {
-        const int cnt = min(SHARD, k_end - s0);
-        __syncthreads();
-        for (int i = threadIdx.x; i < cnt * 8; i += THREADS) {
-            const int code = i >> 3, d = i & 7;
-            cs[i] = d < dim ? codebook[(int64_t)(s0 + code) * dim + d] : 0.f;
-        }
-        __syncthreads();
-        for (int c = 0; c < cnt; ++c) {
-            const float4 ca = *reinterpret_cast<const float4*>(cs + c * 8);
-            const float4 cb = *reinterpret_cast<const float4*>(cs + c * 8 + 4);
-            float dist = 0.f, t;
-            t = q[0] - ca.x; dist = fmaf(t, t, dist);
-            t = q[1] - ca.y; dist = fmaf(t, t, dist);
-            t = q[2] - ca.z; dist = fmaf(t, t, dist);
-            t = q[3] - ca.w; dist = fmaf(t, t, dist);
-            if (D > 4) {
-                t = q[4] - cb.x; dist = fmaf(t, t, dist);
-                t = q[5] - cb.y; dist = fmaf(t, t, dist);
-                t = q[6] - cb.z; dist = fmaf(t, t, dist);
-                t = q[7] - cb.w; dist = fmaf(t, t, dist);
+    for (int j = 0; j < QPL; ++j) {
+        const int64_t qi = q0 + 64 * j;
+#pragma unroll
+        for (int d = 0; d < D; ++d) q[j][d] = qi < n ? queries[qi * D + d] : 0.f;
+        best[j] = INFINITY;
+        best_i[j] = 0x7fffffff;
+    }
+    const int c_begin = blockIdx.y * k_per_part;
+    const int c_end = min(k, c_begin + k_per_part);
+    const float* __restrict__ cb = codebook + (int64_t)c_begin * D;  // wave-uniform: scalar loads
+#pragma unroll 4
+    for (int c = c_begin; c < c_end; ++c, cb += D) {
+        float cc[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) cc[d] = cb[d];
+#pragma unroll
+        for (int j = 0; j < QPL; ++j) {
+            float t = q[j][0] - cc[0];
+            float dist = t * t;
+#pragma unroll
+            for (int d = 1; d < D; ++d) {
+                t = q[j][d] - cc[d];
+                dist = fmaf(t, t, dist);
             }
-            if (dist < best) {  // strict: the lowest index wins an exact tie
-                best = dist;
-                best_i = s0 + c;
-            }
+            const bool lt = dist < best[j];  // strict: the lowest index wins an exact tie
+            best[j] = lt ? dist : best[j];
+            best_i[j] = lt ? c : best_i[j];
         }
     }
-    if (ok) {
-        part_dist[(int64_t)blockIdx.y * n + qi] = best;
-        part_idx[(int64_t)blockIdx.y * n + qi] = best_i;
+#pragma unroll
+    for (int j = 0; j < QPL; ++j) {
+        const int64_t qi = q0 + 64 * j;
+        if (qi < n) {
+            part_dist[(int64_t)blockIdx.y * n + qi] = best[j];
+            part_idx[(int64_t)blockIdx.y * n + qi] = best_i[j];
+        }
+    }
+}
+
+template <int D, int QW>
+__global__ __launch_bounds__(256) void vq_wave_kernel(const float* __restrict__ queries, int64_t n, const float* __restrict__ codebook,
+                                                     int k, int k_per_part, float* __restrict__ part_dist, int32_t* __restrict__ part_idx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t qbase = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * QW;  // wave-uniform
+    if (qbase >= n) return;
+    float q[QW][D];
+#pragma unroll
+    for (int j = 0; j < QW; ++j) {
+        const int64_t qi = qbase + j < n ? qbase + j : n - 1;
+#pragma unroll
+        for (int d = 0; d < D; ++d) q[j][d] = queries[qi * D + d];  // uniform address: every lane holds the query
+    }
+    float best[QW];
+    int best_i[QW];
+#pragma unroll
+    for (int j = 0; j < QW; ++j) {
+        best[j] = INFINITY;
+        best_i[j] = 0x7fffffff;
+    }
+    const int c_begin = blockIdx.y * k_per_part;
+    const int c_end = min(k, c_begin + k_per_part);
+    for (int c = c_begin + lane; c < c_end; c += 64) {  // a lane's codes come in increasing index: strict '<' keeps its lowest
+        float cc[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) cc[d] = codebook[(int64_t)c * D + d];
+#pragma unroll
+        for (int j = 0; j < QW; ++j) {
+            float t = q[j][0] - cc[0];
+            float dist = t * t;
+#pragma unroll
+            for (int d = 1; d < D; ++d) {
+                t = q[j][d] - cc[d];
+                dist = fmaf(t, t, dist);
+            }
+            const bool lt = dist < best[j];
+            best[j] = lt ? dist : best[j];
+            best_i[j] = lt ? c : best_i[j];
+        }
+    }
+    // wavefront-level argmin: (distance, index) pairs combined over the 64 lanes, the lower index winning equal distances
+#pragma unroll
+    for (int j = 0; j < QW; ++j) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const float od = __shfl_xor(best[j], m, 64);
+            const int oi = __shfl_xor(best_i[j], m, 64);
+            const bool take = od < best[j] || (od == best[j] && oi < best_i[j]);
+            best[j] = take ? od : best[j];
+            best_i[j] = take ? oi : best_i[j];
+        }
+        if (lane == 0 && qbase + j < n) {
+            part_dist[(int64_t)blockIdx.y * n + qbase + j] = best[j];
+            part_idx[(int64_t)blockIdx.y * n + qbase + j] = best_i[j];
+        }
     }
 }
 
@@ -262,6 +327,24 @@ __global__ __launch_bounds__(THREADS) void vq_argmin_combine_kernel(const float*
         }
     }
     out_idx[qi] = best_i;
+}
+
+constexpr int VQ_QPL = 2;       // queries per lane of the scan form
+constexpr int VQ_QW = 4;        // queries per wave of the wavefront form
+constexpr int64_t VQ_WAVE_MAX_N = 16384;  // below this many queries the wavefront form fills the chip better
+
+template <int D>
+int launch_vq_t(hipStream_t s, const float* queries, int64_t n, const float* codebook, int k, int parts, int k_per_part,
+                float* part_dist, int32_t* part_idx, bool wave_form) {
+    if (wave_form) {
+        const dim3 grid((unsigned)ceil_div64(n, 4 * VQ_QW), (unsigned)parts);
+        hipLaunchKernelGGL((vq_wave_kernel<D, VQ_QW>), grid, dim3(256), 0, s, queries, n, codebook, k, k_per_part, part_dist, part_idx);
+    } else {
+        const dim3 grid((unsigned)ceil_div64(n, 4 * 64 * VQ_QPL), (unsigned)parts);
+        hipLaunchKernelGGL((vq_scan_kernel<D, VQ_QPL>), grid, dim3(256), 0, s, queries, n, codebook, k, k_per_part, part_dist, part_idx);
+    }
+    L3AC_LAUNCH_CHECK();
+    return L3AC_OK;
 }
 
 }  // namespace
@@ -299,20 +382,41 @@ int launch_fsq(hipStream_t s, const FsqArgs& a) {
     }
 }
 
-// scratch for the partial minima is owned by the caller-visible entry point in capi.cpp
-int launch_vq_argmin_parts(hipStream_t s, const float* queries, int64_t n, const float* codebook, int k, int dim,
-                           int parts, float* part_dist, int32_t* part_idx, int32_t* out_idx) {
+// How the codebook is cut: enough (query group, slice) work items for ~8 waves per SIMD at the scan form, ~4 at the wave form
+int vq_argmin_parts(int64_t n, int k) {
+    const bool wave_form = n < VQ_WAVE_MAX_N;
+    const int64_t waves_q = wave_form ? ceil_div64(n, VQ_QW) : ceil_div64(n, 64 * VQ_QPL);
+    int64_t parts = ceil_div64(wave_form ? 4096 : 8192, waves_q);
+    const int64_t max_parts = ceil_div64(k, wave_form ? 1024 : 512);  // a slice should still amortise its prologue
+    if (parts > max_parts) parts = max_parts;
+    if (parts < 1) parts = 1;
+    return (int)parts;
+}
+size_t vq_argmin_scratch_bytes(int64_t n, int k) { return (size_t)vq_argmin_parts(n, k) * (size_t)n * 8; }
+
+// scratch = vq_argmin_scratch_bytes(n, k) bytes (partial distances, then partial indices)
+int launch_vq_argmin(hipStream_t s, const float* queries, int64_t n, const float* codebook, int k, int dim, void* scratch,
+                     int32_t* out_idx) {
     L3AC_REQUIRE(dim >= 1 && dim <= 8 && k > 0 && n >= 0, "vq_argmin: bad shape (dim=%d k=%d)", dim, k);
     if (n == 0) return L3AC_OK;
-    const int shards = (int)ceil_div64(k, SHARD);
-    const int shards_per_block = (int)ceil_div64(shards, parts);
-    const dim3 grid((unsigned)ceil_div64(n, THREADS), (unsigned)parts);
-    ProfScope prof(s, "vq_argmin_kernel", 3.0 * dim * (double)n * k, 4.0 * ((double)n * dim + (double)k * dim + n));
-    if (dim <= 4)
-        hipLaunchKernelGGL((vq_argmin_kernel<4>), grid, dim3(THREADS), 0, s, queries, n, dim, codebook, k, shards_per_block, part_dist, part_idx);
-    else
-        hipLaunchKernelGGL((vq_argmin_kernel<8>), grid, dim3(THREADS), 0, s, queries, n, dim, codebook, k, shards_per_block, part_dist, part_idx);
-    L3AC_LAUNCH_CHECK();
+    const int parts = vq_argmin_parts(n, k);
+    const int k_per_part = (int)ceil_div64(k, parts);
+    float* part_dist = reinterpret_cast<float*>(scratch);
+    int32_t* part_idx = reinterpret_cast<int32_t*>(part_dist + (size_t)parts * n);
+    const bool wave_form = n < VQ_WAVE_MAX_N;
+    {
+        ProfScope prof(s, wave_form ? "vq_wave_kernel" : "vq_scan_kernel", 3.0 * dim * (double)n * k, 4.0 * ((double)n * dim + (double)k * dim + n));
+        switch (dim) {
+            case 1: L3AC_TRY(launch_vq_t<1>(s, queries, n, codebook, k, parts, k_per_part, part_dist, part_idx, wave_form)); break;
+            case 2: L3AC_TRY(launch_vq_t<2>(s, queries, n, codebook, k, parts, k_per_part, part_dist, part_idx, wave_form)); break;
+            case 3: L3AC_TRY(launch_vq_t<3>(s, queries, n, codebook, k, parts, k_per_part, part_dist, part_idx, wave_form)); break;
+            case 4: L3AC_TRY(launch_vq_t<4>(s, queries, n, codebook, k, parts, k_per_part, part_dist, part_idx, wave_form)); break;
+            case 5: L3AC_TRY(launch_vq_t<5>(s, queries, n, codebook, k, parts, k_per_part, part_dist, part_idx, wave_form)); break;
+            case 6: L3AC_TRY(launch_vq_t<6>(s, queries, n, codebook, k, parts, k_per_part, part_dist, part_idx, wave_form)); break;
+            case 7: L3AC_TRY(launch_vq_t<7>(s, queries, n, codebook, k, parts, k_per_part, part_dist, part_idx, wave_form)); break;
+            default: L3AC_TRY(launch_vq_t<8>(s, queries, n, codebook, k, parts, k_per_part, part_dist, part_idx, wave_form)); break;
+        }
+    }
     hipLaunchKernelGGL(vq_argmin_combine_kernel, dim3((unsigned)ceil_div64(n, THREADS)), dim3(THREADS), 0, s, part_dist,
                        part_idx, n, parts, out_idx);
     L3AC_LAUNCH_CHECK();

@@ -104,8 +104,10 @@ def vq_argmin(queries, codebook):
     lib = _capi.load_library()
     n, dim = queries.shape
     out = torch.empty((n,), dtype=torch.int32, device=queries.device)
+    nbytes = lib.l3ac_vq_argmin_scratch_bytes(n, codebook.shape[0])
+    scratch = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=queries.device)
     _capi.check(lib.l3ac_vq_argmin(queries.data_ptr(), n, codebook.data_ptr(), codebook.shape[0], dim, out.data_ptr(),
-                                   _stream(queries.device)))
+                                   scratch.data_ptr(), nbytes, _stream(queries.device)))
     torch.cuda.synchronize()
     return out
 

@@ -371,6 +371,94 @@ def test_long_clip_multi_window_attention():
     assert _err("long clip wave", wave, O.decode_audio(w, mc, indices=ind_ref["indices"])) < WAVE_ATOL
 
 
+def test_weights_from_disk_and_example_flow(tmp_path):
+    """SURVEY f4.  Five ``.pt`` state dicts in the reference's cache layout ({model_dir}/{name}.{version}/{module}.pt with the
+    weight-norm parametrisation keys, l3ac/__init__.py:70-72, xtract/nn/module.py:43-54) are written to a temporary directory and
+    loaded with ``get_model(name, model_dir=...)``: the results must be bit-identical to the ``synthetic_seed`` route that
+    every other test uses.  Then the flow of reference example.py:7-30 / README.md:36-67, line by line."""
+    from l3ac_amd.config import L3ACConfig, resolve_config_file
+    cfg = L3ACConfig(config_file=resolve_config_file("1kbps"), model_dir=tmp_path)
+    W.save_state_dicts(W.synthetic_state_dicts(cfg.network_config, seed=0), cfg.model_path)
+    assert sorted(f.name for f in cfg.model_path.iterdir()) == sorted(f"{m}.pt" for m in W.MODULE_NAMES)
+    # ---- example.py -------------------------------------------------------------------------------------------------
+    assert "1kbps" in l3ac_amd.list_models() and "3kbps" in l3ac_amd.list_models()       # example.py:8
+    codec = l3ac_amd.get_model("1kbps", model_dir=tmp_path)                               # :9
+    assert codec.config.sample_rate == 16000                                              # :10
+    info = l3ac_amd.get_model_info(codec.network)                                         # :11
+    assert info["macs"] > 3.8e10 and info["params"] > 1.1e7 and abs(info["bps"] - 998.2) < 0.1
+    sample_audio = seeded_audio(1, 40000).numpy()                                         # :13-17 (librosa sample -> synthetic clip)
+    codec.network.to(device="cuda")                                                       # :19
+    codec.network.eval()                                                                  # :20
+    with torch.inference_mode():                                                          # :21
+        audio_in = torch.tensor(sample_audio, dtype=torch.float32, device="cuda")         # :22
+        _, audio_length = audio_in.shape                                                  # :23
+        q_feature, indices = codec.encode_audio(audio_in)                                 # :25
+        audio_out = codec.decode_audio(q_feature)                                         # :26
+        audio_out2 = codec.decode_audio(indices=indices["indices"])                       # :27
+        generated_audio = audio_out[:, :audio_length].detach().cpu().numpy()              # :28
+    assert generated_audio.shape == sample_audio.shape and np.isfinite(generated_audio).all()
+    mse = float(((sample_audio - generated_audio) ** 2).mean())                           # :30
+    assert np.isfinite(mse)
+    assert torch.equal(audio_out, audio_out2)
+    # ---- same weights through the seeded generator: bit-identical tokens, features and waveform -------------------------
+    ref = _codec("1kbps", 0)
+    q2, ind2 = ref.encode_audio(torch.tensor(sample_audio, device="cuda"))
+    assert torch.equal(ind2["indices"], indices["indices"]) and torch.equal(q2, q_feature)
+    assert torch.equal(ref.decode_audio(q2), audio_out)
+    # a missing file is an error, not silently random weights (the reference only logs, module.py:52-54)
+    (cfg.model_path / "en_decoder.pt").unlink()
+    with pytest.raises(FileNotFoundError):
+        l3ac_amd.get_model("1kbps", model_dir=tmp_path)
+
+
+def test_long_audio_chunker():
+    """extract_unit / decode_unit (reference l3ac/codec.py:124-156, corrected to run en_encoder / en_decoder on every
+    chunk and to overlap by the attention look-back) against (i) the oracle run chunk by chunk with the reference's ChunkData
+    bookkeeping, (ii) plain encode_audio when one window covers the clip, (iii) the whole-clip oracle in the valid region."""
+    from oracle import chunk_oracle as CO
+    codec = _codec("1kbps", 0)
+    mc = codec.network.mc
+    hop = mc.hop_length
+    w = W.folded_weights(codec.network.state_dicts())
+    audio = seeded_audio(1, 6 * 16000 + 123)  # 6 s: several windows of 2 s, ragged tail
+    for window, prefix in ((2 * 16000, 30), (2 * 16000, 1), (3 * 16000 + 77, 60)):
+        ci, cq = codec.extract_unit(audio.cuda(), process_window=window, prefix_tokens=prefix)
+        ri, rq, rl = CO.extract_unit(w, mc, audio, window, prefix)
+        assert len(ci.chunk_data) == len(ri.chunk_data) and ci.chunk_len == ri.chunk_len and ci.prefix_len == ri.prefix_len
+        assert [tuple(x.shape) for x in ci.chunk_data] == [tuple(x.shape) for x in ri.chunk_data]
+        n_bad = 0
+        for a, b, lat in zip(ci.chunk_data, ri.chunk_data, rl.chunk_data):
+            nb, ok = index_mismatch_report(a.cpu().numpy(), b.numpy(), lat.numpy(), mc.levels, TAU)
+            assert ok
+            n_bad += nb
+        assert n_bad <= 1  # observed: 0
+        tokens = ci.data
+        assert tokens.shape == (-(-audio.shape[1] // hop),) and torch.equal(tokens.cpu(), ri.data) or n_bad > 0
+        assert _err(f"chunked q_feature w={window} p={prefix}", cq.data, rq.data) < FEAT_ATOL * 4
+        # decode the ORACLE's chunks on the GPU and compare the stitched waveform with the oracle's
+        wave = codec.decode_unit(chunk_indices=l3ac_amd.ChunkData(ri.chunk_len, ri.prefix_len, chunk_data=[x.cuda() for x in ri.chunk_data]),
+                                 audio_length=audio.shape[1])
+        ref = CO.decode_unit(w, mc, ri)[:, :audio.shape[1]]
+        assert wave.shape == (1, audio.shape[1])
+        assert _err(f"chunked wave w={window} p={prefix}", wave, ref) < WAVE_ATOL
+        # from q_feature chunks == from index chunks, bit for bit
+        assert torch.equal(codec.decode_unit(chunk_q_feature=cq), codec.decode_unit(chunk_indices=ci))
+    # one window covers the clip: identical to the plain call
+    ci, cq = codec.extract_unit(audio.cuda(), process_window=8 * 16000)
+    q, ind = codec.encode_audio(audio.cuda())
+    assert len(ci.chunk_data) == 1 and torch.equal(ci.data, ind["indices"][0]) and torch.equal(cq.data, q[0])
+    assert torch.equal(codec.decode_unit(chunk_indices=ci), codec.decode_audio(indices=ind["indices"]))
+    # valid region vs the whole-clip oracle: a chunk that sees one attention window of left context reproduces most of the
+    # whole-clip tokens (not all: the stacked layers reach further back than one window, and the clip-wide statistics differ)
+    _, ind_ref = O.encode_audio(w, mc, audio)
+    ci, _ = codec.extract_unit(audio.cuda(), process_window=2 * 16000, prefix_tokens=mc.en_coder_window_size // 2)
+    agree = float((ci.data.cpu() == ind_ref["indices"][0]).float().mean())
+    ci1, _ = codec.extract_unit(audio.cuda(), process_window=2 * 16000, prefix_tokens=1)
+    agree1 = float((ci1.data.cpu() == ind_ref["indices"][0]).float().mean())
+    print(f"[chunker] tokens equal to the whole-clip oracle: {agree:.3f} with the look-back overlap, {agree1:.3f} with the reference's one-hop overlap")
+    assert agree >= agree1 and agree > 0.5
+
+
 def test_streaming_chunks_and_graph_capture():
     """BASELINE config 5: 1 s chunks through a captured graph give the same tokens as eager calls."""
     codec = _codec("1kbps", 0)

@@ -191,3 +191,30 @@ def test_traffic_summary_is_tied_to_the_kernel_sources(tmp_path):
     roof = {"kernel": "gemm_split_kernel"}
     bench.attach_traffic(roof, tmp_path, "3kbps b256 s16000 split")  # another workload: not attached at all
     assert roof["traffic"] is None and "traffic_stale" not in roof
+
+
+def test_chunk_bookkeeping_matches_the_reference_restatement():
+    """l3ac_amd.chunking.ChunkData (product, any dim) against oracle/chunk_oracle.ChunkData (reference l3ac/codec.py:159-188,
+    dim 0): same chunks when cutting, same stream when merging, for ragged lengths, one-hop and multi-token overlaps."""
+    import torch
+
+    from l3ac_amd.chunking import ChunkData, plan
+    from oracle.chunk_oracle import ChunkData as RefChunkData
+    g = torch.Generator().manual_seed(0)
+    for n, chunk_len, prefix in ((23, 8, 3), (80000, 16200, 270), (81001, 16000 // 270 * 270, 270), (7, 8, 1), (8, 8, 7), (9, 8, 7), (1000, 10, 9)):
+        data = torch.randn(n, generator=g)
+        a = ChunkData(chunk_len, prefix, original_data=data).chunk_data
+        b = RefChunkData(chunk_len, prefix, original_data=data).chunk_data
+        assert len(a) == len(b) and all(torch.equal(x, y) for x, y in zip(a, b))
+        assert torch.equal(ChunkData(chunk_len, prefix, chunk_data=a).data, RefChunkData(chunk_len, prefix, chunk_data=b).data)
+        assert torch.equal(ChunkData(chunk_len, prefix, chunk_data=a).data, data)  # cut then merge is the identity
+    # token features (T, C) are cut / merged along dim 0 as well; the product also accepts another dim
+    feat = torch.randn(37, 5, generator=g)
+    a = ChunkData(10, 4, original_data=feat).chunk_data
+    assert torch.equal(ChunkData(10, 4, chunk_data=a).data, feat)
+    ft = feat.T.contiguous()
+    at = ChunkData(10, 4, original_data=ft, dim=1).chunk_data
+    assert all(torch.equal(x.T, y) for x, y in zip(at, a)) and torch.equal(ChunkData(10, 4, chunk_data=at, dim=1).data, ft)
+    assert plan(270, 5 * 16000, 1) == (79920, 270)  # reference geometry at 1kbps: window rounded to hops, one hop of overlap
+    with pytest.raises(ValueError):
+        plan(270, 1000, 4)
