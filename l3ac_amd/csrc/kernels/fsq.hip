@@ -225,6 +225,9 @@ __global__ __launch_bounds__(256) void vq_scan_kernel(const float* __restrict__ 
     const int c_begin = blockIdx.y * k_per_part;
     const int c_end = min(k, c_begin + k_per_part);
     const float* __restrict__ cb = codebook + (int64_t)c_begin * D;  // wave-uniform: scalar loads
+    // (measured and dropped: comparing only the minimum of a block of 4 codes with the running minimum and redoing the ordered
+    // update on a wave-uniform branch — 6.1 ms instead of 3.3 ms at K = 250 047, N = 42 752: with 128 queries per wave some lane
+    // improves in most blocks, and the branch splits the loop body)
 #pragma unroll 4
     for (int c = c_begin; c < c_end; ++c, cb += D) {
         float cc[D];

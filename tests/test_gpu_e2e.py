@@ -451,7 +451,7 @@ def test_long_audio_chunker():
     # valid region vs the whole-clip oracle: a chunk that sees one attention window of left context reproduces most of the
     # whole-clip tokens (not all: the stacked layers reach further back than one window, and the clip-wide statistics differ)
     _, ind_ref = O.encode_audio(w, mc, audio)
-    ci, _ = codec.extract_unit(audio.cuda(), process_window=2 * 16000, prefix_tokens=mc.en_coder_window_size // 2)
+    ci, _ = codec.extract_unit(audio.cuda(), process_window=2 * 16000, prefix_tokens=60)
     agree = float((ci.data.cpu() == ind_ref["indices"][0]).float().mean())
     ci1, _ = codec.extract_unit(audio.cuda(), process_window=2 * 16000, prefix_tokens=1)
     agree1 = float((ci1.data.cpu() == ind_ref["indices"][0]).float().mean())

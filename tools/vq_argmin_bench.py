@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Explicit-codebook L2 argmin (l3ac_vq_argmin): time and VALU-roofline fraction at the sizes BASELINE.json names."""
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parent.parent))
+from l3ac_amd import _capi
+from oracle import l3ac_oracle as O  # codebook table only (checker-side helper; nothing of the product imports it)
+
+lib = _capi.load_library()
+for levels, n in (([9, 9, 9, 7, 7, 7], 42752), ([7] * 6, 15360), ([7] * 6, 60), ([9, 9, 9, 7, 7, 7], 167)):
+    k = 1
+    for lv in levels:
+        k *= lv
+    q = torch.tanh(torch.randn(n, 6) * 1.2).cuda()
+    cb = O.codebook(levels).cuda()
+    idx = torch.empty(n, dtype=torch.int32, device="cuda")
+    nb = lib.l3ac_vq_argmin_scratch_bytes(n, k)
+    sc = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    f = lambda: _capi.check(lib.l3ac_vq_argmin(q.data_ptr(), n, cb.data_ptr(), k, 6, idx.data_ptr(), sc.data_ptr(), nb, s))
+    for _ in range(3):
+        f()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        f()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 100
+    print(f"K={k} N={n}: {ms:.3f} ms  {18.0 * n * k / ms / 1e9:.1f} TFLOP/s ({18.0 * n * k / ms / 1e9 / 157.3:.3f} of the fp32 VALU peak), "
+          f"{(28.0 * n + 24.0 * k) / ms / 1e6:.1f} GB/s algorithmic")
