@@ -94,6 +94,15 @@ void l3ac_destroy(l3ac_ctx* ctx);
  * before stream capture).  encode/decode grow the workspace themselves when not capturing. */
 int l3ac_reserve(l3ac_ctx* ctx, int32_t batch, int32_t samples);
 int64_t l3ac_workspace_bytes(const l3ac_ctx* ctx);
+/* decode_audio(indices = ...) takes its indices from outside (a wire stream): values outside [0, codebook size) are counted
+ * per context and clamped into range instead of being decomposed into wrapped level indices.  This call synchronises the
+ * device, writes the count since the last reset to *out and optionally resets it. */
+int l3ac_bad_index_count(l3ac_ctx* ctx, int32_t reset, int64_t* out);
+/* Guard of the GRN fast path (layers.py:112-115; l3ac_config.grn_exact).  A context created with grn_exact = 1 evaluates
+ * g / (g + 1e-8) per clip and keeps the smallest per-clip norm g = ||x||_2 any of its GRN layers has seen; this call
+ * synchronises the device, writes that minimum to *out (+inf if no GRN has run) and optionally resets it.  The fast path
+ * (grn_exact = 0) is exact whenever the reported minimum is >= 0.25. */
+int l3ac_grn_min_norm(l3ac_ctx* ctx, int32_t reset, float* out);
 int32_t l3ac_hop_length(const l3ac_ctx* ctx);
 
 /* encode_audio: audio [batch][samples] (row stride `audio_stride` floats) is right-padded with zeros to a

@@ -43,6 +43,10 @@ class Network:
         mc.check_supported()
         self.mc = mc
         self.training = True  # nn.Module default; the reference needs .eval() before inference (vq/fsq.py:31)
+        # GRN (layers.py:112-115) normalises by g / (g + 1e-8), g = the clip's L2 norm over the whole hidden tensor: exactly 1.0f in
+        # fp32 for g >= 0.25, which the kernels assume.  grn_exact = True (set BEFORE .to(device)) is the validation mode: the
+        # literal two-pass formula is evaluated (correct for any input) and min_grn_norm() reports the smallest g seen, i.e.
+        # whether the fast path would have been exact for the data that went through.
         self.grn_exact = False
         self._state_dicts = None
         self._folded = None
@@ -112,6 +116,13 @@ class Network:
             self._ctx.close()
             self._ctx = None
 
+    def min_grn_norm(self, reset: bool = False) -> float:
+        """Validation mode only (grn_exact = True): the smallest per-clip GRN norm seen so far; the default fast path is exact
+        for every input whose value here is >= 0.25."""
+        if not self.grn_exact:
+            raise RuntimeError("min_grn_norm() needs the validation mode: set network.grn_exact = True before .to(device)")
+        return self.context().grn_min_norm(reset)
+
     def context(self) -> _capi.Context:
         if self._ctx is None:
             raise RuntimeError(
@@ -179,8 +190,11 @@ class L3AC:
         return q_feature, {"indices": indices, "level_indices": level_indices}
 
     @torch.no_grad()
-    def decode_audio(self, audio_feature: torch.Tensor = None, indices: torch.Tensor = None) -> torch.Tensor:
-        """(B, T_tok, C) features, or int indices (B, T_tok) -> audio (B, T_tok * hop), not trimmed."""
+    def decode_audio(self, audio_feature: torch.Tensor = None, indices: torch.Tensor = None, validate: bool = False) -> torch.Tensor:
+        """(B, T_tok, C) features, or int indices (B, T_tok) -> audio (B, T_tok * hop), not trimmed.
+        Indices outside [0, codebook_size) — a corrupted or truncated token stream — are clamped into range and counted on
+        the device (``codec.network.context().bad_index_count()``); with ``validate=True`` the call synchronises and raises
+        if this call met any."""
         src = audio_feature if audio_feature is not None else indices
         if src is None:
             raise ValueError("decode_audio needs audio_feature or indices")
@@ -201,7 +215,13 @@ class L3AC:
         audio = torch.empty((b, n_tok * mc.hop_length), dtype=torch.float32, device=src.device)
         with torch.cuda.device(src.device):
             stream = torch.cuda.current_stream(src.device).cuda_stream
+            if validate and i_ptr is not None:
+                ctx.bad_index_count(reset=True)
             _capi.check(ctx.lib.l3ac_decode(ctx.handle, f_ptr, i_ptr, b, n_tok, audio.data_ptr(), stream))
+            if validate and i_ptr is not None:
+                bad = ctx.bad_index_count(reset=True)
+                if bad:
+                    raise ValueError(f"{bad} of {b * n_tok} indices lie outside [0, {mc.codebook_size}): corrupted token stream")
         del keep
         return audio
 

@@ -52,6 +52,8 @@ SIGNATURES = {
     "l3ac_destroy": (None, [_P]),
     "l3ac_reserve": (C.c_int, [_P, _I32, _I32]),
     "l3ac_workspace_bytes": (_I64, [_P]),
+    "l3ac_grn_min_norm": (C.c_int, [_P, _I32, C.POINTER(C.c_float)]),
+    "l3ac_bad_index_count": (C.c_int, [_P, _I32, C.POINTER(_I64)]),
     "l3ac_hop_length": (_I32, [_P]),
     "l3ac_encode": (C.c_int, [_P, _P, _I32, _I32, _I64, _P, _P, _P, _P]),
     "l3ac_decode": (C.c_int, [_P, _P, _P, _I32, _I32, _P, _P]),
@@ -207,6 +209,18 @@ class Context:
         return self.lib.l3ac_hop_length(self.handle)
 
     @property
+    def bad_index_count(self, reset: bool = False) -> int:
+        """Indices outside [0, codebook size) that decode calls of this context have met (and clamped).  Synchronises."""
+        out = _I64(0)
+        check(self.lib.l3ac_bad_index_count(self.handle, int(reset), C.byref(out)))
+        return int(out.value)
+
+    def grn_min_norm(self, reset: bool = False) -> float:
+        """Smallest per-clip GRN norm this context has seen (grn_exact contexts; +inf otherwise).  Synchronises."""
+        out = C.c_float(0.0)
+        check(self.lib.l3ac_grn_min_norm(self.handle, int(reset), C.byref(out)))
+        return float(out.value)
+
     def workspace_bytes(self) -> int:
         return self.lib.l3ac_workspace_bytes(self.handle)
 

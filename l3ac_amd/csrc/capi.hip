@@ -1,4 +1,5 @@
 // extern "C" entry points of libl3ac_hip.so (include/l3ac_hip.h).
+#include <cmath>
 #include <cstdarg>
 #include <cstring>
 #include <new>
@@ -143,6 +144,31 @@ int l3ac_reserve(l3ac_ctx* ctx, int32_t batch, int32_t samples) {
     return workspace_ensure_clip(ctx, batch, samples, nullptr);
 }
 
+int l3ac_bad_index_count(l3ac_ctx* ctx, int32_t reset, int64_t* out) {
+    L3AC_ENTER(ctx);
+    L3AC_REQUIRE(out != nullptr, "bad_index_count: null output");
+    L3AC_HIP_CHECK(hipDeviceSynchronize());
+    int v = 0;
+    L3AC_HIP_CHECK(hipMemcpy(&v, ctx->bad_index_count, sizeof(int), hipMemcpyDeviceToHost));
+    *out = v;
+    if (reset) L3AC_HIP_CHECK(hipMemset(ctx->bad_index_count, 0, sizeof(int)));
+    return L3AC_OK;
+}
+
+int l3ac_grn_min_norm(l3ac_ctx* ctx, int32_t reset, float* out) {
+    L3AC_ENTER(ctx);
+    L3AC_REQUIRE(out != nullptr, "grn_min_norm: null output");
+    L3AC_HIP_CHECK(hipDeviceSynchronize());
+    float v = 0.f;
+    L3AC_HIP_CHECK(hipMemcpy(&v, ctx->grn_min_sumsq, sizeof(float), hipMemcpyDeviceToHost));
+    *out = std::sqrt(v);
+    if (reset) {
+        const float inf = INFINITY;
+        L3AC_HIP_CHECK(hipMemcpy(ctx->grn_min_sumsq, &inf, sizeof(float), hipMemcpyHostToDevice));
+    }
+    return L3AC_OK;
+}
+
 int64_t l3ac_workspace_bytes(const l3ac_ctx* ctx) { return ctx ? (int64_t)ctx->ws.bytes() : 0; }
 int32_t l3ac_hop_length(const l3ac_ctx* ctx) { return ctx ? ctx->hop : 0; }
 
@@ -184,6 +210,7 @@ int l3ac_decode(l3ac_ctx* ctx, const float* q_feature, const int32_t* indices, i
         f.idx_in = indices; f.n = n; f.feat = ctx->cfg.feature_dim; f.n_levels = ctx->cfg.n_levels;
         for (int d = 0; d < f.n_levels; ++d) f.levels[d] = ctx->cfg.levels[d];
         f.w_out = ctx->q_wout; f.b_out = ctx->q_bout; f.q_feature = cur;
+        f.bad_count = ctx->bad_index_count;
         L3AC_TRY(launch_fsq(s, f));
     }
     int frames = 0;

@@ -107,7 +107,7 @@ bool head_pretanh_enabled();
 int launch_geglu(hipStream_t s, const float* h, int64_t ldh, float* y, int64_t ldy, int64_t rows, int inner);
 int launch_grn_sumsq(hipStream_t s, const float* h, int64_t batch, int64_t per_clip, float* sumsq);
 int launch_grn_apply(hipStream_t s, float* h, int64_t batch, int64_t frames, int c, const float* sumsq,
-                     const float* gamma, const float* beta);
+                     const float* gamma, const float* beta, float* min_track = nullptr);  // min_track: running minimum of sumsq
 
 // FirstBlock (tconv/__init__.py:8-27): audio [batch][samples] -> y [batch][frames][d0], frames >= samples (zero tail)
 struct FirstBlockW {
@@ -154,6 +154,7 @@ struct FsqArgs {
     float* level_indices = nullptr;
     float* latents = nullptr;
     bool act_in = false;              // x == idx_in == null and `latents` holds act = (tanh(lat) + 1) / 2 (vq/fsq.py:56)
+    int* bad_count = nullptr;         // decode path: device counter of indices outside [0, codebook size) (they are clamped)
 };
 int launch_fsq(hipStream_t s, const FsqArgs& a);
 // token bit stream (kernels/bitpack.hip)

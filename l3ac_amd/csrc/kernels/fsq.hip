@@ -37,6 +37,8 @@ struct FsqDev {
     float* level_indices;
     float* latents;
     int act_in;  // the `latents` input already holds act = (tanh(lat) + 1) / 2 (SuperFSQ.quantize_act_value's argument)
+    int k_total;      // codebook size: valid indices are 0 .. k_total - 1
+    int* bad_count;   // optional device counter of out-of-range input indices (which are clamped into range)
 };
 
 // streamed once: non-temporal accesses keep the rows out of the way of L2 / MALL residents
@@ -105,7 +107,11 @@ __global__ __launch_bounds__(THREADS) void fsq_kernel(const FsqDev p, const int 
         fetch(g + 1);
         float li[D];
         if (p.idx_in) {  // decode: indices -> level indices (vq/fsq.py:70-71)
-            const int idx = p.idx_in[tk];
+            int idx = p.idx_in[tk];
+            if ((unsigned)idx >= (unsigned)p.k_total) {  // corrupted / truncated stream: counted, clamped (never a wrapped level)
+                if (p.bad_count && ok && sub == 0) atomicAdd(p.bad_count, 1);
+                idx = idx < 0 ? 0 : p.k_total - 1;
+            }
 #pragma unroll
             for (int d = 0; d < D; ++d) li[d] = (float)((idx / p.basis[d]) % p.levels[d]);
         } else {
@@ -372,6 +378,8 @@ int launch_fsq(hipStream_t s, const FsqArgs& a) {
     p.w_in = a.w_in; p.b_in = a.b_in; p.w_out = a.w_out; p.b_out = a.b_out; p.idx_in = a.idx_in;
     p.q_feature = a.q_feature; p.indices = a.indices; p.level_indices = a.level_indices; p.latents = a.latents;
     p.act_in = a.act_in ? 1 : 0;
+    p.k_total = (int)basis;
+    p.bad_count = a.bad_count;
     if (a.act_in) L3AC_REQUIRE(!a.x && !a.idx_in && a.latents, "fsq: act_in needs the activation values in `latents` and no other input");
     switch (a.n_levels) {
         case 1: return launch_fsq_t<1>(s, p);

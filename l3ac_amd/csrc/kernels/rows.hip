@@ -350,8 +350,11 @@ __global__ __launch_bounds__(THREADS) void grn_sumsq_kernel(const float* __restr
 __global__ __launch_bounds__(THREADS) void grn_apply_kernel(float* __restrict__ h, int64_t per_clip4, int c4,
                                                            const float* __restrict__ sumsq,
                                                            const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta) {
+                                                           const float* __restrict__ beta, int* __restrict__ min_track) {
     const int64_t b = blockIdx.y;
+    // guard of the fast path (which takes the normaliser as exactly 1.0f, true for ||x|| >= 0.25): the smallest sum of squares
+    // seen by this context (non-negative floats order like their bit patterns)
+    if (min_track && blockIdx.x == 0 && threadIdx.x == 0) atomicMin(min_track, __float_as_int(sumsq[b]));
     const float g = sqrtf(sumsq[b]);
     const float nx = g / (g + 1e-8f);  // layers.py:114 (the mean over a size-1 dim is the value itself)
     float4* base = reinterpret_cast<float4*>(h) + b * per_clip4;
@@ -468,12 +471,12 @@ int launch_grn_sumsq(hipStream_t s, const float* h, int64_t batch, int64_t per_c
 }
 
 int launch_grn_apply(hipStream_t s, float* h, int64_t batch, int64_t frames, int c, const float* sumsq,
-                     const float* gamma, const float* beta) {
+                     const float* gamma, const float* beta, float* min_track) {
     const int64_t per_clip4 = frames * c / 4;
     const unsigned gx = (unsigned)(ceil_div64(per_clip4, THREADS * 8) < 1 ? 1 : ceil_div64(per_clip4, THREADS * 8));
     ProfScope prof(s, "grn_apply_kernel", 4.0 * batch * frames * c, 8.0 * batch * frames * c);
     hipLaunchKernelGGL(grn_apply_kernel, dim3(gx, (unsigned)batch), dim3(THREADS), 0, s, h, per_clip4, c / 4, sumsq, gamma,
-                       beta);
+                       beta, reinterpret_cast<int*>(min_track));
     L3AC_LAUNCH_CHECK();
     return L3AC_OK;
 }

@@ -427,6 +427,13 @@ int network_build(l3ac_ctx* ctx, const l3ac_tensor* tensors, int n_tensors) {
         }
     }
 
+    L3AC_HIP_CHECK(hipMalloc((void**)&ctx->bad_index_count, sizeof(int)));
+    L3AC_HIP_CHECK(hipMemset(ctx->bad_index_count, 0, sizeof(int)));
+    {  // GRN guard: starts at +inf
+        const float inf = INFINITY;
+        L3AC_HIP_CHECK(hipMalloc((void**)&ctx->grn_min_sumsq, sizeof(float)));
+        L3AC_HIP_CHECK(hipMemcpy(ctx->grn_min_sumsq, &inf, sizeof(float), hipMemcpyHostToDevice));
+    }
     // ---- name index for the per-block entry points ------------------------------------------------------
     blk = 1;
     for (int i = 0; i < c.n_enc; ++i) {
@@ -459,6 +466,10 @@ int network_build(l3ac_ctx* ctx, const l3ac_tensor* tensors, int n_tensors) {
 }
 
 void network_free(l3ac_ctx* ctx) {
+    if (ctx->bad_index_count) (void)hipFree(ctx->bad_index_count);
+    ctx->bad_index_count = nullptr;
+    if (ctx->grn_min_sumsq) (void)hipFree(ctx->grn_min_sumsq);
+    ctx->grn_min_sumsq = nullptr;
     if (ctx->arena) (void)hipFree(ctx->arena);
     ctx->arena = nullptr;
     if (ctx->img_arena) (void)hipFree(ctx->img_arena);
@@ -591,7 +602,7 @@ static int run_conv_unit_rows(l3ac_ctx* ctx, hipStream_t s, const ConvUnitW& w, 
     L3AC_TRY(launch_gemm(s, g));
     if (ctx->cfg.grn_exact) {
         L3AC_TRY(launch_grn_sumsq(s, ws.h, batch, (int64_t)frames * 4 * w.c, ws.sumsq));
-        L3AC_TRY(launch_grn_apply(s, ws.h, batch, frames, 4 * w.c, ws.sumsq, w.gamma, w.beta));
+        L3AC_TRY(launch_grn_apply(s, ws.h, batch, frames, 4 * w.c, ws.sumsq, w.gamma, w.beta, ctx->grn_min_sumsq));
     }
     GemmArgs g2{};  // pw_conv2 + residual (modules.py:39, xtract/nn/layers.py:59-62)
     g2.a = ws.h; g2.lda = 4 * w.c; g2.w = w.w2; g2.w_img = ctx->img(w.w2); g2.ldw = 4 * w.c; g2.c = y; g2.ldc = w.c; g2.m = rows; g2.n = w.c; g2.k = 4 * w.c;

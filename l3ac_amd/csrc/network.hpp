@@ -100,6 +100,8 @@ struct l3ac_ctx {
     Workspace ws;
     // Cross-stream ordering of the (single, in-place) workspace: every call that touches `ws` records `ws_done` on its stream
     // when it has enqueued its last kernel, and a later call on a DIFFERENT stream first makes that stream wait for it.
+    int* bad_index_count = nullptr;  // device: indices outside [0, codebook size) seen by l3ac_decode since the last reset
+    float* grn_min_sumsq = nullptr;  // device: smallest per-clip sum of squares any GRN of this context has seen (grn_exact only)
     hipEvent_t ws_done = nullptr;
     hipStream_t ws_stream = nullptr;
     bool ws_done_valid = false;

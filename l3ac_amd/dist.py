@@ -28,13 +28,15 @@ def shard_batch(batch: torch.Tensor, rank: Optional[int] = None, world: Optional
     return batch[start:stop]
 
 
-def gather_batch(local: torch.Tensor, total: int, group=None) -> torch.Tensor:
-    """All-gather per-rank slices (as produced by `shard_range`) back into the full batch, on every rank."""
+def gather_batch(local: torch.Tensor, total: int, group=None, force_ragged: bool = False) -> torch.Tensor:
+    """All-gather per-rank slices (as produced by `shard_range`) back into the full batch, on every rank.
+    `force_ragged` takes the padded path (the one a batch that does not divide by the world size needs) whatever the sizes,
+    also in a world of one: it is how that path is exercised on a single GPU (tests)."""
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not force_ragged:
         return local
     base, extra = divmod(total, world)
-    if extra == 0:  # equal shards: one collective straight into the output
+    if extra == 0 and not force_ragged:  # equal shards: one collective straight into the output
         out = torch.empty((total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(out, local.contiguous(), group=group)
         return out

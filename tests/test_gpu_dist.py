@@ -15,7 +15,7 @@ import os, sys
 sys.path.insert(0, os.environ["L3AC_REPO"])
 import torch, torch.distributed as dist
 import l3ac_amd
-from l3ac_amd.dist import ShardedCodec
+from l3ac_amd.dist import PendingGathers, ShardedCodec, gather_batch, gather_batch_async
 from tests.helpers import seeded_audio
 torch.cuda.set_device(0)
 dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
@@ -30,6 +30,13 @@ dist.all_reduce(t)
 out = torch.empty(6, 30, dtype=torch.int32, device="cuda")
 dist.all_gather_into_tensor(out, ind["indices"])
 ok = torch.equal(idx, ind["indices"]) and torch.equal(wave, ref) and torch.equal(out, ind["indices"]) and float(t.sum()) == 4.0
+# the padded (ragged-batch) gather path and the bench's overlap loop, on RCCL
+ok = ok and torch.equal(gather_batch(ref, 6, force_ragged=True), ref) and torch.equal(gather_batch(ind["indices"], 6, force_ragged=True), ind["indices"])
+pend = PendingGathers()
+for step in range(3):
+    pend.push(gather_batch_async(ind["indices"] + step, 6, force=True), gather_batch_async(ref * (step + 1), 6, force=True))
+pend.drain()
+ok = ok and pend.retired == 3 and torch.equal(pend.results[0], ind["indices"] + 2) and torch.equal(pend.results[1], ref * 3)
 dist.destroy_process_group()
 print("RCCL_OK" if ok else "RCCL_MISMATCH")
 """

@@ -344,6 +344,16 @@ def test_edge_cases():
     assert torch.equal(i1["indices"], i2["indices"])
     assert _err("grn exact vs fast (features)", q1, q2) < 1e-5
     assert _err("grn exact vs fast (wave)", codec.decode_audio(q1), exact.decode_audio(q1)) < 1e-4  # fused vs unfused summation order
+    # the guard of the fast path: in validation mode the context reports the smallest GRN norm it has seen — far above the 0.25
+    # below which g / (g + 1e-8) stops being exactly 1.0f, for ordinary audio and for digital silence alike
+    assert exact.network.min_grn_norm() > 0.25
+    exact.network.min_grn_norm(reset=True)
+    exact.decode_audio(exact.encode_audio(torch.zeros(1, 4000).cuda())[0])
+    g_silence = exact.network.min_grn_norm()
+    print(f"[grn guard] smallest ||x|| over all GRN layers on digital silence: {g_silence:.3e}")
+    assert 0.25 < g_silence < float("inf")
+    with pytest.raises(RuntimeError):
+        codec.network.min_grn_norm()  # only the validation mode tracks it
     # errors are loud
     with pytest.raises(RuntimeError):
         codec.encode_audio(torch.zeros(1, 1000))  # CPU tensor: no CPU path
@@ -351,6 +361,22 @@ def test_edge_cases():
         codec.encode_audio(torch.zeros(1000).cuda())
     with pytest.raises(ValueError):
         codec.decode_audio()
+    # indices from outside: out-of-range values are counted and clamped, never decomposed into wrapped levels
+    good = codec.encode_audio(seeded_audio(1, 4000).cuda())[1]["indices"]
+    bad = good.clone()
+    bad[0, 3] = mc.codebook_size + 5
+    bad[0, 7] = -1
+    ctx = codec.network.context()
+    ctx.bad_index_count(reset=True)
+    wave_bad = codec.decode_audio(indices=bad)
+    assert ctx.bad_index_count(reset=True) == 2 and torch.isfinite(wave_bad).all()
+    clamped = good.clone()
+    clamped[0, 3] = mc.codebook_size - 1
+    clamped[0, 7] = 0
+    assert torch.equal(wave_bad, codec.decode_audio(indices=clamped))
+    with pytest.raises(ValueError, match="outside"):
+        codec.decode_audio(indices=bad, validate=True)
+    codec.decode_audio(indices=good, validate=True)
 
 
 def test_long_clip_multi_window_attention():
