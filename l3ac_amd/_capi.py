@@ -208,7 +208,6 @@ class Context:
     def hop_length(self) -> int:
         return self.lib.l3ac_hop_length(self.handle)
 
-    @property
     def bad_index_count(self, reset: bool = False) -> int:
         """Indices outside [0, codebook size) that decode calls of this context have met (and clamped).  Synchronises."""
         out = _I64(0)
@@ -221,6 +220,7 @@ class Context:
         check(self.lib.l3ac_grn_min_norm(self.handle, int(reset), C.byref(out)))
         return float(out.value)
 
+    @property
     def workspace_bytes(self) -> int:
         return self.lib.l3ac_workspace_bytes(self.handle)
 
