@@ -66,6 +66,17 @@ struct WGeo {
     static_assert(LDS <= 160 * 1024, "LDS budget exceeded");
 };
 
+#ifdef L3AC_WIDE_STAMPS  // diagnostic build (tools/wide_stamps.py): s_memtime at the phase boundaries of every pass of wave 0
+__device__ unsigned long long g_wide_stamps[256 * 16 * 8];
+#define WIDE_STAMP(slot)                                                                                      \
+    do {                                                                                                      \
+        if (lane == 0 && wave == 0 && pass_no < 16)                                                           \
+            g_wide_stamps[((size_t)blockIdx.x * 16 + pass_no) * 8 + (slot)] = __builtin_amdgcn_s_memtime();   \
+    } while (0)
+#else
+#define WIDE_STAMP(slot) do { } while (0)
+#endif
+
 __device__ __forceinline__ int rowmap(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 
 // one 1-KB LDS-DMA piece: lane l copies 16 B from its own source pointer to lds_dst + 16 l (guide §5.7: M0 is written
@@ -135,7 +146,10 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
     const int64_t n_tiles = (rows + 31) / 32;
     const int64_t tile_stride = (int64_t)gridDim.x * 4;
     // every wave of the block runs the same number of passes (block barriers inside)
-    for (int64_t base = (int64_t)blockIdx.x * 4; base < n_tiles; base += tile_stride) {
+    int pass_no = 0;
+    (void)pass_no;
+    for (int64_t base = (int64_t)blockIdx.x * 4; base < n_tiles; base += tile_stride, ++pass_no) {
+        WIDE_STAMP(0);
         const int64_t tile = base + wave;              // this wave's 32 rows (beyond the last tile: its results are not stored)
         const int64_t row0 = tile * 32;
         const bool tile_ok = tile < n_tiles;
@@ -151,6 +165,7 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
                 for (int pl = 0; pl < 3; ++pl) ap[s][pl] = *reinterpret_cast<const bf16x8*>(src + (s * 3 + pl) * 1024);
         }
 
+        WIDE_STAMP(1);
         // ---- output accumulators start at the pw_conv2 bias ------------------------------------------------------
         f32x16_t yacc[G::CT];
 #pragma unroll
@@ -217,6 +232,7 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
             }
         };
 
+        WIDE_STAMP(2);
         // ---- first product of hidden tile 0 (ring slots 0 .. NA-1): nothing to overlap with -------------------------
         bf16x8 wf[3];
         frag(0, 0, wf);
@@ -239,6 +255,7 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
             step_sync();
         }
 
+        WIDE_STAMP(3);
 #pragma unroll 1
         for (int nt = 0; nt + 1 < G::NT; ++nt) {
             // ---- first product of tile nt+1 (slots NA .. 2NA-1) beside the activation of tile nt ----------------------
@@ -269,11 +286,13 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
             second_product(std::integral_constant<int, 0>{}, std::false_type{}, wf);
             xacc = xnext;
         }
+        WIDE_STAMP(4);
         // ---- last hidden tile: activation alone, second product from slots NA .. 2NA-1 ------------------------------
 #pragma unroll
         for (int pr = 0; pr < 8; ++pr) act_pair(xacc, G::NT - 1, 2 * pr);
         second_product(std::integral_constant<int, G::NA>{}, std::true_type{}, wf);
 
+        WIDE_STAMP(5);
         // ---- residual + store (xtract/nn/layers.py:59-62).  The accumulators hold, per lane, 4 channels of ONE frame for each of
         // the 4 C/32 (tile, group) pairs: stored directly that is 32 B per row per instruction.  Instead every 32-channel tile
         // goes through a 4-KB LDS buffer of this wave — written as [32 frames][8 slots of 16 B], slot = quad ^ swz(frame), read
@@ -313,6 +332,7 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
             __builtin_amdgcn_wave_barrier();
         }
     }
+    WIDE_STAMP(6);
     // leave no LDS-DMA in flight behind the workgroup
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -412,6 +432,12 @@ int launch_wide(hipStream_t s, const ConvUnitW& w, const float* x, float* y, uns
 }
 
 }  // namespace
+
+#ifdef L3AC_WIDE_STAMPS
+extern "C" int l3ac_debug_wide_stamps(unsigned long long* out, int n) {  // diagnostic builds only (not part of the ABI)
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wide_stamps), (size_t)n * sizeof(unsigned long long));
+}
+#endif
 
 bool conv_unit_wide_supported(int c) { return c == 128 || c == 192 || c == 256; }
 // scratch the pair of kernels needs: the split LayerNorm output of `rows` frames (whole 32-frame tiles), 6 bytes per element

@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
-"""Where conv_unit_wide_kernel spends its cycles (diagnostic build only):
+"""Where a pass of conv_unit_wide_kernel spends its cycles (diagnostic build only):
 
     L3AC_EXTRA_HIPCC_FLAGS=-DL3AC_WIDE_STAMPS python -m l3ac_amd.build      # in the build container
     gpurun -- python tools/wide_stamps.py [C] [batch] [frames]
 
-The kernel stamps s_memtime (shader cycles) for wave 0 (group A) and wave 4 (group B) of every workgroup at: 0 start of a
-pass (= start of its memory phase) | 1 end of the memory phase | 2 end of the compute phase, into a __device__ array that
-only this tool reads.
+The kernel stamps s_memtime (shader cycles) at the phase boundaries of every pass of wave 0 of every workgroup into a
+__device__ array that only this tool reads.  Phases: 0 pass start | 1 after the plane loads | 2 after the entry barrier |
+3 after the first product of hidden tile 0 | 4 after the hidden-tile loop | 5 after the last tile | 6 after the residual store
+(written by the NEXT stamp 0 / the final stamp).  (tools/experiments/conv_unit_wide_v1.hip / _v2.hip carry the same stamps.)
 """
 import ctypes as C
 import sys
@@ -37,29 +38,27 @@ e0.record()
 _capi.check(lib.l3ac_op_conv_unit(ctx.handle, block.encode(), x.data_ptr(), batch, frames, y.data_ptr(), s))
 e1.record()
 torch.cuda.synchronize()
-ms = e0.elapsed_time(e1)
-rows = batch * frames
-print(f"C={c} rows={rows}: {ms:.3f} ms = {rows * (16.0 * c * c) / ms / 1e9:.1f} TFLOP/s fp32-equivalent")
-n = 256 * 2 * 16 * 4
+print(f"C={c} rows={batch * frames}: {e0.elapsed_time(e1):.3f} ms")
+n = 256 * 16 * 8
 buf = np.zeros(n, dtype=np.uint64)
 fn = lib.l3ac_debug_wide_stamps
 fn.restype = C.c_int
 assert fn(buf.ctypes.data_as(C.c_void_p), n) == 0
-st = buf.reshape(256, 2, 16, 4).astype(np.int64)
-nb = 4 * c // 32
-ideal_compute = nb * 2 * (c // 32) * 6 * 2 * 16  # MFMA cycles of one tile: blocks x (2 tiles x NK + CT) k steps x 6 x 16 cycles
-for g in range(2):
-    for p in range(16):
-        ok = [b for b in range(256) if st[b, g, p, 0] > 0 and st[b, g, p, 2] > 0]
-        if not ok:
-            continue
-        mem = np.median([st[b, g, p, 1] - st[b, g, p, 0] for b in ok])
-        comp = np.median([st[b, g, p, 2] - st[b, g, p, 1] for b in ok])
-        print(f"group {'AB'[g]} pass {p} ({len(ok)} blocks): memory phase {mem / 1e3:.1f}k | compute phase {comp / 1e3:.1f}k "
-              f"(its own MFMA cycles: {ideal_compute / 1e3:.1f}k; the SIMD's pipe serves two such waves)")
-first = st[:, :, 0, 0]
-last = st[:, :, :, 1:3].max(axis=(2, 3))
-span = (last.max(axis=1) - np.where(first > 0, first, np.iinfo(np.int64).max).min(axis=1))[first.max(axis=1) > 0]
-passes = int(np.ceil(np.ceil(rows / 16) / 8 / 256))
-print(f"kernel span per block: median {np.median(span) / 1e3:.0f}k cycles, max {span.max() / 1e3:.0f}k; MFMA-only lower bound "
-      f"{passes * 2 * ideal_compute / 1e3:.0f}k (2 tiles per SIMD and pass, {passes} passes); clock ~{np.median(span) / ms / 1e6:.2f} GHz")
+st = buf.reshape(256, 16, 8).astype(np.int64)
+passes = int(np.ceil(np.ceil(batch * frames / 32) / 4 / 256))
+names = ["plane loads", "entry barrier", "first product (tile 0)", "hidden-tile loop", "last tile", "residual + store"]
+tot = []
+for p in range(passes):
+    blk = [b for b in range(256) if st[b, p, 0] > 0 and st[b, p, 5] > 0]
+    d = np.array([[st[b, p, i + 1] - st[b, p, i] for i in range(5)] for b in blk])
+    # the pass ends where the next one starts (stamp 0), or — last pass of a block — at the exit stamp, which the kernel
+    # stores under the pass counter's final value
+    nxt = np.array([(st[b, p + 1, 0] if st[b, p + 1, 0] > 0 else st[b, p + 1, 6]) - st[b, p, 5] for b in blk])
+    med = list(np.median(d, axis=0)) + [float(np.median(nxt))]
+    tot.append(med)
+    print(f"pass {p} ({len(blk)} blocks): " + " | ".join(f"{n_} {m / 1e3:.1f}k" for n_, m in zip(names, med)) + f" | total {sum(med) / 1e3:.1f}k cycles")
+tot = np.array(tot)
+print("share of a pass: " + ", ".join(f"{n_} {100 * v:.1f}%" for n_, v in zip(names, tot.sum(0) / tot.sum())))
+span = np.array([st[b, :, 6].max() - st[b, 0, 0] for b in range(256) if st[b, 0, 0] > 0])
+print(f"kernel span per block: median {np.median(span) / 1e3:.0f}k cycles, max {span.max() / 1e3:.0f}k; "
+      f"ideal MFMA-only: {passes * (4 * c // 32) * (c // 16 + c // 16) * 6 * 32 / 1e3:.0f}k")
