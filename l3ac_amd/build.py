@@ -65,12 +65,19 @@ def _depfile_newest(dep: Path) -> float:
     return newest
 
 
+# Flags of single sources.  conv_unit_wide.hip places single-issue vector instructions one by one into the gaps behind its
+# MFMAs; the SLP vectoriser would re-pack the per-element fp32 operations into v_pk_*_f32, which cost several times their
+# issue slot beside an MFMA (MI355X_MICROARCH.md, 'price of one filler beside MFMAs').
+PER_FILE_FLAGS = {"kernels/conv_unit_wide.hip": ["-fno-slp-vectorize"]}
+
+
 def _flag_stamp(hipcc: str, flags) -> str:
     """Identity of everything that shapes an object besides its sources: the flag list (L3AC_EXTRA_HIPCC_FLAGS included)
     and the compiler version.  A change forces a full rebuild."""
     import hashlib
     ver = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout
-    return hashlib.sha256(("\n".join(flags) + "\n" + ver).encode()).hexdigest()
+    per_file = "\n".join(f"{k}: {' '.join(v)}" for k, v in sorted(PER_FILE_FLAGS.items()))
+    return hashlib.sha256(("\n".join(flags) + "\n" + per_file + "\n" + ver).encode()).hexdigest()
 
 
 def build_library(force: bool = False, verbose: bool = False) -> Path:
@@ -95,7 +102,7 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
             newest = max(s.stat().st_mtime, _depfile_newest(d) if d.exists() else hdr_time)
             stale = o.stat().st_mtime < newest
         if stale:
-            jobs.append([hipcc, *flags, "-MD", "-MF", str(d), "-c", str(s), "-o", str(o)])
+            jobs.append([hipcc, *flags, *PER_FILE_FLAGS.get(src, []), "-MD", "-MF", str(d), "-c", str(s), "-o", str(o)])
 
     def run(cmd):
         if verbose:

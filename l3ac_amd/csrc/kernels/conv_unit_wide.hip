@@ -55,11 +55,14 @@ struct WGeo {
     static constexpr int RING = NSTEP * SLOT;
     static constexpr int TOTAL = NT * NSTEP;  // slots of the whole stream
     static constexpr int WAIT = 3 * (PF - 2); // this wave's DMA instructions that may stay outstanding at a step's end
-    // LDS (bytes): ring | alpha, 1/alpha, gamma, beta [4][H4] | b1 [H4] | b2 [C] | epilogue transposition buffers
-    static constexpr int OFF_P = RING;
+    // LDS (bytes): alpha, 1/alpha, gamma, beta [4][H4] | b1 [H4] | b2 [C] | ring | epilogue transposition buffers.  The tables
+    // come first so that their reads (one per activation pair, the tile index in the address) reach with the 16-bit
+    // immediate of ds_read from one lane base
+    static constexpr int OFF_P = 0;
     static constexpr int OFF_B1 = OFF_P + 4 * H4 * 4;
     static constexpr int OFF_B2 = OFF_B1 + H4 * 4;
-    static constexpr int OFF_TB = OFF_B2 + C * 4;             // epilogue transposition buffers: 2 x 4 KB per wave
+    static constexpr int OFF_RING = OFF_B2 + C * 4;
+    static constexpr int OFF_TB = OFF_RING + RING;            // epilogue transposition buffers: 2 x 4 KB per wave
     static constexpr int LDS = OFF_TB + 4 * 8192;
     static_assert(C % 64 == 0 && NS1 % KS == 0 && CT % 2 == 0 && NA == CT / 2, "bad geometry");
     static_assert(PF >= 3 && WAIT <= 63, "ring too small / vmcnt field too narrow");
@@ -79,14 +82,125 @@ __device__ unsigned long long g_wide_stamps[256 * 16 * 8];
 
 __device__ __forceinline__ int rowmap(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 
-// one 1-KB LDS-DMA piece: lane l copies 16 B from its own source pointer to lds_dst + 16 l (guide §5.7: M0 is written
-// in the statement that uses it; the copy is invisible to hipcc's s_waitcnt bookkeeping and is counted by hand)
-__device__ __forceinline__ void dma16(const unsigned char* gsrc, unsigned lds_dst) {
+// this wave's quarter of one 12-KB slot: three 1-KB LDS-DMA pieces, lane l copying 16 B from base + 16 l (+0, +1024, +2048) to
+// lds_dst + 16 l (+ the same).  One statement = one M0 write for the three pieces (the instruction offset is added to the
+// global AND the LDS address), a wave-uniform 64-bit base in SGPRs and one loop-invariant 32-bit lane offset: no vector
+// address arithmetic per piece (guide §5.7: M0 is written in the statement that uses it; the copies are invisible to hipcc's
+// s_waitcnt bookkeeping and are counted by hand).
+__device__ __forceinline__ void dma_slot_quarter(const unsigned char* base, unsigned lane_off, unsigned lds_dst) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
-                 : "memory");
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(lane_off), "s"(base), "s"(lds_dst)
+        : "memory");
+}
+
+template <int N, class F, int I = 0>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, F, I + 1>(static_cast<F&&>(f));
+    }
+}
+
+// ---- the activation of one PAIR of hidden rows (two elements per lane), cut into stages of at most three single-issue vector
+// instructions so that the kernel can place them one by one into the gaps behind its MFMAs (one wave per SIMD: ~5
+// single-issue instructions hide behind a 32-cycle MFMA; packed-fp32 instructions are an anti-lever there — guide,
+// 'price of one filler beside MFMAs' — so every operation is written per element and the file is built with
+// -fno-slp-vectorize).  The arithmetic is device_math.hpp's snake_act2 / sin_squared2 followed by GRN with normaliser 1 and
+// split_bf16.hpp's split2, operation for operation: the results are bit-identical to those helpers'.
+struct ActPair {
+    float h[2], t[2], n[2], r[2], z[2], p[2], c[2], o[2], sv[2];
+    float al[2], ia[2], ga[2], be[2];
+    int ni[2];
+    unsigned p0, p1;
+};
+constexpr int ACT_STAGES = 27;
+// tab: this lane's row of the interleaved parameter table for the pair (alpha, alpha', 1/alpha, 1/alpha' | gamma, gamma', beta,
+// beta'); h0/h1: the pair's pre-activations; out0..2: the pair's packed bf16 planes
+template <int T>
+__device__ __forceinline__ void act_stage(ActPair& a, const float* tab, float h0, float h1, unsigned& out0, unsigned& out1, unsigned& out2) {
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+#define L3AC_BOTH(expr) _Pragma("unroll") for (int e = 0; e < 2; ++e) { expr; }
+    if constexpr (T == 0) {
+        const f32x4v v = *reinterpret_cast<const f32x4v*>(tab);
+        a.al[0] = v.x, a.al[1] = v.y, a.ia[0] = v.z, a.ia[1] = v.w;
+    } else if constexpr (T == 1) {
+        const f32x4v v = *reinterpret_cast<const f32x4v*>(tab + 4);
+        a.ga[0] = v.x, a.ga[1] = v.y, a.be[0] = v.z, a.be[1] = v.w;
+    } else if constexpr (T == 2) {
+        a.h[0] = h0, a.h[1] = h1;
+    } else if constexpr (T == 3) {
+        L3AC_BOTH(a.t[e] = a.al[e] * a.h[e])
+    } else if constexpr (T == 4) {
+        L3AC_BOTH(a.t[e] = __builtin_amdgcn_fmed3f(a.t[e], -SIN2_ARG_MAX, SIN2_ARG_MAX))
+    } else if constexpr (T == 5) {
+        L3AC_BOTH(a.n[e] = a.t[e] * 0.636619772367581343f)
+    } else if constexpr (T == 6) {
+        L3AC_BOTH(a.n[e] = __builtin_rintf(a.n[e]))
+    } else if constexpr (T == 7) {
+        L3AC_BOTH(a.r[e] = __builtin_fmaf(a.n[e], -1.57079637050628662109375f, a.t[e]))
+    } else if constexpr (T == 8) {
+        L3AC_BOTH(a.r[e] = __builtin_fmaf(a.n[e], 4.37113900018624283e-8f, a.r[e]))
+    } else if constexpr (T == 9) {
+        L3AC_BOTH(a.z[e] = a.r[e] * a.r[e])
+    } else if constexpr (T == 10) {
+        L3AC_BOTH(a.p[e] = __builtin_fmaf(a.z[e], -1.9515295891e-4f, 8.3321608736e-3f))
+    } else if constexpr (T == 11) {
+        L3AC_BOTH(a.p[e] = __builtin_fmaf(a.p[e], a.z[e], -1.6666654611e-1f))
+    } else if constexpr (T == 12) {
+        L3AC_BOTH(a.p[e] = a.p[e] * a.z[e])
+    } else if constexpr (T == 13) {
+        L3AC_BOTH(a.p[e] = __builtin_fmaf(a.p[e], a.r[e], a.r[e]))  // sin(r), |r| <= pi/4
+    } else if constexpr (T == 14) {
+        L3AC_BOTH(a.p[e] = a.p[e] * a.p[e])
+    } else if constexpr (T == 15) {
+        L3AC_BOTH(a.c[e] = __builtin_fmaf(a.p[e], -2.0f, 1.0f))  // cos(2r)
+    } else if constexpr (T == 16) {
+        L3AC_BOTH(a.ni[e] = (int)a.n[e])
+    } else if constexpr (T == 17) {
+        L3AC_BOTH(a.ni[e] = (int)((unsigned)a.ni[e] << 31))
+    } else if constexpr (T == 18) {
+        L3AC_BOTH(a.c[e] = __builtin_bit_cast(float, __builtin_bit_cast(int, a.c[e]) ^ a.ni[e]))  // cos(2u) = (-1)^n cos(2r)
+    } else if constexpr (T == 19) {
+        L3AC_BOTH(a.c[e] = __builtin_fmaf(a.c[e], -0.5f, 0.5f))  // sin(u)^2 = (1 - cos 2u) / 2
+    } else if constexpr (T == 20) {
+        L3AC_BOTH(a.sv[e] = __builtin_fmaf(a.ia[e], a.c[e], a.h[e]))  // snake
+    } else if constexpr (T == 21) {
+        L3AC_BOTH(a.o[e] = __builtin_fmaf(a.ga[e], a.sv[e], a.be[e]))  // GRN, normaliser 1
+    } else if constexpr (T == 22) {
+        L3AC_BOTH(a.o[e] = a.o[e] + a.sv[e])
+    } else if constexpr (T == 23) {
+        const f32x2_t v = {a.o[0], a.o[1]};
+        a.p0 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+        out0 = a.p0;
+        a.t[0] = __builtin_bit_cast(float, a.p0 << 16), a.t[1] = __builtin_bit_cast(float, a.p0 & 0xffff0000u);
+    } else if constexpr (T == 24) {
+        L3AC_BOTH(a.r[e] = a.o[e] - a.t[e])
+        const f32x2_t v = {a.r[0], a.r[1]};
+        a.p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+        out1 = a.p1;
+    } else if constexpr (T == 25) {
+        a.t[0] = __builtin_bit_cast(float, a.p1 << 16), a.t[1] = __builtin_bit_cast(float, a.p1 & 0xffff0000u);
+    } else {
+        static_assert(T == ACT_STAGES - 1, "stage list out of step with ACT_STAGES");
+        L3AC_BOTH(a.z[e] = a.r[e] - a.t[e])
+        const f32x2_t v = {a.z[0], a.z[1]};
+        out2 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+    }
+#undef L3AC_BOTH
+}
+
+// one of the six plane products of a k step, in mfma_split's order (split_bf16.hpp)
+template <int M>
+__device__ __forceinline__ f32x16_t mfma_plane(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16_t acc) {
+    constexpr int IA[6] = {2, 1, 0, 1, 0, 0}, IB[6] = {0, 1, 2, 0, 1, 0};
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[IA[M]], b[IB[M]], acc, 0, 0, 0);
 }
 
 template <int C>
@@ -94,8 +208,8 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
                                                               const float* __restrict__ x, float* __restrict__ y, const int64_t rows) {
     using G = WGeo<C>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_wide[];
-    unsigned char* ring = smem_wide;
-    float* Ps = reinterpret_cast<float*>(smem_wide + G::OFF_P);
+    unsigned char* ring = smem_wide + G::OFF_RING;
+    float* Pt = reinterpret_cast<float*>(smem_wide + G::OFF_P);
     float* B1s = reinterpret_cast<float*>(smem_wide + G::OFF_B1);
     float* B2s = reinterpret_cast<float*>(smem_wide + G::OFF_B2);
     const int tid = threadIdx.x;
@@ -106,14 +220,11 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
 
     // ---- the weight stream: this wave copies bytes [3072 wave, 3072 wave + 3072) of every slot ------------------
     const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)ring;
-    const unsigned char* const src_lane = w.wide_img + 3072 * wave + 16 * lane;
+    const unsigned char* const src_wave = w.wide_img + 3072 * wave;  // wave-uniform
+    const unsigned lane_off = 16u * (unsigned)lane;
     int dma_slot = 0;  // next slot of the stream to fetch (wave-uniform)
     auto issue = [&](int ring_pos) __attribute__((always_inline)) {
-        const unsigned char* src = src_lane + (int64_t)dma_slot * G::SLOT;
-        const unsigned dst = ring_lds + (unsigned)(ring_pos * G::SLOT) + 3072u * (unsigned)wave;
-        dma16(src, dst);
-        dma16(src + 1024, dst + 1024u);
-        dma16(src + 2048, dst + 2048u);
+        dma_slot_quarter(src_wave + (int64_t)dma_slot * G::SLOT, lane_off, ring_lds + (unsigned)(ring_pos * G::SLOT) + 3072u * (unsigned)wave);
         dma_slot = dma_slot + 1 == G::TOTAL ? 0 : dma_slot + 1;
     };
     // end of a step: this wave's pieces of the slot after next have landed, then everybody's have, and everybody is done
@@ -127,21 +238,17 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
     for (int j = 0; j < G::PF; ++j) issue(j);
 
     // ---- parameters resident for the lifetime of the workgroup ---------------------------------------------------
+    // activation parameters, interleaved per PAIR of hidden channels (2c, 2c+1): alpha x2, 1/alpha x2 | gamma x2, beta x2
     for (int i = tid; i < G::H4; i += 256) {
-        Ps[i] = w.alpha[i];
-        Ps[G::H4 + i] = w.inv_alpha[i];
-        Ps[2 * G::H4 + i] = w.gamma[i];
-        Ps[3 * G::H4 + i] = w.beta[i];
+        float* row = Pt + 8 * (i >> 1) + (i & 1);
+        row[0] = w.alpha[i];
+        row[2] = w.inv_alpha[i];
+        row[4] = w.gamma[i];
+        row[6] = w.beta[i];
         B1s[i] = w.b1[i];
     }
     for (int i = tid; i < C; i += 256) B2s[i] = w.b2[i];
     __syncthreads();  // (plain loads above: hipcc drains them here, the DMA pieces with them)
-
-    auto frag = [&](int ring_pos, int piece, bf16x8 (&f)[3]) __attribute__((always_inline)) {  // 3 planes of one k step
-        const unsigned char* p = ring + ring_pos * G::SLOT + piece * 3072 + 16 * lane;
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) f[pl] = *reinterpret_cast<const bf16x8*>(p + 1024 * pl);
-    };
 
     const int64_t n_tiles = (rows + 31) / 32;
     const int64_t tile_stride = (int64_t)gridDim.x * 4;
@@ -183,114 +290,150 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
             for (int r = 0; r < 16; ++r) acc[r] = B1s[32 * nt + rowmap(r, lh)];
             return acc;
         };
-        // snake + GRN (normaliser == 1; layers.py:29-33, :112-115) on rows (r, r + 1) of hidden tile nt, in place, and the
-        // bf16x3 split of the pair into element (r & 7) / 2 of k step r / 8 of the second product's B operand
+        // the activated hidden tile as the second product's B operand (snake + GRN with normaliser 1, layers.py:29-33, :112-115,
+        // then the bf16x3 split): element j of k step s, plane pl
         unsigned xbp[2][3][4];
-        auto act_pair = [&](f32x16_t& xacc, int nt, int r) __attribute__((always_inline)) {
-            const float* pp = Ps + 32 * nt + rowmap(r, lh);
-            const f32x2 al = *reinterpret_cast<const f32x2*>(pp);
-            const f32x2 ia = *reinterpret_cast<const f32x2*>(pp + G::H4);
-            const f32x2 ga = *reinterpret_cast<const f32x2*>(pp + 2 * G::H4);
-            const f32x2 be = *reinterpret_cast<const f32x2*>(pp + 3 * G::H4);
-            f32x2 hv;
-            hv.x = xacc[r];
-            hv.y = xacc[r + 1];
-            const f32x2 sv = snake_act2(hv, al, ia);
-            const f32x2 o = __builtin_elementwise_fma(ga, sv, be) + sv;
-            split2(o.x, o.y, xbp[r >> 3][0][(r & 7) >> 1], xbp[r >> 3][1][(r & 7) >> 1], xbp[r >> 3][2][(r & 7) >> 1]);
+        unsigned xbq[3][4];  // first half of the NEXT tile while xbp[0] still feeds the running second product (a separate array: updating
+                             // xbp[0] in place made hipcc keep both generations of every tuple and spill 240 registers)
+        // One ring slot = one "slot step" of 24 MFMAs (4 k steps of the first product, or 2 output tiles x 2 k steps of the
+        // second), closed by step_sync.  Every instruction of a slot step is placed by hand into one of its 24 MFMA gaps and
+        // a sched_barrier(0) closes each gap: gap g = (k step ks, plane product m) holds the MFMA, at even m one fragment read
+        // of the NEXT k step (planes in the order the MFMAs take them: 2, 1, 0 — four to six gaps ahead of their use; the last
+        // k step fetches the first fragment of the following slot, which landed a step ago), in gap 0 the DMA issue, and the
+        // stages of the activation stream that fall to it.  The activation of a hidden tile is 8 pairs x ACT_STAGES stages:
+        // its first half (rows 0-7 = k step 0 of the second product's B operand) runs beside the SECOND product of the
+        // previous tile, its second half beside the FIRST product of the next tile, so the vector work is spread over all
+        // 2 NA x 24 gaps of an iteration.
+        bf16x8 fb[2][3];
+        auto frag1 = [&](int ring_pos, int piece, int pl) __attribute__((always_inline)) -> bf16x8 {
+            return *reinterpret_cast<const bf16x8*>(ring + ring_pos * G::SLOT + piece * 3072 + 16 * lane + 1024 * pl);
         };
-        // second product of hidden tile nt from the ring slots OFF .. OFF + NA - 1 (2 output tiles per slot);
-        // wf holds the first fragment on entry and, unless LAST_OF_PASS, the next slot's first fragment on exit
-        auto second_product = [&](auto off_, auto last_, bf16x8 (&wf)[3]) __attribute__((always_inline)) {
-            constexpr int OFF = decltype(off_)::value;
-            constexpr bool LAST_OF_PASS = decltype(last_)::value;
-            bf16x8 xb[2][3];
+        ActPair ast[4];
+        // stages of the half-tile stream (4 pairs x ACT_STAGES) that fall to gap `gap` of the half phase's 24 NA gaps
+        auto act_gap = [&](auto gap_, auto half_, const f32x16_t& xa, const float* tab) __attribute__((always_inline)) {
+            constexpr int GAP = decltype(gap_)::value, HALF = decltype(half_)::value;
+            constexpr int TOTAL_ST = 4 * ACT_STAGES, GAPS = 24 * G::NA;
+            constexpr int LO = GAP * TOTAL_ST / GAPS, HI = (GAP + 1) * TOTAL_ST / GAPS;
+            static_for<HI - LO>([&](auto k_) {
+                constexpr int ST = LO + decltype(k_)::value, P = ST / ACT_STAGES, T = ST % ACT_STAGES;
+                constexpr int R = 2 * (4 * HALF + P);  // the pair's first accumulator register
+                // rows rowmap(R, lh), +1 of the tile: table row (32 nt + rowmap) / 2, 8 floats each; tab carries nt and lh
+                if constexpr (HALF == 0)
+                    act_stage<T>(ast[P], tab + 4 * ((R & 3) + 8 * (R >> 2)), xa[R], xa[R + 1], xbq[0][P], xbq[1][P], xbq[2][P]);
+                else
+                    act_stage<T>(ast[P], tab + 4 * ((R & 3) + 8 * (R >> 2)), xa[R], xa[R + 1], xbp[1][0][P], xbp[1][1][P], xbp[1][2][P]);
+            });
+        };
+        // PHASE 0: first product, k steps KS I .. KS I + 3 of a hidden tile from ring slot POS into acc.
+        // PHASE 1: second product, output tiles 2 I, 2 I + 1 from ring slot POS (piece 2 c2 + s) with B operand xb.
+        // NEXT: the ring slot whose first fragment is fetched for the following slot step (-1: none).  ACT: -1 none, else the
+        // half (0 / 1) of the activation stream of xa that runs in the gaps.  BIAS: fetch the next-but-one tile's pw_conv1 bias
+        // into xinit (the registers the finished tile left) at the free odd gaps.
+        auto slot_step = [&](auto phase_, auto pos_, auto next_, auto i_, auto act_, auto bias_, int issue_pos, f32x16_t& acc,
+                             const bf16x8 (&xb)[2][3], const f32x16_t& xa, const float* tab, f32x16_t& xinit,
+                             const float* bias_src) __attribute__((always_inline)) {
+            constexpr int PHASE = decltype(phase_)::value, POS = decltype(pos_)::value, NEXT = decltype(next_)::value;
+            constexpr int I = decltype(i_)::value, ACT = decltype(act_)::value;
+            constexpr bool BIAS = decltype(bias_)::value;
+            static_for<24>([&](auto g_) {
+                constexpr int g = decltype(g_)::value, ks = g / 6, m = g % 6;
+                if constexpr (PHASE == 0)
+                    acc = mfma_plane<m>(fb[ks & 1], ap[G::KS * I + ks], acc);
+                else
+                    yacc[2 * I + (ks >> 1)] = mfma_plane<m>(fb[ks & 1], xb[ks & 1], yacc[2 * I + (ks >> 1)]);
+                if constexpr (m % 2 == 0) {
+                    constexpr int pl = 2 - m / 2;
+                    if constexpr (ks + 1 < 4)
+                        fb[(ks + 1) & 1][pl] = frag1(POS, ks + 1, pl);
+                    else if constexpr (NEXT >= 0)
+                        fb[0][pl] = frag1(NEXT, 0, pl);
+                }
+                if constexpr (g == 0) issue(issue_pos);
+                if constexpr (BIAS && m % 2 == 1 && g < 8) {
+                    typedef float f32x4v __attribute__((ext_vector_type(4)));
+                    const f32x4v v = *reinterpret_cast<const f32x4v*>(bias_src + 8 * (g / 2));
+                    xinit[4 * (g / 2)] = v.x, xinit[4 * (g / 2) + 1] = v.y, xinit[4 * (g / 2) + 2] = v.z, xinit[4 * (g / 2) + 3] = v.w;
+                }
+                if constexpr (ACT >= 0) act_gap(std::integral_constant<int, 24 * I + g>{}, std::integral_constant<int, ACT>{}, xa, tab);
+#ifndef NO_GAP_WALL
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+            });
+            step_sync();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto make_xb = [&](bf16x8 (&xb)[2][3]) __attribute__((always_inline)) {
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
                     xb[s][pl] = __builtin_bit_cast(bf16x8, u32x4{xbp[s][pl][0], xbp[s][pl][1], xbp[s][pl][2], xbp[s][pl][3]});
-#pragma unroll
-            for (int i = 0; i < G::NA; ++i) {
-                issue((OFF + i + G::PF) % G::NSTEP);
-#pragma unroll
-                for (int c2 = 0; c2 < 2; ++c2)
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        bf16x8 cur[3];
-                        if (c2 == 0 && s == 0) {
-#pragma unroll
-                            for (int pl = 0; pl < 3; ++pl) cur[pl] = wf[pl];
-                        } else {
-                            frag(OFF + i, 2 * c2 + s, cur);
-                        }
-                        yacc[2 * i + c2] = mfma_split(cur, xb[s], yacc[2 * i + c2]);
-                    }
-                // the slot after this one landed a step ago: its first fragment is fetched across the barrier
-                if (!(LAST_OF_PASS && i + 1 == G::NA)) frag(i + 1 < G::NA ? OFF + i + 1 : G::NA, 0, wf);
-                step_sync();
-            }
         };
+        using IC_none = std::integral_constant<int, -1>;
+        const float* const tab_lane = Pt + 16 * lh;  // + 128 nt: the lane's rows of hidden tile nt
+        const float* const b1_lane = B1s + 4 * lh;   // + 32 nt
+        bf16x8 xb[2][3] = {};
+        f32x16_t xdummy = {};
 
         WIDE_STAMP(2);
-        // ---- first product of hidden tile 0 (ring slots 0 .. NA-1): nothing to overlap with -------------------------
-        bf16x8 wf[3];
-        frag(0, 0, wf);
+        // ---- first product of hidden tile 0 (ring slots 0 .. NA-1), then the first half of its activation: nothing to overlap
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) fb[0][pl] = frag1(0, 0, pl);
         f32x16_t xacc = bias1(0);
-#pragma unroll
-        for (int i = 0; i < G::NA; ++i) {
-            issue((i + G::PF) % G::NSTEP);
-#pragma unroll
-            for (int ks = 0; ks < G::KS; ++ks) {
-                bf16x8 cur[3];
-                if (ks == 0) {
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) cur[pl] = wf[pl];
-                } else {
-                    frag(i, ks, cur);
-                }
-                xacc = mfma_split(cur, ap[G::KS * i + ks], xacc);
-            }
-            frag(i + 1, 0, wf);  // i + 1 == NA: the first slot of iteration 0
-            step_sync();
-        }
+        f32x16_t xinit = {};
+        static_for<G::NA>([&](auto i_) {
+            constexpr int i = decltype(i_)::value;
+            slot_step(std::integral_constant<int, 0>{}, std::integral_constant<int, i>{}, std::integral_constant<int, i + 1>{}, i_, IC_none{},
+                      std::false_type{}, (i + G::PF) % G::NSTEP, xacc, xb, xdummy, tab_lane, xdummy, b1_lane);
+        });
+        static_for<4 * ACT_STAGES>([&](auto st_) {
+            constexpr int ST = decltype(st_)::value, P = ST / ACT_STAGES, T = ST % ACT_STAGES, R = 2 * P;
+            act_stage<T>(ast[P], tab_lane + 4 * ((R & 3) + 8 * (R >> 2)), xacc[R], xacc[R + 1], xbp[0][0][P], xbp[0][1][P], xbp[0][2][P]);
+        });
 
         WIDE_STAMP(3);
 #pragma unroll 1
         for (int nt = 0; nt + 1 < G::NT; ++nt) {
-            // ---- first product of tile nt+1 (slots NA .. 2NA-1) beside the activation of tile nt ----------------------
+            // ---- A: first product of tile nt+1 (slots NA .. 2NA-1) beside the second half of tile nt's activation -------
             f32x16_t xnext = bias1(nt + 1);
-#pragma unroll
-            for (int i = 0; i < G::NA; ++i) {
-                issue((G::NA + i + G::PF) % G::NSTEP);
-#pragma unroll
-                for (int ks = 0; ks < G::KS; ++ks) {
-                    constexpr int STEPS = G::KS * G::NA;  // k steps of this phase; 8 activation pairs are dealt over them
-                    const int s = G::KS * i + ks;
-                    bf16x8 cur[3];
-                    if (ks == 0) {
-#pragma unroll
-                        for (int pl = 0; pl < 3; ++pl) cur[pl] = wf[pl];
-                    } else {
-                        frag(G::NA + i, ks, cur);
-                    }
-                    xnext = mfma_split(cur, ap[s], xnext);
-#pragma unroll
-                    for (int pr = 0; pr < 8; ++pr)
-                        if (pr * STEPS / 8 == s) act_pair(xacc, nt, 2 * pr);
-                }
-                frag(i + 1 < G::NA ? G::NA + i + 1 : 0, 0, wf);
-                step_sync();
-            }
-            // ---- second product of tile nt (slots 0 .. NA-1) --------------------------------------------------------
-            second_product(std::integral_constant<int, 0>{}, std::false_type{}, wf);
+            const float* const tab_a = tab_lane + 128 * nt;
+            static_for<G::NA>([&](auto i_) {
+                constexpr int i = decltype(i_)::value;
+                slot_step(std::integral_constant<int, 0>{}, std::integral_constant<int, G::NA + i>{},
+                          std::integral_constant<int, (G::NA + i + 1) % G::NSTEP>{}, i_, std::integral_constant<int, 1>{}, std::false_type{},
+                          (G::NA + i + G::PF) % G::NSTEP, xnext, xb, xacc, tab_a, xdummy, b1_lane);
+            });
+            // ---- B: second product of tile nt (slots 0 .. NA-1) beside the first half of tile nt+1's activation ----------
+            make_xb(xb);
+            const float* const tab_b = tab_a + 128;
+            const float* const bias_b = b1_lane + 32 * (nt + 2);  // nt + 2 == NT on the last iteration: reads the b2 table, unused
+            static_for<G::NA>([&](auto i_) {
+                constexpr int i = decltype(i_)::value;
+                slot_step(std::integral_constant<int, 1>{}, std::integral_constant<int, i>{}, std::integral_constant<int, i + 1>{}, i_,
+                          std::integral_constant<int, 0>{}, std::false_type{}, (i + G::PF) % G::NSTEP, xdummy, xb,
+                          xnext, tab_b, xinit, bias_b);
+            });
             xacc = xnext;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xbp[0][pl][j] = xbq[pl][j];
         }
         WIDE_STAMP(4);
-        // ---- last hidden tile: activation alone, second product from slots NA .. 2NA-1 ------------------------------
-#pragma unroll
-        for (int pr = 0; pr < 8; ++pr) act_pair(xacc, G::NT - 1, 2 * pr);
-        second_product(std::integral_constant<int, G::NA>{}, std::true_type{}, wf);
+        // ---- last hidden tile: second half of its activation alone, second product from slots NA .. 2NA-1 ------------------
+        static_for<4 * ACT_STAGES>([&](auto st_) {
+            constexpr int ST = decltype(st_)::value, P = ST / ACT_STAGES, T = ST % ACT_STAGES, R = 2 * (4 + P);
+            act_stage<T>(ast[P], tab_lane + 128 * (G::NT - 1) + 4 * ((R & 3) + 8 * (R >> 2)), xacc[R], xacc[R + 1], xbp[1][0][P], xbp[1][1][P],
+                         xbp[1][2][P]);
+        });
+        make_xb(xb);
+        static_for<G::NA>([&](auto i_) {
+            constexpr int i = decltype(i_)::value;
+            // the stream wraps: the slot after the pass's last one is ring position 0, the first slot of the next pass
+            slot_step(std::integral_constant<int, 1>{}, std::integral_constant<int, G::NA + i>{},
+                      std::integral_constant<int, (G::NA + i + 1) % G::NSTEP>{}, i_, IC_none{}, std::false_type{},
+                      (G::NA + i + G::PF) % G::NSTEP, xdummy, xb, xdummy, tab_lane, xdummy, b1_lane);
+        });
 
         WIDE_STAMP(5);
         // ---- residual + store (xtract/nn/layers.py:59-62).  The accumulators hold, per lane, 4 channels of ONE frame for each of

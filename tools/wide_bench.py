@@ -3,6 +3,7 @@
 
     L3AC_LIB_PATH=.../libA.so python tools/wide_bench.py; L3AC_LIB_PATH=.../libB.so python tools/wide_bench.py
 """
+import hashlib
 import sys
 
 import torch
@@ -16,6 +17,7 @@ codec.network.to(device="cuda").eval()
 ctx = codec.network.context()
 lib = ctx.lib
 s = torch.cuda.current_stream().cuda_stream
+torch.manual_seed(0)
 for c, block, batch, frames in ((256, "decoder.blocks.4.1.module", 256, 900), (192, "encoder.blocks.7.0.module", 256, 180)):
     x = torch.randn(batch, frames, c, device="cuda")
     y = torch.empty_like(x)
@@ -33,4 +35,5 @@ for c, block, batch, frames in ((256, "decoder.blocks.4.1.module", 256, 900), (1
         torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) / 4)
     ms = sorted(ts)[len(ts) // 2]
-    print(f"C={c} rows={batch * frames}: {ms:.4f} ms per unit (front end + main), {batch * frames * 16.0 * c * c / ms / 1e9:.1f} TFLOP/s fp32-equivalent")
+    digest = hashlib.sha256(y.cpu().numpy().tobytes()).hexdigest()[:16]  # same box + same seed: equal digests = bit-identical results
+    print(f"C={c} rows={batch * frames}: {ms:.4f} ms per unit (front end + main), {batch * frames * 16.0 * c * c / ms / 1e9:.1f} TFLOP/s fp32-equivalent, output sha256 {digest}")
