@@ -54,6 +54,7 @@ struct WGeo {
     static constexpr int PF = NSTEP - 1;    // slots in flight
     static constexpr int RING = NSTEP * SLOT;
     static constexpr int TOTAL = NT * NSTEP;  // slots of the whole stream
+    static constexpr int AP_AGPR_FROM = C >= 256 ? NS1 - 6 : NS1;  // k steps of the LayerNorm operand kept in AGPRs
     static constexpr int WAIT = 3 * (PF - 2); // this wave's DMA instructions that may stay outstanding at a step's end
     // LDS (bytes): alpha, 1/alpha, gamma, beta [4][H4] | b1 [H4] | b2 [C] | ring | epilogue transposition buffers.  The tables
     // come first so that their reads (one per activation pair, the tile index in the address) reach with the 16-bit
@@ -218,6 +219,17 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
     const int lj = lane & 31;  // frame within the tile (MFMA column)
     const int lh = lane >> 5;
 
+    // LDS addressing of the fragment reads: two per-lane byte offsets kept opaque to the optimiser (ring positions 0-3, 4-7), the
+    // rest an immediate of the ds_read (16-bit field).  Left alone, hipcc keeps every base + constant combination beyond 64 KB in
+    // a register of its own: 23 registers at C = 256, paid for with AGPR copies of the operands inside the loop.
+    auto opaque = [](int v) __attribute__((always_inline)) -> int {
+        asm volatile("" : "+v"(v));
+        return v;
+    };
+    const int ring_lo = opaque(G::OFF_RING + 16 * lane);
+    const int ring_hi = opaque(G::OFF_RING + 16 * lane + 4 * G::SLOT);
+    static_assert(G::NSTEP <= 8 && 4 * G::SLOT + 3 * 3072 + 2 * 1024 < 65536, "fragment offsets must fit the ds_read immediate");
+
     // ---- the weight stream: this wave copies bytes [3072 wave, 3072 wave + 3072) of every slot ------------------
     const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)ring;
     const unsigned char* const src_wave = w.wide_img + 3072 * wave;  // wave-uniform
@@ -252,6 +264,22 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
 
     const int64_t n_tiles = (rows + 31) / 32;
     const int64_t tile_stride = (int64_t)gridDim.x * 4;
+#ifndef L3AC_WIDE_NO_STAGGER
+    // Passes run in lock step across the chip, so every workgroup would fetch its operand planes and store its tile at the
+    // same moment: HBM idles through the loops and saturates in between (the store phase measured 24 k cycles = 10.7 B / clk /
+    // CU).  Workgroups that run one pass fewer than the busiest ones (at 256 x 900 frames: all but 8) have a whole pass of
+    // slack, so they start up to 0.9 pass late, in 8 steps by blockIdx / 8 (i.e. evenly inside every XCD): their memory
+    // phases then fall into other workgroups' compute phases.  Results do not depend on it.
+    {
+        const int64_t wg_passes = (n_tiles + 3) / 4;
+        const int64_t max_passes = (wg_passes + gridDim.x - 1) / gridDim.x;
+        const int64_t my_passes = (wg_passes - blockIdx.x + gridDim.x - 1) / gridDim.x;
+        constexpr long long PASS_CYCLES = (long long)G::NT * G::NSTEP * 24 * 32 * 6 / 5 + 35000;
+        const long long delay = my_passes < max_passes ? (long long)((blockIdx.x >> 3) & 7) * (PASS_CYCLES * 9 / 80) : 0;
+        const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+        while ((long long)__builtin_amdgcn_s_memtime() - t0 < delay) __builtin_amdgcn_s_sleep(16);
+    }
+#endif
     // every wave of the block runs the same number of passes (block barriers inside)
     int pass_no = 0;
     (void)pass_no;
@@ -271,6 +299,14 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) ap[s][pl] = *reinterpret_cast<const bf16x8*>(src + (s * 3 + pl) * 1024);
         }
+
+        // At C = 256 the 192 operand registers, the 160 accumulators and the activation's working set exceed the 256 arch VGPRs:
+        // left alone hipcc parks part of ap in AGPRs and copies it back (4 v_accvgpr_read per MFMA) inside the loop.  An MFMA
+        // reads its B operand from an AGPR just as well: the last k steps are moved there for good, once per pass.
+#pragma unroll
+        for (int s = G::AP_AGPR_FROM; s < G::NS1; ++s)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) asm volatile("" : "+a"(ap[s][pl]));
 
         WIDE_STAMP(1);
         // ---- output accumulators start at the pw_conv2 bias ------------------------------------------------------
@@ -306,7 +342,7 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
         // 2 NA x 24 gaps of an iteration.
         bf16x8 fb[2][3];
         auto frag1 = [&](int ring_pos, int piece, int pl) __attribute__((always_inline)) -> bf16x8 {
-            return *reinterpret_cast<const bf16x8*>(ring + ring_pos * G::SLOT + piece * 3072 + 16 * lane + 1024 * pl);
+            return *reinterpret_cast<const bf16x8*>(smem_wide + (ring_pos < 4 ? ring_lo : ring_hi) + (ring_pos & 3) * G::SLOT + piece * 3072 + 1024 * pl);
         };
         ActPair ast[4];
         // stages of the half-tile stream (4 pairs x ACT_STAGES) that fall to gap `gap` of the half phase's 24 NA gaps
@@ -420,6 +456,19 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
                 for (int j = 0; j < 4; ++j) xbp[0][pl][j] = xbq[pl][j];
         }
         WIDE_STAMP(4);
+        // ---- the residual rows of this wave's tile, all 4 C bytes per frame at once: the operand planes are dead from here on, so
+        //      their registers hold the 8 x C/32 row pieces while the last second product runs (fetched tile by tile inside the
+        //      store loop they cost 8 serial memory latencies: 21 k of a pass's 263 k cycles)
+        const int er = lane >> 3, es = lane & 7;  // row within a group of 8, 16-B slot
+        float4 xres[G::CT][4];
+#pragma unroll
+        for (int ct = 0; ct < G::CT; ++ct)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t rr = row0 + 8 * i + er;
+                const bool ok = tile_ok && rr < rows;
+                xres[ct][i] = *reinterpret_cast<const float4*>(x + (ok ? rr : 0) * C + 32 * ct + 4 * es);
+            }
         // ---- last hidden tile: second half of its activation alone, second product from slots NA .. 2NA-1 ------------------
         static_for<4 * ACT_STAGES>([&](auto st_) {
             constexpr int ST = decltype(st_)::value, P = ST / ACT_STAGES, T = ST % ACT_STAGES, R = 2 * (4 + P);
@@ -442,17 +491,9 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
         // back row-major — so that the residual load and the store move whole 128-B lines, 8 rows per instruction.
         {
             unsigned char* tbuf = smem_wide + G::OFF_TB + 8192 * wave;
-            const int er = lane >> 3, es = lane & 7;  // row within a group of 8, 16-B slot
             const int swl = (lj ^ (lj >> 3)) & 7;
 #pragma unroll
             for (int ct = 0; ct < G::CT; ++ct) {
-                float4 xres[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int64_t rr = row0 + 8 * i + er;
-                    xres[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (tile_ok && rr < rows) xres[i] = *reinterpret_cast<const float4*>(x + rr * C + 32 * ct + 4 * es);
-                }
                 unsigned char* tb = tbuf + (ct & 1) * 4096;  // two tiles in flight
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
@@ -468,7 +509,7 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
                     const float4 v = *reinterpret_cast<const float4*>(tb + 128 * r + 16 * (es ^ ((r ^ (r >> 3)) & 7)));
                     if (tile_ok && rr < rows)
                         *reinterpret_cast<float4*>(y + rr * C + 32 * ct + 4 * es) =
-                            make_float4(xres[i].x + v.x, xres[i].y + v.y, xres[i].z + v.z, xres[i].w + v.w);
+                            make_float4(xres[ct][i].x + v.x, xres[ct][i].y + v.y, xres[ct][i].z + v.z, xres[ct][i].w + v.w);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
