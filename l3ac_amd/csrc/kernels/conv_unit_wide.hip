@@ -201,7 +201,16 @@ __device__ __forceinline__ void act_stage(ActPair& a, const float* tab, float h0
 template <int M>
 __device__ __forceinline__ f32x16_t mfma_plane(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16_t acc) {
     constexpr int IA[6] = {2, 1, 0, 1, 0, 0}, IB[6] = {0, 1, 2, 0, 1, 0};
+#ifdef L3AC_WIDE_X16  // timing experiment only (wrong results): the same operands through two 16x16x32 MFMAs (16 cycles each)
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    f32x4v c0 = {acc[0], acc[1], acc[2], acc[3]}, c1 = {acc[4], acc[5], acc[6], acc[7]};
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[IA[M]], b[IB[M]], c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[IA[M]], b[IB[M]], c1, 0, 0, 0);
+    acc[0] = c0.x, acc[1] = c0.y, acc[2] = c0.z, acc[3] = c0.w, acc[4] = c1.x, acc[5] = c1.y, acc[6] = c1.z, acc[7] = c1.w;
+    return acc;
+#else
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[IA[M]], b[IB[M]], acc, 0, 0, 0);
+#endif
 }
 
 template <int C>
@@ -236,14 +245,18 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
     const unsigned lane_off = 16u * (unsigned)lane;
     int dma_slot = 0;  // next slot of the stream to fetch (wave-uniform)
     auto issue = [&](int ring_pos) __attribute__((always_inline)) {
+#ifndef L3AC_WIDE_NODMA  // (timing experiments only)
         dma_slot_quarter(src_wave + (int64_t)dma_slot * G::SLOT, lane_off, ring_lds + (unsigned)(ring_pos * G::SLOT) + 3072u * (unsigned)wave);
+#endif
         dma_slot = dma_slot + 1 == G::TOTAL ? 0 : dma_slot + 1;
     };
     // end of a step: this wave's pieces of the slot after next have landed, then everybody's have, and everybody is done
     // reading the slot that the next step's DMA overwrites
     auto step_sync = [&]() __attribute__((always_inline)) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::WAIT) : "memory");
+#ifndef L3AC_WIDE_NOBAR  // (timing experiments only: results are wrong without the barrier)
         __builtin_amdgcn_s_barrier();
+#endif
         asm volatile("" ::: "memory");
     };
 #pragma unroll

@@ -234,11 +234,7 @@ __global__ __launch_bounds__(256) void vq_scan_kernel(const float* __restrict__ 
     // (measured and dropped: comparing only the minimum of a block of 4 codes with the running minimum and redoing the ordered
     // update on a wave-uniform branch — 6.1 ms instead of 3.3 ms at K = 250 047, N = 42 752: with 128 queries per wave some lane
     // improves in most blocks, and the branch splits the loop body)
-#pragma unroll 4
-    for (int c = c_begin; c < c_end; ++c, cb += D) {
-        float cc[D];
-#pragma unroll
-        for (int d = 0; d < D; ++d) cc[d] = cb[d];
+    auto visit = [&](const float (&cc)[D], int c) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < QPL; ++j) {
             float t = q[j][0] - cc[0];
@@ -252,6 +248,62 @@ __global__ __launch_bounds__(256) void vq_scan_kernel(const float* __restrict__ 
             best[j] = lt ? dist : best[j];
             best_i[j] = lt ? c : best_i[j];
         }
+    };
+    // Blocks of CB codes, two register sets in ping-pong: the scalar loads of the next block are issued BEFORE the current one
+    // is evaluated (sched_barrier keeps them there), so the s_waitcnt in front of a block's first vector instruction finds its
+    // coordinates already there.  One code per iteration left the wave waiting for its s_load in every iteration: 49 instead
+    // of the instruction stream's 31 cycles per (query, code) pair.
+    constexpr int CB = 4;
+    float blk_a[CB][D], blk_b[CB][D];
+    auto load_block = [&](float (&dst)[CB][D], const float* __restrict__ src) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < CB; ++i)
+#pragma unroll
+            for (int d = 0; d < D; ++d) dst[i][d] = src[i * D + d];
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto visit_block = [&](const float (&src)[CB][D], int c0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < CB; ++i) visit(src[i], c0 + i);
+        // (the running minima end every dependency chain of the block: naming them pins the block's arithmetic in front of the
+        // wait + loads that follow — sched_barrier alone orders only what instruction selection has already put there)
+#pragma unroll
+        for (int j = 0; j < QPL; ++j) asm volatile("" : "+v"(best[j]), "+v"(best_i[j])::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // scalar loads return out of order, so the only wait there is is lgkmcnt(0): it is placed BEFORE the next block's loads are
+    // issued (the block it waits for was requested a whole block evaluation earlier), never between them and their use
+    auto landed = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0), vmcnt / expcnt untouched
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    const int n_blocks = (c_end - c_begin) / CB;
+    const float* const cb_last = cb + (int64_t)(n_blocks > 0 ? n_blocks - 1 : 0) * (CB * D);  // prefetches never run past the slice
+    int c = c_begin;
+    if (n_blocks > 0) load_block(blk_a, cb);
+#pragma unroll 1
+    for (int b = 0; b + 1 < n_blocks; b += 2) {
+        const float* nb = cb + CB * D;
+        landed();
+        load_block(blk_b, nb);
+        visit_block(blk_a, c);
+        nb = nb + CB * D <= cb_last ? nb + CB * D : cb_last;
+        landed();
+        load_block(blk_a, nb);
+        visit_block(blk_b, c + CB);
+        cb += 2 * CB * D;
+        c += 2 * CB;
+    }
+    if (n_blocks & 1) {  // blk_a holds the last block
+        visit_block(blk_a, c);
+        cb += CB * D;
+        c += CB;
+    }
+    for (; c < c_end; ++c, cb += D) {
+        float cc[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) cc[d] = cb[d];
+        visit(cc, c);
     }
 #pragma unroll
     for (int j = 0; j < QPL; ++j) {
@@ -338,7 +390,7 @@ __global__ __launch_bounds__(THREADS) void vq_argmin_combine_kernel(const float*
     out_idx[qi] = best_i;
 }
 
-constexpr int VQ_QPL = 2;       // queries per lane of the scan form
+constexpr int VQ_QPL = 4;       // queries per lane of the scan form
 constexpr int VQ_QW = 4;        // queries per wave of the wavefront form
 constexpr int64_t VQ_WAVE_MAX_N = 16384;  // below this many queries the wavefront form fills the chip better
 
