@@ -73,7 +73,7 @@ __global__ void split_image_kernel(const float* __restrict__ w, int64_t ldw, int
 // KTAIL: k % 32 != 0 (k % 8 == 0): the last tile's out-of-range 8-value groups re-read the row's last valid group —
 // finite numbers that meet the image's zero padding
 template <bool KTAIL>
-__global__ __launch_bounds__(THREADS, 3) void gemm_split_kernel(const GemmArgs p, const int gp) {
+__device__ __forceinline__ void gemm_split_body32(const GemmArgs& p, const int gp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_split[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -181,6 +181,202 @@ __global__ __launch_bounds__(THREADS, 3) void gemm_split_kernel(const GemmArgs p
     gemm_epilogue<4>(p, acc, m0, n0, wave, li, lh);
 }
 
+// ---- the same GEMM on v_mfma_f32_16x16x32_bf16 ------------------------------------------------------------------------
+// Same tile (128 x 128 x 32, wave w = rows [32w, 32w+32) across all 128 columns), same weight image, same six plane products
+// per MAC, but every 32x32x16 product becomes 16x16x32 ones (16 cycles each, the same matrix-core cycles per FLOP).  Why: on
+// this power-limited chip the clock a dense MFMA loop holds depends on the instruction's shape — MI355X_MICROARCH.md (DVFS, item
+// 7) measures the 16x16x32 loop at 1.12-1.15 x the FLOP/s of the 32x32x16 loop at equal cycles; a timing-only substitution in
+// this kernel gave 4.24 -> 3.75 ms per step over its 29 launches.
+//   A (activations): lane (m = lane & 15, kg = lane >> 4) owns k = 8 kg .. 8 kg + 7 of rows m and 16 + m of the wave's strip:
+//                    2 x 32 B per row and k tile, four lanes per 128-B line.
+//   B (weights):     lane (n = lane & 15, kg) reads chunk kg of row 16 t + n of the k tile's planes: the image and its XOR
+//                    swizzle are the 32x32 kernel's (any 64 lanes of this pattern touch 64 distinct 16-B slots of one KB).
+//   D:               acc[h][t][i] = c[row 16 h + 4 (lane >> 4) + i][column 16 t + (lane & 15)].
+typedef float f32x4a __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void gemm_epilogue16(const GemmArgs& p, f32x4a (&acc)[2][8], int64_t m0, int n0, int wave, int ln, int lg) {
+    const int64_t mw = m0 + 32 * wave + 4 * lg;  // + 16 h + i
+    if (p.epi == EPI_GEGLU) {
+        // 32-column tiles come in (value, gate) pairs: 16-column tiles t, t + 2 for t = 0, 1, 4, 5; output column
+        // j = n0 / 2 + 16 (t / 2) + 16 (t & 1) + ln with t / 2 even
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            if ((t >> 1) & 1) continue;
+            const int j = (n0 >> 1) + 16 * (t >> 1) + 16 * (t & 1) + ln;
+            if (j >= (int)p.ldc) continue;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int64_t m = mw + 16 * h + i;
+                    if (m < p.m) p.c[m * p.ldc + j] = acc[h][t][i] * gelu_erf(acc[h][t + 2][i]);
+                }
+        }
+        return;
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int n = n0 + 16 * t + ln;
+        if (n >= p.n) continue;
+        const float bias = p.bias ? p.bias[n] : 0.f;
+        float alpha = 0.f, inv_alpha = 0.f, gamma = 0.f, beta = 0.f;
+        if (p.epi == EPI_SNAKE || p.epi == EPI_SNAKE_GRN) {
+            alpha = p.alpha[n];
+            inv_alpha = p.inv_alpha[n];
+        }
+        if (p.epi == EPI_SNAKE_GRN) {
+            gamma = p.gamma[n];
+            beta = p.beta[n];
+        }
+        if (p.epi == EPI_SNAKE || p.epi == EPI_SNAKE_GRN) {  // packed fp32 math on register pairs (two rows, same column)
+            const f32x2 al = (f32x2)(alpha), ia = (f32x2)(inv_alpha), ga = (f32x2)(gamma), be = (f32x2)(beta), bi = (f32x2)(bias);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < 4; i += 2) {
+                    f32x2 hv;
+                    hv.x = acc[h][t][i];
+                    hv.y = acc[h][t][i + 1];
+                    const f32x2 sv = snake_act2(hv + bi, al, ia);
+                    const f32x2 o = p.epi == EPI_SNAKE_GRN ? __builtin_elementwise_fma(ga, sv, be) + sv : sv;  // layers.py:115, n_x == 1
+                    const int64_t m = mw + 16 * h + i;
+                    if (m < p.m) p.c[m * p.ldc + n] = o.x;
+                    if (m + 1 < p.m) p.c[(m + 1) * p.ldc + n] = o.y;
+                }
+            continue;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t m = mw + 16 * h + i;
+                if (m >= p.m) continue;
+                float v = acc[h][t][i] + bias;
+                if (p.epi == EPI_BIAS_RES) v = p.res[m * p.ldres + n] + v;
+                p.c[m * p.ldc + n] = v;
+            }
+    }
+}
+
+template <bool KTAIL>
+__device__ __forceinline__ void gemm_split_body16(const GemmArgs& p, const int gp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_split[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ln = lane & 15, lg = lane >> 4;
+    // XCD-aware tile order (gemm_f32.hip): all column tiles of one A row panel run on one XCD
+    const int n_blocks = (p.n + BN - 1) / BN;
+    const int64_t m_panels = (p.m + BM - 1) / BM;
+    const int GP = gp;
+    const int64_t group = blockIdx.x / (GP * n_blocks);
+    const int64_t in_group = blockIdx.x % (GP * n_blocks);
+    const int64_t panels_here = (group * GP + GP <= m_panels) ? GP : m_panels - group * GP;
+    const int64_t m0 = (group * GP + in_group % panels_here) * BM;
+    const int n0 = (int)(in_group / panels_here) * BN;
+    const int n_tiles = (p.k + BK - 1) / BK;
+    const int last = n_tiles - 1;
+
+    // rows past the edge are clamped to row 0: they only feed accumulators that are never stored
+    const int64_t row_lo = m0 + 32 * wave + ln, row_hi = row_lo + 16;
+    const float* a_lo = p.a + (row_lo < p.m ? row_lo : 0) * p.lda + 8 * lg;
+    const float* a_hi = p.a + (row_hi < p.m ? row_hi : 0) * p.lda + 8 * lg;
+    const unsigned char* w_src = p.w_img + (int64_t)(n0 / BN) * n_tiles * W_TILE + 16 * tid;
+
+    float4 a_pre[2][4];  // [k tile parity][row half x 2 float4]
+    u32x4 w_reg[W_LOADS];
+    auto load_a = [&](int kt, float4 (&dst)[4]) __attribute__((always_inline)) {
+        int o = kt * BK;
+        if (KTAIL) {  // the last tile's groups beyond k re-read the row's last valid group: finite values on the image's zero padding
+            const int kmax = p.k - 8 - 8 * lg;
+            o = o < kmax ? o : kmax;
+        }
+        dst[0] = *reinterpret_cast<const float4*>(a_lo + o);
+        dst[1] = *reinterpret_cast<const float4*>(a_lo + o + 4);
+        dst[2] = *reinterpret_cast<const float4*>(a_hi + o);
+        dst[3] = *reinterpret_cast<const float4*>(a_hi + o + 4);
+    };
+    auto load_w = [&](int kt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < W_LOADS; ++i) w_reg[i] = *reinterpret_cast<const u32x4*>(w_src + (int64_t)kt * W_TILE + 16 * THREADS * i);
+    };
+    auto store_w = [&](int buf) __attribute__((always_inline)) {
+        unsigned char* base = smem_split + buf * W_TILE + 16 * tid;
+#pragma unroll
+        for (int i = 0; i < W_LOADS; ++i) *reinterpret_cast<u32x4*>(base + 16 * THREADS * i) = w_reg[i];
+    };
+    auto read_b = [&](const unsigned char* ws, int t, bf16x8 (&b)[3]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) b[pl] = *reinterpret_cast<const bf16x8*>(ws + pl * W_PLANE + tile_off(16 * t + ln, lg));
+    };
+
+    f32x4a acc[2][8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc[h][t] = f32x4a{0.f, 0.f, 0.f, 0.f};
+
+    load_a(0, a_pre[0]);
+    load_a(last < 1 ? last : 1, a_pre[1]);
+    load_w(0);
+    store_w(0);
+    __syncthreads();
+    // straight-line body: tile indices are clamped instead of branched on, which keeps hipcc's s_waitcnt counts exact
+    auto step = [&](int kt, float4 (&cur)[4]) __attribute__((always_inline)) {
+        const int buf = kt & 1;
+        load_w(kt + 1 < last ? kt + 1 : last);
+        u32x4 af[2][3];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            unsigned x0, x1, x2, y0, y1, y2, z0, z1, z2, u0, u1, u2;
+            split2(cur[2 * h].x, cur[2 * h].y, x0, x1, x2);
+            split2(cur[2 * h].z, cur[2 * h].w, y0, y1, y2);
+            split2(cur[2 * h + 1].x, cur[2 * h + 1].y, z0, z1, z2);
+            split2(cur[2 * h + 1].z, cur[2 * h + 1].w, u0, u1, u2);
+            af[h][0] = u32x4{x0, y0, z0, u0};
+            af[h][1] = u32x4{x1, y1, z1, u1};
+            af[h][2] = u32x4{x2, y2, z2, u2};
+        }
+        load_a(kt + 2 < last ? kt + 2 : last, cur);  // the registers are free again: two tiles ahead
+        const unsigned char* ws = smem_split + buf * W_TILE;
+        bf16x8 bq[2][3];
+        read_b(ws, 0, bq[0]);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            if (t + 1 < 8) read_b(ws, t + 1, bq[(t + 1) & 1]);
+            const bf16x8 b0 = bq[t & 1][0], b1 = bq[t & 1][1], b2 = bq[t & 1][2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const bf16x8 a0 = __builtin_bit_cast(bf16x8, af[h][0]);
+                const bf16x8 a1 = __builtin_bit_cast(bf16x8, af[h][1]);
+                const bf16x8 a2 = __builtin_bit_cast(bf16x8, af[h][2]);
+                acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b0, acc[h][t], 0, 0, 0);
+                acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc[h][t], 0, 0, 0);
+                acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b2, acc[h][t], 0, 0, 0);
+                acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0, acc[h][t], 0, 0, 0);
+                acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, acc[h][t], 0, 0, 0);
+                acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc[h][t], 0, 0, 0);
+            }
+            if (t == 3) store_w(buf ^ 1);
+        }
+        __syncthreads();
+    };
+    for (int kt = 0; kt < n_tiles; kt += 2) {
+        step(kt, a_pre[0]);
+        if (kt + 1 < n_tiles) step(kt + 1, a_pre[1]);
+    }
+    gemm_epilogue16(p, acc, m0, n0, wave, ln, lg);
+}
+
+// SHAPE: the MFMA instruction, 16 = v_mfma_f32_16x16x32_bf16 (default), 32 = v_mfma_f32_32x32x16_bf16 (L3AC_SPLIT_MFMA=32)
+template <bool KTAIL, int SHAPE>
+__global__ __launch_bounds__(THREADS, 3) void gemm_split_kernel(const GemmArgs p, const int gp) {
+    if constexpr (SHAPE == 16)
+        gemm_split_body16<KTAIL>(p, gp);
+    else
+        gemm_split_body32<KTAIL>(p, gp);
+}
+
 std::atomic<int> g_split_enabled{-1};
 
 }  // namespace
@@ -251,10 +447,21 @@ int launch_gemm_split(hipStream_t s, const GemmArgs& g) {
         return e ? std::atoi(e) : 0;
     }();
     const int gp = gp_env > 0 ? gp_env : 8;
-    if (g.k % BK == 0)
-        hipLaunchKernelGGL((gemm_split_kernel<false>), dim3((unsigned)blocks), dim3(THREADS), 2 * W_TILE, s, g, gp);
-    else
-        hipLaunchKernelGGL((gemm_split_kernel<true>), dim3((unsigned)blocks), dim3(THREADS), 2 * W_TILE, s, g, gp);
+    static const bool shape32 = [] {  // L3AC_SPLIT_MFMA=32: the 32x32x16 form of the kernel (A/B runs)
+        const char* e = std::getenv("L3AC_SPLIT_MFMA");
+        return e && std::atoi(e) == 32;
+    }();
+    if (shape32) {
+        if (g.k % BK == 0)
+            hipLaunchKernelGGL((gemm_split_kernel<false, 32>), dim3((unsigned)blocks), dim3(THREADS), 2 * W_TILE, s, g, gp);
+        else
+            hipLaunchKernelGGL((gemm_split_kernel<true, 32>), dim3((unsigned)blocks), dim3(THREADS), 2 * W_TILE, s, g, gp);
+    } else {
+        if (g.k % BK == 0)
+            hipLaunchKernelGGL((gemm_split_kernel<false, 16>), dim3((unsigned)blocks), dim3(THREADS), 2 * W_TILE, s, g, gp);
+        else
+            hipLaunchKernelGGL((gemm_split_kernel<true, 16>), dim3((unsigned)blocks), dim3(THREADS), 2 * W_TILE, s, g, gp);
+    }
     L3AC_LAUNCH_CHECK();
     return L3AC_OK;
 }
