@@ -194,8 +194,9 @@ __device__ __forceinline__ void gemm_split_body32(const GemmArgs& p, const int g
 //   D:               acc[h][t][i] = c[row 16 h + 4 (lane >> 4) + i][column 16 t + (lane & 15)].
 typedef float f32x4a __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void gemm_epilogue16(const GemmArgs& p, f32x4a (&acc)[2][8], int64_t m0, int n0, int wave, int ln, int lg) {
-    const int64_t mw = m0 + 32 * wave + 4 * lg;  // + 16 h + i
+template <int RG>
+__device__ __forceinline__ void gemm_epilogue16(const GemmArgs& p, f32x4a (&acc)[RG][8], int64_t m0, int n0, int wave, int ln, int lg) {
+    const int64_t mw = m0 + 16 * RG * wave + 4 * lg;  // + 16 h + i
     if (p.epi == EPI_GEGLU) {
         // 32-column tiles come in (value, gate) pairs: 16-column tiles t, t + 2 for t = 0, 1, 4, 5; output column
         // j = n0 / 2 + 16 (t / 2) + 16 (t & 1) + ln with t / 2 even
@@ -205,7 +206,7 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmArgs& p, f32x4a (&acc)
             const int j = (n0 >> 1) + 16 * (t >> 1) + 16 * (t & 1) + ln;
             if (j >= (int)p.ldc) continue;
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < RG; ++h)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int64_t m = mw + 16 * h + i;
@@ -231,7 +232,7 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmArgs& p, f32x4a (&acc)
         if (p.epi == EPI_SNAKE || p.epi == EPI_SNAKE_GRN) {  // packed fp32 math on register pairs (two rows, same column)
             const f32x2 al = (f32x2)(alpha), ia = (f32x2)(inv_alpha), ga = (f32x2)(gamma), be = (f32x2)(beta), bi = (f32x2)(bias);
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < RG; ++h)
 #pragma unroll
                 for (int i = 0; i < 4; i += 2) {
                     f32x2 hv;
@@ -246,7 +247,7 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmArgs& p, f32x4a (&acc)
             continue;
         }
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < RG; ++h)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int64_t m = mw + 16 * h + i;
@@ -258,8 +259,10 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmArgs& p, f32x4a (&acc)
     }
 }
 
-template <bool KTAIL>
+template <bool KTAIL, int RG>
 __device__ __forceinline__ void gemm_split_body16(const GemmArgs& p, const int gp) {
+    constexpr int WM = 16 * RG;   // rows per wave
+    constexpr int BMW = 4 * WM;   // rows per block
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_split[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -267,34 +270,38 @@ __device__ __forceinline__ void gemm_split_body16(const GemmArgs& p, const int g
     const int ln = lane & 15, lg = lane >> 4;
     // XCD-aware tile order (gemm_f32.hip): all column tiles of one A row panel run on one XCD
     const int n_blocks = (p.n + BN - 1) / BN;
-    const int64_t m_panels = (p.m + BM - 1) / BM;
+    const int64_t m_panels = (p.m + BMW - 1) / BMW;
     const int GP = gp;
     const int64_t group = blockIdx.x / (GP * n_blocks);
     const int64_t in_group = blockIdx.x % (GP * n_blocks);
     const int64_t panels_here = (group * GP + GP <= m_panels) ? GP : m_panels - group * GP;
-    const int64_t m0 = (group * GP + in_group % panels_here) * BM;
+    const int64_t m0 = (group * GP + in_group % panels_here) * BMW;
     const int n0 = (int)(in_group / panels_here) * BN;
     const int n_tiles = (p.k + BK - 1) / BK;
     const int last = n_tiles - 1;
 
     // rows past the edge are clamped to row 0: they only feed accumulators that are never stored
-    const int64_t row_lo = m0 + 32 * wave + ln, row_hi = row_lo + 16;
-    const float* a_lo = p.a + (row_lo < p.m ? row_lo : 0) * p.lda + 8 * lg;
-    const float* a_hi = p.a + (row_hi < p.m ? row_hi : 0) * p.lda + 8 * lg;
+    const float* a_row[RG];
+#pragma unroll
+    for (int h = 0; h < RG; ++h) {
+        const int64_t row = m0 + WM * wave + 16 * h + ln;
+        a_row[h] = p.a + (row < p.m ? row : 0) * p.lda + 8 * lg;
+    }
     const unsigned char* w_src = p.w_img + (int64_t)(n0 / BN) * n_tiles * W_TILE + 16 * tid;
 
-    float4 a_pre[2][4];  // [k tile parity][row half x 2 float4]
+    float4 a_pre[2][2 * RG];  // [k tile parity][row group x 2 float4]
     u32x4 w_reg[W_LOADS];
-    auto load_a = [&](int kt, float4 (&dst)[4]) __attribute__((always_inline)) {
+    auto load_a = [&](int kt, float4 (&dst)[2 * RG]) __attribute__((always_inline)) {
         int o = kt * BK;
         if (KTAIL) {  // the last tile's groups beyond k re-read the row's last valid group: finite values on the image's zero padding
             const int kmax = p.k - 8 - 8 * lg;
             o = o < kmax ? o : kmax;
         }
-        dst[0] = *reinterpret_cast<const float4*>(a_lo + o);
-        dst[1] = *reinterpret_cast<const float4*>(a_lo + o + 4);
-        dst[2] = *reinterpret_cast<const float4*>(a_hi + o);
-        dst[3] = *reinterpret_cast<const float4*>(a_hi + o + 4);
+#pragma unroll
+        for (int h = 0; h < RG; ++h) {
+            dst[2 * h] = *reinterpret_cast<const float4*>(a_row[h] + o);
+            dst[2 * h + 1] = *reinterpret_cast<const float4*>(a_row[h] + o + 4);
+        }
     };
     auto load_w = [&](int kt) __attribute__((always_inline)) {
 #pragma unroll
@@ -310,9 +317,9 @@ __device__ __forceinline__ void gemm_split_body16(const GemmArgs& p, const int g
         for (int pl = 0; pl < 3; ++pl) b[pl] = *reinterpret_cast<const bf16x8*>(ws + pl * W_PLANE + tile_off(16 * t + ln, lg));
     };
 
-    f32x4a acc[2][8];
+    f32x4a acc[RG][8];
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < RG; ++h)
 #pragma unroll
         for (int t = 0; t < 8; ++t) acc[h][t] = f32x4a{0.f, 0.f, 0.f, 0.f};
 
@@ -322,12 +329,12 @@ __device__ __forceinline__ void gemm_split_body16(const GemmArgs& p, const int g
     store_w(0);
     __syncthreads();
     // straight-line body: tile indices are clamped instead of branched on, which keeps hipcc's s_waitcnt counts exact
-    auto step = [&](int kt, float4 (&cur)[4]) __attribute__((always_inline)) {
+    auto step = [&](int kt, float4 (&cur)[2 * RG]) __attribute__((always_inline)) {
         const int buf = kt & 1;
         load_w(kt + 1 < last ? kt + 1 : last);
-        u32x4 af[2][3];
+        u32x4 af[RG][3];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < RG; ++h) {
             unsigned x0, x1, x2, y0, y1, y2, z0, z1, z2, u0, u1, u2;
             split2(cur[2 * h].x, cur[2 * h].y, x0, x1, x2);
             split2(cur[2 * h].z, cur[2 * h].w, y0, y1, y2);
@@ -346,7 +353,7 @@ __device__ __forceinline__ void gemm_split_body16(const GemmArgs& p, const int g
             if (t + 1 < 8) read_b(ws, t + 1, bq[(t + 1) & 1]);
             const bf16x8 b0 = bq[t & 1][0], b1 = bq[t & 1][1], b2 = bq[t & 1][2];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < RG; ++h) {
                 const bf16x8 a0 = __builtin_bit_cast(bf16x8, af[h][0]);
                 const bf16x8 a1 = __builtin_bit_cast(bf16x8, af[h][1]);
                 const bf16x8 a2 = __builtin_bit_cast(bf16x8, af[h][2]);
@@ -365,14 +372,17 @@ __device__ __forceinline__ void gemm_split_body16(const GemmArgs& p, const int g
         step(kt, a_pre[0]);
         if (kt + 1 < n_tiles) step(kt + 1, a_pre[1]);
     }
-    gemm_epilogue16(p, acc, m0, n0, wave, ln, lg);
+    gemm_epilogue16<RG>(p, acc, m0, n0, wave, ln, lg);
 }
 
-// SHAPE: the MFMA instruction, 16 = v_mfma_f32_16x16x32_bf16 (default), 32 = v_mfma_f32_32x32x16_bf16 (L3AC_SPLIT_MFMA=32)
+// SHAPE: 16 = v_mfma_f32_16x16x32_bf16, 32 rows per wave (default); 32 = v_mfma_f32_32x32x16_bf16 (L3AC_SPLIT_MFMA=32);
+// 64 = 16x16x32 with 64 rows per wave, i.e. 256-row blocks at two per CU (L3AC_SPLIT_MFMA=64)
 template <bool KTAIL, int SHAPE>
-__global__ __launch_bounds__(THREADS, 3) void gemm_split_kernel(const GemmArgs p, const int gp) {
+__global__ __launch_bounds__(THREADS, SHAPE == 64 ? 2 : 3) void gemm_split_kernel(const GemmArgs p, const int gp) {
     if constexpr (SHAPE == 16)
-        gemm_split_body16<KTAIL>(p, gp);
+        gemm_split_body16<KTAIL, 2>(p, gp);
+    else if constexpr (SHAPE == 64)
+        gemm_split_body16<KTAIL, 4>(p, gp);
     else
         gemm_split_body32<KTAIL>(p, gp);
 }
@@ -447,20 +457,28 @@ int launch_gemm_split(hipStream_t s, const GemmArgs& g) {
         return e ? std::atoi(e) : 0;
     }();
     const int gp = gp_env > 0 ? gp_env : 8;
-    static const bool shape32 = [] {  // L3AC_SPLIT_MFMA=32: the 32x32x16 form of the kernel (A/B runs)
+    static const int shape = [] {  // L3AC_SPLIT_MFMA=32: the 32x32x16 form; =64: 16x16x32 with 64 rows per wave (A/B runs)
         const char* e = std::getenv("L3AC_SPLIT_MFMA");
-        return e && std::atoi(e) == 32;
+        const int v = e ? std::atoi(e) : 16;
+        return v == 32 || v == 64 ? v : 16;
     }();
-    if (shape32) {
-        if (g.k % BK == 0)
-            hipLaunchKernelGGL((gemm_split_kernel<false, 32>), dim3((unsigned)blocks), dim3(THREADS), 2 * W_TILE, s, g, gp);
+    const bool tail = g.k % BK != 0;
+    if (shape == 64) {
+        const int64_t blocks64 = ceil_div64(g.m, 2 * BM) * ceil_div64(g.n, BN);
+        if (tail)
+            hipLaunchKernelGGL((gemm_split_kernel<true, 64>), dim3((unsigned)blocks64), dim3(THREADS), 2 * W_TILE, s, g, gp);
         else
+            hipLaunchKernelGGL((gemm_split_kernel<false, 64>), dim3((unsigned)blocks64), dim3(THREADS), 2 * W_TILE, s, g, gp);
+    } else if (shape == 32) {
+        if (tail)
             hipLaunchKernelGGL((gemm_split_kernel<true, 32>), dim3((unsigned)blocks), dim3(THREADS), 2 * W_TILE, s, g, gp);
-    } else {
-        if (g.k % BK == 0)
-            hipLaunchKernelGGL((gemm_split_kernel<false, 16>), dim3((unsigned)blocks), dim3(THREADS), 2 * W_TILE, s, g, gp);
         else
+            hipLaunchKernelGGL((gemm_split_kernel<false, 32>), dim3((unsigned)blocks), dim3(THREADS), 2 * W_TILE, s, g, gp);
+    } else {
+        if (tail)
             hipLaunchKernelGGL((gemm_split_kernel<true, 16>), dim3((unsigned)blocks), dim3(THREADS), 2 * W_TILE, s, g, gp);
+        else
+            hipLaunchKernelGGL((gemm_split_kernel<false, 16>), dim3((unsigned)blocks), dim3(THREADS), 2 * W_TILE, s, g, gp);
     }
     L3AC_LAUNCH_CHECK();
     return L3AC_OK;

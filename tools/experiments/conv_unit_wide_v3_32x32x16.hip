@@ -45,22 +45,17 @@ struct WGeo {
     static constexpr int H4 = 4 * C;
     static constexpr int NT = H4 / 32;      // hidden tiles
     static constexpr int NS1 = C / 16;      // k steps of the first product
-    static constexpr int CT = C / 32;       // output tiles of 32 channels (epilogue)
-    static constexpr int RT = C / 16;       // output row tiles of 16 channels (second product)
+    static constexpr int CT = C / 32;       // output tiles
     static constexpr int KQ = C / 8;        // channel quads per lane half
-    static constexpr int KS = C >= 256 ? 8 : 4;  // pieces (weight fragments of 3 planes x 1 KB = 12 MFMAs) per ring slot: the step barrier, the
-                                                 // DMA statement and the counted wait come once per slot, so fewer, larger slots where the ring
-                                                 // still holds four of them (a multiple of 4: every wave copies whole 1-KB blocks)
-    static constexpr int SLOT = KS * 3 * 1024;
-    static constexpr int NA = NS1 / KS;     // slots of one W1 tile == slots of one W2 tile
-    static constexpr int DMA_N = SLOT / 4096;  // 1-KB LDS-DMA instructions per wave and slot
-    static constexpr int HALF_POS = 49152 / SLOT;  // ring positions per opaque LDS base (fragment offsets must fit 16 bits)
+    static constexpr int KS = 4;            // k steps of W1 per slot
+    static constexpr int SLOT = KS * 3 * 1024;  // = 2 output tiles of W2 (2 x 2 steps x 3 planes x 1 KB)
+    static constexpr int NA = NS1 / KS;     // slots of one W1 tile == slots of one W2 tile (= CT / 2)
     static constexpr int NSTEP = 2 * NA;    // slots per hidden-tile iteration == ring size
     static constexpr int PF = NSTEP - 1;    // slots in flight
     static constexpr int RING = NSTEP * SLOT;
     static constexpr int TOTAL = NT * NSTEP;  // slots of the whole stream
     static constexpr int AP_AGPR_FROM = C >= 256 ? NS1 - 6 : NS1;  // k steps of the LayerNorm operand kept in AGPRs
-    static constexpr int WAIT = DMA_N * (PF - 2);  // this wave's DMA instructions that may stay outstanding at a step's end
+    static constexpr int WAIT = 3 * (PF - 2); // this wave's DMA instructions that may stay outstanding at a step's end
     // LDS (bytes): alpha, 1/alpha, gamma, beta [4][H4] | b1 [H4] | b2 [C] | ring | epilogue transposition buffers.  The tables
     // come first so that their reads (one per activation pair, the tile index in the address) reach with the 16-bit
     // immediate of ds_read from one lane base
@@ -70,7 +65,7 @@ struct WGeo {
     static constexpr int OFF_RING = OFF_B2 + C * 4;
     static constexpr int OFF_TB = OFF_RING + RING;            // epilogue transposition buffers: 2 x 4 KB per wave
     static constexpr int LDS = OFF_TB + 4 * 8192;
-    static_assert(C % 64 == 0 && NS1 % KS == 0 && KS % 4 == 0 && NSTEP <= 2 * HALF_POS, "bad geometry");
+    static_assert(C % 64 == 0 && NS1 % KS == 0 && CT % 2 == 0 && NA == CT / 2, "bad geometry");
     static_assert(PF >= 3 && WAIT <= 63, "ring too small / vmcnt field too narrow");
     static_assert(LDS <= 160 * 1024, "LDS budget exceeded");
 };
@@ -88,39 +83,22 @@ __device__ unsigned long long g_wide_stamps[256 * 16 * 8];
 
 __device__ __forceinline__ int rowmap(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 
-// this wave's quarter of one ring slot: N 1-KB LDS-DMA pieces, lane l copying 16 B from base + 16 l + 1024 i to lds_dst + 16 l + 1024 i.
-// One statement = one M0 write for all pieces (the instruction offset is added to the global AND the LDS address; both are
-// passed pre-biased by +3072 when N = 6 so that the offsets fit the signed 13-bit field), a wave-uniform 64-bit base in SGPRs
-// and one loop-invariant 32-bit lane offset: no vector address arithmetic per piece (guide 5.7: M0 is written in the statement
-// that uses it; the copies are invisible to hipcc's s_waitcnt bookkeeping and are counted by hand).
-template <int N>
+// this wave's quarter of one 12-KB slot: three 1-KB LDS-DMA pieces, lane l copying 16 B from base + 16 l (+0, +1024, +2048) to
+// lds_dst + 16 l (+ the same).  One statement = one M0 write for the three pieces (the instruction offset is added to the
+// global AND the LDS address), a wave-uniform 64-bit base in SGPRs and one loop-invariant 32-bit lane offset: no vector
+// address arithmetic per piece (guide §5.7: M0 is written in the statement that uses it; the copies are invisible to hipcc's
+// s_waitcnt bookkeeping and are counted by hand).
 __device__ __forceinline__ void dma_slot_quarter(const unsigned char* base, unsigned lane_off, unsigned lds_dst) {
-    static_assert(N == 3 || N == 6, "3 KB or 6 KB per wave");
     unsigned keep;
-    if constexpr (N == 3) {
-        asm volatile(
-            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-            "global_load_lds_dwordx4 %1, %2\n\t"
-            "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-            "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(keep)
-            : "v"(lane_off), "s"(base), "s"(lds_dst)
-            : "memory");
-    } else {
-        asm volatile(
-            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-            "global_load_lds_dwordx4 %1, %2 offset:-3072\n\t"
-            "global_load_lds_dwordx4 %1, %2 offset:-2048\n\t"
-            "global_load_lds_dwordx4 %1, %2 offset:-1024\n\t"
-            "global_load_lds_dwordx4 %1, %2\n\t"
-            "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-            "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(keep)
-            : "v"(lane_off), "s"(base + 3072), "s"(lds_dst + 3072u)
-            : "memory");
-    }
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(lane_off), "s"(base), "s"(lds_dst)
+        : "memory");
 }
 
 template <int N, class F, int I = 0>
@@ -219,14 +197,20 @@ __device__ __forceinline__ void act_stage(ActPair& a, const float* tab, float h0
 #undef L3AC_BOTH
 }
 
-// one of the six plane products of a fragment pair, in mfma_split's order (split_bf16.hpp), on v_mfma_f32_16x16x32_bf16: D[16 x 16]
-// += A[16 x 32] B[32 x 16]; A: lane (row = lane & 15, k group = lane >> 4) holds 8 k values; B: lane (column = lane & 15, k group);
-// D: lane (column = lane & 15), registers = rows 4 (lane >> 4) .. + 3.  (Why this shape: DESIGN.md 3.1, 'MFMA shape'.)
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
+// one of the six plane products of a k step, in mfma_split's order (split_bf16.hpp)
 template <int M>
-__device__ __forceinline__ f32x4_t mfma_plane(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4_t acc) {
+__device__ __forceinline__ f32x16_t mfma_plane(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16_t acc) {
     constexpr int IA[6] = {2, 1, 0, 1, 0, 0}, IB[6] = {0, 1, 2, 0, 1, 0};
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[IA[M]], b[IB[M]], acc, 0, 0, 0);
+#ifdef L3AC_WIDE_X16  // timing experiment only (wrong results): the same operands through two 16x16x32 MFMAs (16 cycles each)
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    f32x4v c0 = {acc[0], acc[1], acc[2], acc[3]}, c1 = {acc[4], acc[5], acc[6], acc[7]};
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[IA[M]], b[IB[M]], c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[IA[M]], b[IB[M]], c1, 0, 0, 0);
+    acc[0] = c0.x, acc[1] = c0.y, acc[2] = c0.z, acc[3] = c0.w, acc[4] = c1.x, acc[5] = c1.y, acc[6] = c1.z, acc[7] = c1.w;
+    return acc;
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[IA[M]], b[IB[M]], acc, 0, 0, 0);
+#endif
 }
 
 template <int C>
@@ -241,8 +225,8 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ln = lane & 15;  // frame within a 16-frame half of the tile (MFMA column) / weight row of a fragment
-    const int lg = lane >> 4;  // k group of an operand fragment; row group 4 lg .. 4 lg + 3 of an accumulator tile
+    const int lj = lane & 31;  // frame within the tile (MFMA column)
+    const int lh = lane >> 5;
 
     // LDS addressing of the fragment reads: two per-lane byte offsets kept opaque to the optimiser (ring positions 0-3, 4-7), the
     // rest an immediate of the ds_read (16-bit field).  Left alone, hipcc keeps every base + constant combination beyond 64 KB in
@@ -252,17 +236,17 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
         return v;
     };
     const int ring_lo = opaque(G::OFF_RING + 16 * lane);
-    const int ring_hi = opaque(G::OFF_RING + 16 * lane + G::HALF_POS * G::SLOT);
-    static_assert((G::HALF_POS - 1) * G::SLOT + (G::KS - 1) * 3072 + 2 * 1024 + 1024 < 65536, "fragment offsets must fit the ds_read immediate");
+    const int ring_hi = opaque(G::OFF_RING + 16 * lane + 4 * G::SLOT);
+    static_assert(G::NSTEP <= 8 && 4 * G::SLOT + 3 * 3072 + 2 * 1024 < 65536, "fragment offsets must fit the ds_read immediate");
 
     // ---- the weight stream: this wave copies bytes [3072 wave, 3072 wave + 3072) of every slot ------------------
     const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)ring;
-    const unsigned char* const src_wave = w.wide_img + (G::SLOT / 4) * wave;  // wave-uniform
+    const unsigned char* const src_wave = w.wide_img + 3072 * wave;  // wave-uniform
     const unsigned lane_off = 16u * (unsigned)lane;
     int dma_slot = 0;  // next slot of the stream to fetch (wave-uniform)
     auto issue = [&](int ring_pos) __attribute__((always_inline)) {
 #ifndef L3AC_WIDE_NODMA  // (timing experiments only)
-        dma_slot_quarter<G::DMA_N>(src_wave + (int64_t)dma_slot * G::SLOT, lane_off, ring_lds + (unsigned)(ring_pos * G::SLOT) + (unsigned)(G::SLOT / 4) * (unsigned)wave);
+        dma_slot_quarter(src_wave + (int64_t)dma_slot * G::SLOT, lane_off, ring_lds + (unsigned)(ring_pos * G::SLOT) + 3072u * (unsigned)wave);
 #endif
         dma_slot = dma_slot + 1 == G::TOTAL ? 0 : dma_slot + 1;
     };
@@ -303,7 +287,7 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
         const int64_t wg_passes = (n_tiles + 3) / 4;
         const int64_t max_passes = (wg_passes + gridDim.x - 1) / gridDim.x;
         const int64_t my_passes = (wg_passes - blockIdx.x + gridDim.x - 1) / gridDim.x;
-        constexpr long long PASS_CYCLES = (long long)G::NT * G::NSTEP * (12 * G::KS) * 16 * 6 / 5 + 35000;
+        constexpr long long PASS_CYCLES = (long long)G::NT * G::NSTEP * 24 * 32 * 6 / 5 + 35000;
         const long long delay = my_passes < max_passes ? (long long)((blockIdx.x >> 3) & 7) * (PASS_CYCLES * 9 / 80) : 0;
         const long long t0 = (long long)__builtin_amdgcn_s_memtime();
         while ((long long)__builtin_amdgcn_s_memtime() - t0 < delay) __builtin_amdgcn_s_sleep(16);
@@ -338,163 +322,145 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
             for (int pl = 0; pl < 3; ++pl) asm volatile("" : "+a"(ap[s][pl]));
 
         WIDE_STAMP(1);
-        // ---- output accumulators start at the pw_conv2 bias: yacc[rt][fh][i] = y[channel 16 rt + 4 lg + i][frame 16 fh + ln]
-        f32x4_t yacc[G::RT][2];
+        // ---- output accumulators start at the pw_conv2 bias ------------------------------------------------------
+        f32x16_t yacc[G::CT];
 #pragma unroll
-        for (int rt = 0; rt < G::RT; ++rt) {
-            const f32x4_t b2v = *reinterpret_cast<const f32x4_t*>(B2s + 16 * rt + 4 * lg);
-            yacc[rt][0] = b2v;
-            yacc[rt][1] = b2v;
-        }
+        for (int ct = 0; ct < G::CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) yacc[ct][r] = B2s[32 * ct + rowmap(r, lh)];
 
         // the slot at ring position 0 (and the one after it) must have landed: first pass = the prologue's copies,
         // later passes = guaranteed by the previous pass's last step
         step_sync();
 
-        // a hidden tile of 32 channels x 32 frames = four 16 x 16 accumulator tiles, index 2 hh + fh (hidden half, frame half):
-        // element i of tile (hh, fh) = hidden channel 16 hh + 4 lg + i at frame 16 fh + ln
-        struct XTile { f32x4_t q[4]; };
-        auto bias1 = [&](int nt) __attribute__((always_inline)) -> XTile {
-            XTile t;
+        auto bias1 = [&](int nt) __attribute__((always_inline)) -> f32x16_t {
+            f32x16_t acc;
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const f32x4_t v = *reinterpret_cast<const f32x4_t*>(B1s + 32 * nt + 16 * hh + 4 * lg);
-                t.q[2 * hh] = v;
-                t.q[2 * hh + 1] = v;
-            }
-            return t;
+            for (int r = 0; r < 16; ++r) acc[r] = B1s[32 * nt + rowmap(r, lh)];
+            return acc;
         };
         // the activated hidden tile as the second product's B operand (snake + GRN with normaliser 1, layers.py:29-33, :112-115,
-        // then the bf16x3 split): xbp[fh][plane][w], word w = 2 hh + ip = hidden channels 16 hh + 4 lg + 2 ip, + 1 of frame 16 fh + ln
-        // — the k order sigma(lg, j) = (j < 4 ? 4 lg + j : 16 + 4 lg + j - 4) that the W2 image is built in
+        // then the bf16x3 split): element j of k step s, plane pl
         unsigned xbp[2][3][4];
-        unsigned xbq[3][4];  // frame half 0 of the NEXT tile while xbp[0] still feeds the running second product (a separate array: updating
+        unsigned xbq[3][4];  // first half of the NEXT tile while xbp[0] still feeds the running second product (a separate array: updating
                              // xbp[0] in place made hipcc keep both generations of every tuple and spill 240 registers)
-        // One ring slot = one "slot step" of 12 KS MFMAs (v_mfma_f32_16x16x32_bf16, 16 cycles): KS pieces of 3 planes x 1 KB, a piece =
-        // one weight fragment (16 rows x 32 k) used against both frame halves, 6 plane products each.  First product: piece
-        // (k block b, hidden half hh); second product: piece = output row tile rt.  Every instruction of a slot step is placed
-        // into one of its 12 KS MFMA gaps and a sched_barrier(0) closes every window of three gaps (inside it a sched_group_barrier
-        // pattern of one MFMA + two fillers): gap g = (piece, frame half, plane
-        // product m) holds the MFMA, at three gaps of a piece one fragment read of the NEXT piece (the last piece fetches the first fragment of the following slot, which landed a step ago),
-        // in gap 0 the DMA issue, and the stages of the activation stream that fall to it.  The activation of a hidden tile is
-        // 8 pairs x ACT_STAGES stages: frame half 0 runs beside the SECOND product of the previous tile, frame half 1 beside
-        // the FIRST product of the next tile, so the vector work is spread over all 2 NA x 12 KS gaps of an iteration.
+        // One ring slot = one "slot step" of 24 MFMAs (4 k steps of the first product, or 2 output tiles x 2 k steps of the
+        // second), closed by step_sync.  Every instruction of a slot step is placed by hand into one of its 24 MFMA gaps and
+        // a sched_barrier(0) closes each gap: gap g = (k step ks, plane product m) holds the MFMA, at even m one fragment read
+        // of the NEXT k step (planes in the order the MFMAs take them: 2, 1, 0 — four to six gaps ahead of their use; the last
+        // k step fetches the first fragment of the following slot, which landed a step ago), in gap 0 the DMA issue, and the
+        // stages of the activation stream that fall to it.  The activation of a hidden tile is 8 pairs x ACT_STAGES stages:
+        // its first half (rows 0-7 = k step 0 of the second product's B operand) runs beside the SECOND product of the
+        // previous tile, its second half beside the FIRST product of the next tile, so the vector work is spread over all
+        // 2 NA x 24 gaps of an iteration.
         bf16x8 fb[2][3];
         auto frag1 = [&](int ring_pos, int piece, int pl) __attribute__((always_inline)) -> bf16x8 {
-            return *reinterpret_cast<const bf16x8*>(smem_wide + (ring_pos < G::HALF_POS ? ring_lo : ring_hi) + (ring_pos % G::HALF_POS) * G::SLOT + piece * 3072 + 1024 * pl);
+            return *reinterpret_cast<const bf16x8*>(smem_wide + (ring_pos < 4 ? ring_lo : ring_hi) + (ring_pos & 3) * G::SLOT + piece * 3072 + 1024 * pl);
         };
         ActPair ast[4];
-        // stages of the half-tile stream (4 pairs x ACT_STAGES) that fall to gap `gap` of the half phase's 12 KS NA gaps; pair P of
-        // frame half HALF = hidden half P >> 1, register pair P & 1 of accumulator tile 2 (P >> 1) + HALF
-        auto act_gap = [&](auto gap_, auto half_, const XTile& xa, const float* tab) __attribute__((always_inline)) {
+        // stages of the half-tile stream (4 pairs x ACT_STAGES) that fall to gap `gap` of the half phase's 24 NA gaps
+        auto act_gap = [&](auto gap_, auto half_, const f32x16_t& xa, const float* tab) __attribute__((always_inline)) {
             constexpr int GAP = decltype(gap_)::value, HALF = decltype(half_)::value;
-            constexpr int TOTAL_ST = 4 * ACT_STAGES, GAPS = 12 * G::KS * G::NA;
+            constexpr int TOTAL_ST = 4 * ACT_STAGES, GAPS = 24 * G::NA;
             constexpr int LO = GAP * TOTAL_ST / GAPS, HI = (GAP + 1) * TOTAL_ST / GAPS;
             static_for<HI - LO>([&](auto k_) {
                 constexpr int ST = LO + decltype(k_)::value, P = ST / ACT_STAGES, T = ST % ACT_STAGES;
-                constexpr int Q = 2 * (P >> 1) + HALF, E = 2 * (P & 1);
-                // table row of channels 32 nt + 16 hh + 4 lg + 2 ip, + 1: 8 floats per pair; tab carries nt and lg
-                const float* row = tab + 64 * (P >> 1) + 8 * (P & 1);
+                constexpr int R = 2 * (4 * HALF + P);  // the pair's first accumulator register
+                // rows rowmap(R, lh), +1 of the tile: table row (32 nt + rowmap) / 2, 8 floats each; tab carries nt and lh
                 if constexpr (HALF == 0)
-                    act_stage<T>(ast[P], row, xa.q[Q][E], xa.q[Q][E + 1], xbq[0][P], xbq[1][P], xbq[2][P]);
+                    act_stage<T>(ast[P], tab + 4 * ((R & 3) + 8 * (R >> 2)), xa[R], xa[R + 1], xbq[0][P], xbq[1][P], xbq[2][P]);
                 else
-                    act_stage<T>(ast[P], row, xa.q[Q][E], xa.q[Q][E + 1], xbp[1][0][P], xbp[1][1][P], xbp[1][2][P]);
+                    act_stage<T>(ast[P], tab + 4 * ((R & 3) + 8 * (R >> 2)), xa[R], xa[R + 1], xbp[1][0][P], xbp[1][1][P], xbp[1][2][P]);
             });
         };
-        // PHASE 0: first product, pieces 4 I .. 4 I + 3 = (k block, hidden half) of a hidden tile from ring slot POS into acc.
-        // PHASE 1: second product, output row tiles 4 I .. 4 I + 3 from ring slot POS with B operand xb[frame half].
+        // PHASE 0: first product, k steps KS I .. KS I + 3 of a hidden tile from ring slot POS into acc.
+        // PHASE 1: second product, output tiles 2 I, 2 I + 1 from ring slot POS (piece 2 c2 + s) with B operand xb.
         // NEXT: the ring slot whose first fragment is fetched for the following slot step (-1: none).  ACT: -1 none, else the
-        // frame half (0 / 1) of the activation stream of xa that runs in the gaps.
-        auto slot_step = [&](auto phase_, auto pos_, auto next_, auto i_, auto act_, int issue_pos, XTile& acc,
-                             const bf16x8 (&xb)[2][3], const XTile& xa, const float* tab) __attribute__((always_inline)) {
+        // half (0 / 1) of the activation stream of xa that runs in the gaps.  BIAS: fetch the next-but-one tile's pw_conv1 bias
+        // into xinit (the registers the finished tile left) at the free odd gaps.
+        auto slot_step = [&](auto phase_, auto pos_, auto next_, auto i_, auto act_, auto bias_, int issue_pos, f32x16_t& acc,
+                             const bf16x8 (&xb)[2][3], const f32x16_t& xa, const float* tab, f32x16_t& xinit,
+                             const float* bias_src) __attribute__((always_inline)) {
             constexpr int PHASE = decltype(phase_)::value, POS = decltype(pos_)::value, NEXT = decltype(next_)::value;
             constexpr int I = decltype(i_)::value, ACT = decltype(act_)::value;
-            static_for<12 * G::KS>([&](auto g_) {
-                constexpr int g = decltype(g_)::value, pc = g / 12, fh = (g % 12) / 6, m = g % 6;
-                constexpr int piece = G::KS * I + pc;
+            constexpr bool BIAS = decltype(bias_)::value;
+            static_for<24>([&](auto g_) {
+                constexpr int g = decltype(g_)::value, ks = g / 6, m = g % 6;
                 if constexpr (PHASE == 0)
-                    acc.q[2 * (piece & 1) + fh] = mfma_plane<m>(fb[pc & 1], ap[2 * (piece >> 1) + fh], acc.q[2 * (piece & 1) + fh]);
+                    acc = mfma_plane<m>(fb[ks & 1], ap[G::KS * I + ks], acc);
                 else
-                    yacc[piece][fh] = mfma_plane<m>(fb[pc & 1], xb[fh], yacc[piece][fh]);
-                // the next piece's planes in the order 0, 1, 2: its first MFMA takes plane 2 of the weights, the YOUNGEST read, so the one
-                // s_waitcnt in front of it covers all three (LDS returns in order) instead of one wait per plane
-                if constexpr (g % 12 == 0 || g % 12 == 3 || g % 12 == 6) {
-                    constexpr int pl = (g % 12) / 3;
-                    if constexpr (pc + 1 < G::KS)
-                        fb[(pc + 1) & 1][pl] = frag1(POS, pc + 1, pl);
+                    yacc[2 * I + (ks >> 1)] = mfma_plane<m>(fb[ks & 1], xb[ks & 1], yacc[2 * I + (ks >> 1)]);
+                if constexpr (m % 2 == 0) {
+                    constexpr int pl = 2 - m / 2;
+                    if constexpr (ks + 1 < 4)
+                        fb[(ks + 1) & 1][pl] = frag1(POS, ks + 1, pl);
                     else if constexpr (NEXT >= 0)
                         fb[0][pl] = frag1(NEXT, 0, pl);
                 }
                 if constexpr (g == 0) issue(issue_pos);
-                if constexpr (ACT >= 0) act_gap(std::integral_constant<int, 12 * G::KS * I + g>{}, std::integral_constant<int, ACT>{}, xa, tab);
-#ifndef L3AC_WIDE_WALL_EVERY
-#define L3AC_WIDE_WALL_EVERY 3  // a wall after every gap (or every second) sends hipcc's register allocation over the edge at C = 256
-#endif
-                if constexpr (g % L3AC_WIDE_WALL_EVERY == L3AC_WIDE_WALL_EVERY - 1) {
-#ifndef L3AC_WIDE_SGB
-#define L3AC_WIDE_SGB 2
-#endif
-#if L3AC_WIDE_SGB > 0
-                    // inside a window: one MFMA, then at most L3AC_WIDE_SGB fillers — a 16-cycle MFMA holds the issue port for 8, so a
-                    // gap costs max(16, 8 + 4 fillers) cycles: two per gap are free, the third and fourth cost 4 cycles each
-                    // (measured: the loop's cycles follow that sum over the gaps of the compiled stream)
-                    static_for<L3AC_WIDE_WALL_EVERY>([&](auto) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x106, L3AC_WIDE_SGB, 0);
-                    });
-#endif
-                    __builtin_amdgcn_sched_barrier(0);
+                if constexpr (BIAS && m % 2 == 1 && g < 8) {
+                    typedef float f32x4v __attribute__((ext_vector_type(4)));
+                    const f32x4v v = *reinterpret_cast<const f32x4v*>(bias_src + 8 * (g / 2));
+                    xinit[4 * (g / 2)] = v.x, xinit[4 * (g / 2) + 1] = v.y, xinit[4 * (g / 2) + 2] = v.z, xinit[4 * (g / 2) + 3] = v.w;
                 }
+                if constexpr (ACT >= 0) act_gap(std::integral_constant<int, 24 * I + g>{}, std::integral_constant<int, ACT>{}, xa, tab);
+#ifndef NO_GAP_WALL
+                __builtin_amdgcn_sched_barrier(0);
+#endif
             });
             step_sync();
             __builtin_amdgcn_sched_barrier(0);
         };
         auto make_xb = [&](bf16x8 (&xb)[2][3]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int fh = 0; fh < 2; ++fh)
+            for (int s = 0; s < 2; ++s)
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
-                    xb[fh][pl] = __builtin_bit_cast(bf16x8, u32x4{xbp[fh][pl][0], xbp[fh][pl][1], xbp[fh][pl][2], xbp[fh][pl][3]});
+                    xb[s][pl] = __builtin_bit_cast(bf16x8, u32x4{xbp[s][pl][0], xbp[s][pl][1], xbp[s][pl][2], xbp[s][pl][3]});
         };
         using IC_none = std::integral_constant<int, -1>;
-        const float* const tab_lane = Pt + 16 * lg;  // + 128 nt: the lane's rows of hidden tile nt
+        const float* const tab_lane = Pt + 16 * lh;  // + 128 nt: the lane's rows of hidden tile nt
+        const float* const b1_lane = B1s + 4 * lh;   // + 32 nt
         bf16x8 xb[2][3] = {};
-        XTile xdummy = {};
+        f32x16_t xdummy = {};
 
         WIDE_STAMP(2);
-        // ---- first product of hidden tile 0 (ring slots 0 .. NA-1), then frame half 0 of its activation: nothing to overlap
+        // ---- first product of hidden tile 0 (ring slots 0 .. NA-1), then the first half of its activation: nothing to overlap
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) fb[0][pl] = frag1(0, 0, pl);
-        XTile xacc = bias1(0);
+        f32x16_t xacc = bias1(0);
+        f32x16_t xinit = {};
         static_for<G::NA>([&](auto i_) {
             constexpr int i = decltype(i_)::value;
             slot_step(std::integral_constant<int, 0>{}, std::integral_constant<int, i>{}, std::integral_constant<int, i + 1>{}, i_, IC_none{},
-                      (i + G::PF) % G::NSTEP, xacc, xb, xdummy, tab_lane);
+                      std::false_type{}, (i + G::PF) % G::NSTEP, xacc, xb, xdummy, tab_lane, xdummy, b1_lane);
         });
         static_for<4 * ACT_STAGES>([&](auto st_) {
-            constexpr int ST = decltype(st_)::value, P = ST / ACT_STAGES, T = ST % ACT_STAGES, Q = 2 * (P >> 1), E = 2 * (P & 1);
-            act_stage<T>(ast[P], tab_lane + 64 * (P >> 1) + 8 * (P & 1), xacc.q[Q][E], xacc.q[Q][E + 1], xbp[0][0][P], xbp[0][1][P], xbp[0][2][P]);
+            constexpr int ST = decltype(st_)::value, P = ST / ACT_STAGES, T = ST % ACT_STAGES, R = 2 * P;
+            act_stage<T>(ast[P], tab_lane + 4 * ((R & 3) + 8 * (R >> 2)), xacc[R], xacc[R + 1], xbp[0][0][P], xbp[0][1][P], xbp[0][2][P]);
         });
 
         WIDE_STAMP(3);
 #pragma unroll 1
         for (int nt = 0; nt + 1 < G::NT; ++nt) {
-            // ---- A: first product of tile nt+1 (slots NA .. 2NA-1) beside frame half 1 of tile nt's activation ------------
-            XTile xnext = bias1(nt + 1);
+            // ---- A: first product of tile nt+1 (slots NA .. 2NA-1) beside the second half of tile nt's activation -------
+            f32x16_t xnext = bias1(nt + 1);
             const float* const tab_a = tab_lane + 128 * nt;
             static_for<G::NA>([&](auto i_) {
                 constexpr int i = decltype(i_)::value;
                 slot_step(std::integral_constant<int, 0>{}, std::integral_constant<int, G::NA + i>{},
-                          std::integral_constant<int, (G::NA + i + 1) % G::NSTEP>{}, i_, std::integral_constant<int, 1>{},
-                          (G::NA + i + G::PF) % G::NSTEP, xnext, xb, xacc, tab_a);
+                          std::integral_constant<int, (G::NA + i + 1) % G::NSTEP>{}, i_, std::integral_constant<int, 1>{}, std::false_type{},
+                          (G::NA + i + G::PF) % G::NSTEP, xnext, xb, xacc, tab_a, xdummy, b1_lane);
             });
-            // ---- B: second product of tile nt (slots 0 .. NA-1) beside frame half 0 of tile nt+1's activation ---------------
+            // ---- B: second product of tile nt (slots 0 .. NA-1) beside the first half of tile nt+1's activation ----------
             make_xb(xb);
             const float* const tab_b = tab_a + 128;
+            const float* const bias_b = b1_lane + 32 * (nt + 2);  // nt + 2 == NT on the last iteration: reads the b2 table, unused
             static_for<G::NA>([&](auto i_) {
                 constexpr int i = decltype(i_)::value;
                 slot_step(std::integral_constant<int, 1>{}, std::integral_constant<int, i>{}, std::integral_constant<int, i + 1>{}, i_,
-                          std::integral_constant<int, 0>{}, (i + G::PF) % G::NSTEP, xdummy, xb, xnext, tab_b);
+                          std::integral_constant<int, 0>{}, std::false_type{}, (i + G::PF) % G::NSTEP, xdummy, xb,
+                          xnext, tab_b, xinit, bias_b);
             });
             xacc = xnext;
 #pragma unroll
@@ -516,19 +482,19 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
                 const bool ok = tile_ok && rr < rows;
                 xres[ct][i] = *reinterpret_cast<const float4*>(x + (ok ? rr : 0) * C + 32 * ct + 4 * es);
             }
-        // ---- last hidden tile: frame half 1 of its activation alone, second product from slots NA .. 2NA-1 ------------------
+        // ---- last hidden tile: second half of its activation alone, second product from slots NA .. 2NA-1 ------------------
         static_for<4 * ACT_STAGES>([&](auto st_) {
-            constexpr int ST = decltype(st_)::value, P = ST / ACT_STAGES, T = ST % ACT_STAGES, Q = 2 * (P >> 1) + 1, E = 2 * (P & 1);
-            act_stage<T>(ast[P], tab_lane + 128 * (G::NT - 1) + 64 * (P >> 1) + 8 * (P & 1), xacc.q[Q][E], xacc.q[Q][E + 1], xbp[1][0][P],
-                         xbp[1][1][P], xbp[1][2][P]);
+            constexpr int ST = decltype(st_)::value, P = ST / ACT_STAGES, T = ST % ACT_STAGES, R = 2 * (4 + P);
+            act_stage<T>(ast[P], tab_lane + 128 * (G::NT - 1) + 4 * ((R & 3) + 8 * (R >> 2)), xacc[R], xacc[R + 1], xbp[1][0][P], xbp[1][1][P],
+                         xbp[1][2][P]);
         });
         make_xb(xb);
         static_for<G::NA>([&](auto i_) {
             constexpr int i = decltype(i_)::value;
             // the stream wraps: the slot after the pass's last one is ring position 0, the first slot of the next pass
             slot_step(std::integral_constant<int, 1>{}, std::integral_constant<int, G::NA + i>{},
-                      std::integral_constant<int, (G::NA + i + 1) % G::NSTEP>{}, i_, IC_none{}, (G::NA + i + G::PF) % G::NSTEP, xdummy, xb,
-                      xdummy, tab_lane);
+                      std::integral_constant<int, (G::NA + i + 1) % G::NSTEP>{}, i_, IC_none{}, std::false_type{},
+                      (G::NA + i + G::PF) % G::NSTEP, xdummy, xb, xdummy, tab_lane, xdummy, b1_lane);
         });
 
         WIDE_STAMP(5);
@@ -538,19 +504,14 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
         // back row-major — so that the residual load and the store move whole 128-B lines, 8 rows per instruction.
         {
             unsigned char* tbuf = smem_wide + G::OFF_TB + 8192 * wave;
+            const int swl = (lj ^ (lj >> 3)) & 7;
 #pragma unroll
             for (int ct = 0; ct < G::CT; ++ct) {
                 unsigned char* tb = tbuf + (ct & 1) * 4096;  // two tiles in flight
-                // this lane's 4 x 16 B of the 32-channel tile: row tiles 2 ct, 2 ct + 1 (channels 16 rtl + 4 lg .. + 3 = slot 4 rtl + lg),
-                // frames ln and 16 + ln
 #pragma unroll
-                for (int rtl = 0; rtl < 2; ++rtl)
-#pragma unroll
-                    for (int fh = 0; fh < 2; ++fh) {
-                        const int fr = 16 * fh + ln;
-                        const f32x4_t v = yacc[2 * ct + rtl][fh];
-                        *reinterpret_cast<float4*>(tb + 128 * fr + 16 * ((4 * rtl + lg) ^ ((fr ^ (fr >> 3)) & 7))) = make_float4(v.x, v.y, v.z, v.w);
-                    }
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(tb + 128 * lj + 16 * ((2 * g + lh) ^ swl)) =
+                        make_float4(yacc[ct][4 * g], yacc[ct][4 * g + 1], yacc[ct][4 * g + 2], yacc[ct][4 * g + 3]);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -575,10 +536,9 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
 
 // ---- front end: depth-wise conv k7 + LayerNorm (modules.py:33-35, layers.py:80) -> three bf16 planes in the main kernel's
 // fragment order.  One thread = one frame x one channel quad, one wave per frame, one 32-frame tile per workgroup (8 frames
-// per wave); taps outside the frame's clip are the conv's zero padding.  Plane image: [tile of 32 frames][block s = 2 b + fh]
-// [plane][1 KB] for k block b (32 channels) and frame half fh; inside a block lane (n = frame & 15, kg) owns 16 B = channels
-// 32 b + 8 kg .. + 7 of frame 16 fh + n — the B operand of v_mfma_f32_16x16x32_bf16: channel quad Q of frame f lands in block
-// 2 (Q >> 3) + (f >> 4) at byte 16 (16 ((Q >> 1) & 3) + (f & 15)) + 8 (Q & 1).
+// per wave); taps outside the frame's clip are the conv's zero padding.  Plane image: [tile of 32 frames][k step s][plane][1 KB]; inside a block lane (lh, lj) owns 16 B =
+// channels split_sigma(s, lh, j), j = 0..7, of frame lj: quad Q = C-channel / 4 of frame lj lands in block s = Q >> 2 at
+// byte 16 (32 (Q & 1) + lj) + 8 ((Q >> 1) & 1).
 template <int C>
 __global__ __launch_bounds__(256) void dwconv_ln_split_kernel(const ConvUnitW w, const float* __restrict__ x, unsigned char* __restrict__ planes,
                                                               const int64_t rows, const int frames) {
@@ -633,7 +593,7 @@ __global__ __launch_bounds__(256) void dwconv_ln_split_kernel(const ConvUnitW w,
             split2(dz * rstd * lw.z + lb.z, dw_ * rstd * lw.w + lb.w, p[0][1], p[1][1], p[2][1]);
         }
         if (lane_ok) {
-            unsigned char* dst = img + (2 * (q >> 3) + (lj >> 4)) * 3072 + 16 * (16 * ((q >> 1) & 3) + (lj & 15)) + 8 * (q & 1);
+            unsigned char* dst = img + (q >> 2) * 3072 + 16 * (32 * (q & 1) + lj) + 8 * ((q >> 1) & 1);
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint2*>(dst + 1024 * pl) = make_uint2(p[pl][0], p[pl][1]);
         }
@@ -695,49 +655,13 @@ int launch_conv_unit_wide(hipStream_t s, const ConvUnitW& w, const float* x, flo
     }
 }
 
-// The weight stream in consumption order: W1(0) | W1(1) W2(0) | W1(2) W2(1) | ... | W1(NT-1) W2(NT-2) | W2(NT-1), where W1(nt) / W2(nt) are
-// the fragment-ordered images of hidden tile nt for v_mfma_f32_16x16x32_bf16 (A operand: lane (m = lane & 15, kg = lane >> 4) holds 8
-// consecutive bf16 of row m), C/16 pieces of 3 planes x 1 KB each:
-//   W1(nt): piece 2 b + hh (k block b, hidden half hh), plane p, lane (m, kg): W1[32 nt + 16 hh + m][32 b + 8 kg + j], j = 0..7
-//   W2(nt): piece rt (output row tile), plane p, lane (m, kg): W2[16 rt + m][32 nt + sigma(kg, j)], sigma(kg, j) = j < 4 ? 4 kg + j :
-//           16 + 4 kg + j - 4 — the order in which the activated accumulator tiles become the second product's B operand
-namespace {
-void put_split(std::vector<unsigned char>& img, size_t off, float v) {  // the three bf16 planes of v, 1 KB apart
-    uint16_t pl[3];
-    split3_host(v, pl);
-    for (int p = 0; p < 3; ++p) std::memcpy(img.data() + off + (size_t)p * 1024, &pl[p], 2);
-}
-std::vector<unsigned char> wide_w1_image(const float* w1, int c) {
-    const int h4 = 4 * c, pieces = c / 16;
-    std::vector<unsigned char> img((size_t)(h4 / 32) * pieces * 3072, 0);
-    for (int nt = 0; nt < h4 / 32; ++nt)
-        for (int b = 0; b < c / 32; ++b)
-            for (int hh = 0; hh < 2; ++hh)
-                for (int m = 0; m < 16; ++m)
-                    for (int kg = 0; kg < 4; ++kg)
-                        for (int j = 0; j < 8; ++j)
-                            put_split(img, ((size_t)nt * pieces + 2 * b + hh) * 3072 + (size_t)(16 * kg + m) * 16 + 2 * j,
-                                      w1[(size_t)(32 * nt + 16 * hh + m) * c + 32 * b + 8 * kg + j]);
-    return img;
-}
-std::vector<unsigned char> wide_w2_image(const float* w2, int c) {
-    const int h4 = 4 * c, pieces = c / 16;
-    std::vector<unsigned char> img((size_t)(h4 / 32) * pieces * 3072, 0);
-    for (int nt = 0; nt < h4 / 32; ++nt)
-        for (int rt = 0; rt < pieces; ++rt)
-            for (int m = 0; m < 16; ++m)
-                for (int kg = 0; kg < 4; ++kg)
-                    for (int j = 0; j < 8; ++j) {
-                        const int sigma = j < 4 ? 4 * kg + j : 16 + 4 * kg + j - 4;
-                        put_split(img, ((size_t)nt * pieces + rt) * 3072 + (size_t)(16 * kg + m) * 16 + 2 * j,
-                                  w2[(size_t)(16 * rt + m) * h4 + 32 * nt + sigma]);
-                    }
-    return img;
-}
-}  // namespace
+// The weight stream in consumption order: W1(0) | W1(1) W2(0) | W1(2) W2(1) | ... | W1(NT-1) W2(NT-2) | W2(NT-1), where
+// W1(nt) / W2(nt) are the fragment-ordered tile images of conv_unit_w1_image / conv_unit_w2_image (conv_unit_split.hip):
+//   W1(nt): k step s, plane p, lane half h, row r (32): 8 bf16 = W1[32 nt + r][split_sigma(s, h, j)]      (C/16 x 3 KB)
+//   W2(nt): output tile ct, k step s (2), plane, half, row: 8 bf16 = W2[32 ct + r][32 nt + split_sigma(s, h, j)]  (C/32 x 6 KB)
 std::vector<unsigned char> conv_unit_wide_image(const float* w1, const float* w2, int c) {
-    const std::vector<unsigned char> i1 = wide_w1_image(w1, c), i2 = wide_w2_image(w2, c);
-    const size_t t1 = (size_t)(c / 16) * 3072, t2 = t1;
+    const std::vector<unsigned char> i1 = conv_unit_w1_image(w1, c), i2 = conv_unit_w2_image(w2, c);
+    const size_t t1 = (size_t)(c / 16) * 3072, t2 = (size_t)192 * c;
     const int nt_n = 4 * c / 32;
     std::vector<unsigned char> img;
     img.reserve(i1.size() + i2.size());
