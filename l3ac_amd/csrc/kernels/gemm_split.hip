@@ -44,9 +44,14 @@ constexpr int W_TILE = 3 * W_PLANE;   // = L3AC_SPLIT_TILE_BYTES
 constexpr int W_LOADS = W_TILE / (16 * THREADS);
 static_assert(W_TILE == L3AC_SPLIT_TILE_BYTES, "image geometry");
 
-// byte offset of 16-B chunk `chunk` (8 k values) of row `row` in a [128][32] bf16 plane; the XOR spreads the 16 rows a
-// ds_read_b128 lane group touches over all 16 slots of the 256-B bank row
-__host__ __device__ __forceinline__ int tile_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+// byte offset of 16-B chunk `chunk` (8 k values) of row `row` in a [128][32] bf16 plane: chunk ^ sigma(row / 4) with sigma(q) = -q mod 4.
+// A ds_read_b128 is served in four groups of 16 lanes — {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 — and a group
+// is conflict-free when its lanes hit 16 distinct 16-B slots of the 256-B bank row, i.e. distinct values of 4 (row & 3) + position.
+//   16x16x32 fragments: lane (n = lane & 15, kg = lane >> 4) reads chunk kg of row 16 t + n, so a group holds the (row / 4, kg) pairs
+//     {(0,0), (3,0), (1,1), (2,1)} (and the like): kg ^ {0, 3, 2, 1}[row / 4] separates them; sigma(q) = q (round 1) does not.
+//   32x32x16 fragments: lane (row = lane & 31, h) reads chunk 2 s + h: a group holds one chunk of rows with four different row / 4:
+//     any bijective sigma is conflict-free.
+__host__ __device__ __forceinline__ int tile_off(int row, int chunk) { return row * 64 + ((chunk ^ ((0 - (row >> 2)) & 3)) << 4); }
 
 // w [n][k] fp32 (row stride ldw) -> tile-ordered split image (device-side builder; network.hip builds the same image on
 // the host).  One thread = one 16-B chunk (8 k values of one row) of each plane.
@@ -194,71 +199,100 @@ __device__ __forceinline__ void gemm_split_body32(const GemmArgs& p, const int g
 //   D:               acc[h][t][i] = c[row 16 h + 4 (lane >> 4) + i][column 16 t + (lane & 15)].
 typedef float f32x4a __attribute__((ext_vector_type(4)));
 
+// Epilogue of the 16x16 accumulator layout.  Stored as they are, the tiles give 64-B row segments (16 lanes x 4 B) — measured: 29-42 k
+// cycles per block, a quarter to a half of a block's life, ten times the 32x32 layout's epilogue.  v_permlane16_swap_b32 exchanges the
+// odd 16-lane rows of one register with the even rows of another: applied to element i of the column tiles 2 u and 2 u + 1 it leaves
+//   first  result: lanes 0-31 = row 16 h + i,     columns 32 u .. 32 u + 31; lanes 32-63 = row 16 h + 8 + i,  same columns
+//   second result: lanes 0-31 = row 16 h + 4 + i, columns 32 u .. 32 u + 31; lanes 32-63 = row 16 h + 12 + i, same columns
+// i.e. whole 128-B lines per half wave, and the lane's column (hence its bias / snake / GRN parameters) is 32 u + (lane & 31) for both.
 template <int RG>
-__device__ __forceinline__ void gemm_epilogue16(const GemmArgs& p, f32x4a (&acc)[RG][8], int64_t m0, int n0, int wave, int ln, int lg) {
-    const int64_t mw = m0 + 16 * RG * wave + 4 * lg;  // + 16 h + i
+__device__ __forceinline__ void gemm_epilogue16(const GemmArgs& p, f32x4a (&acc)[RG][8], int64_t m0, int n0, int wave, int lane) {
+    const int c32 = lane & 31, hi = lane >> 5;
+    const int64_t mw = m0 + 16 * RG * wave + 8 * hi;  // + 16 h + i (first result), + 16 h + 4 + i (second)
+    // (inline asm: with __builtin_amdgcn_permlane16_swap hipcc 7.2 folded the four swaps of a tile pair into one — every row of a
+    // group of eight came out as its first; the s_nop covers the VALU-write -> permlane read hazard of operands written just before)
+    auto swapped = [&](int h, int u, int i, float& lo, float& up) __attribute__((always_inline)) {
+        float a = acc[h][2 * u][i], b = acc[h][2 * u + 1][i];
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a), "+v"(b));
+        lo = a;
+        up = b;
+    };
     if (p.epi == EPI_GEGLU) {
-        // 32-column tiles come in (value, gate) pairs: 16-column tiles t, t + 2 for t = 0, 1, 4, 5; output column
-        // j = n0 / 2 + 16 (t / 2) + 16 (t & 1) + ln with t / 2 even
+        // 32-column tiles come in (value, gate) pairs u = 0, 2 with u + 1; output column j = n0 / 2 + 16 u + c32
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            if ((t >> 1) & 1) continue;
-            const int j = (n0 >> 1) + 16 * (t >> 1) + 16 * (t & 1) + ln;
-            if (j >= (int)p.ldc) continue;
+        for (int u = 0; u < 4; u += 2) {
+            const int j = (n0 >> 1) + 16 * u + c32;
 #pragma unroll
             for (int h = 0; h < RG; ++h)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
+                    float v0, v1, g0, g1;
+                    swapped(h, u, i, v0, v1);
+                    swapped(h, u + 1, i, g0, g1);
                     const int64_t m = mw + 16 * h + i;
-                    if (m < p.m) p.c[m * p.ldc + j] = acc[h][t][i] * gelu_erf(acc[h][t + 2][i]);
+                    if (j < (int)p.ldc) {
+                        if (m < p.m) p.c[m * p.ldc + j] = v0 * gelu_erf(g0);
+                        if (m + 4 < p.m) p.c[(m + 4) * p.ldc + j] = v1 * gelu_erf(g1);
+                    }
                 }
         }
         return;
     }
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const int n = n0 + 16 * t + ln;
-        if (n >= p.n) continue;
-        const float bias = p.bias ? p.bias[n] : 0.f;
+    for (int u = 0; u < 4; ++u) {
+        const int n = n0 + 32 * u + c32;
+        const bool n_ok = n < p.n;
+        const int nc = n_ok ? n : 0;
+        const float bias = p.bias ? p.bias[nc] : 0.f;
         float alpha = 0.f, inv_alpha = 0.f, gamma = 0.f, beta = 0.f;
         if (p.epi == EPI_SNAKE || p.epi == EPI_SNAKE_GRN) {
-            alpha = p.alpha[n];
-            inv_alpha = p.inv_alpha[n];
+            alpha = p.alpha[nc];
+            inv_alpha = p.inv_alpha[nc];
         }
         if (p.epi == EPI_SNAKE_GRN) {
-            gamma = p.gamma[n];
-            beta = p.beta[n];
-        }
-        if (p.epi == EPI_SNAKE || p.epi == EPI_SNAKE_GRN) {  // packed fp32 math on register pairs (two rows, same column)
-            const f32x2 al = (f32x2)(alpha), ia = (f32x2)(inv_alpha), ga = (f32x2)(gamma), be = (f32x2)(beta), bi = (f32x2)(bias);
-#pragma unroll
-            for (int h = 0; h < RG; ++h)
-#pragma unroll
-                for (int i = 0; i < 4; i += 2) {
-                    f32x2 hv;
-                    hv.x = acc[h][t][i];
-                    hv.y = acc[h][t][i + 1];
-                    const f32x2 sv = snake_act2(hv + bi, al, ia);
-                    const f32x2 o = p.epi == EPI_SNAKE_GRN ? __builtin_elementwise_fma(ga, sv, be) + sv : sv;  // layers.py:115, n_x == 1
-                    const int64_t m = mw + 16 * h + i;
-                    if (m < p.m) p.c[m * p.ldc + n] = o.x;
-                    if (m + 1 < p.m) p.c[(m + 1) * p.ldc + n] = o.y;
-                }
-            continue;
+            gamma = p.gamma[nc];
+            beta = p.beta[nc];
         }
 #pragma unroll
-        for (int h = 0; h < RG; ++h)
+        for (int h = 0; h < RG; ++h) {
+            float lo[4], up[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int64_t m = mw + 16 * h + i;
-                if (m >= p.m) continue;
-                float v = acc[h][t][i] + bias;
-                if (p.epi == EPI_BIAS_RES) v = p.res[m * p.ldres + n] + v;
-                p.c[m * p.ldc + n] = v;
+            for (int i = 0; i < 4; ++i) swapped(h, u, i, lo[i], up[i]);  // (every lane takes part in the swap: no early exit above)
+            if (!n_ok) continue;
+            if (p.epi == EPI_SNAKE || p.epi == EPI_SNAKE_GRN) {  // packed fp32 math on register pairs (two rows, same column)
+                const f32x2 al = (f32x2)(alpha), ia = (f32x2)(inv_alpha), ga = (f32x2)(gamma), be = (f32x2)(beta), bi = (f32x2)(bias);
+#pragma unroll
+                for (int half = 0; half < 2; ++half)
+#pragma unroll
+                    for (int i = 0; i < 4; i += 2) {
+                        f32x2 hv;
+                        hv.x = half ? up[i] : lo[i];
+                        hv.y = half ? up[i + 1] : lo[i + 1];
+                        const f32x2 sv = snake_act2(hv + bi, al, ia);
+                        const f32x2 o = p.epi == EPI_SNAKE_GRN ? __builtin_elementwise_fma(ga, sv, be) + sv : sv;  // layers.py:115, n_x == 1
+                        const int64_t m = mw + 16 * h + 4 * half + i;
+                        if (m < p.m) p.c[m * p.ldc + n] = o.x;
+                        if (m + 1 < p.m) p.c[(m + 1) * p.ldc + n] = o.y;
+                    }
+                continue;
             }
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int64_t m = mw + 16 * h + 4 * half + i;
+                    if (m >= p.m) continue;
+                    float v = (half ? up[i] : lo[i]) + bias;
+                    if (p.epi == EPI_BIAS_RES) v = p.res[m * p.ldres + n] + v;
+                    p.c[m * p.ldc + n] = v;
+                }
+        }
     }
 }
 
+#ifdef L3AC_SPLIT_STAMPS  // diagnostic build (tools/split_stamps.py): per-phase s_memtime sums of wave 0 of the first 4096 blocks
+__device__ long long g_split_stamps[8 * 4096];
+#endif
 template <bool KTAIL, int RG>
 __device__ __forceinline__ void gemm_split_body16(const GemmArgs& p, const int gp) {
     constexpr int WM = 16 * RG;   // rows per wave
@@ -329,8 +363,16 @@ __device__ __forceinline__ void gemm_split_body16(const GemmArgs& p, const int g
     store_w(0);
     __syncthreads();
     // straight-line body: tile indices are clamped instead of branched on, which keeps hipcc's s_waitcnt counts exact
+#ifdef L3AC_SPLIT_STAMPS
+    long long t_split = 0, t_mfma = 0, t_tail = 0;
+    const long long t_begin = (long long)__builtin_amdgcn_s_memtime();
+#define SPLIT_STAMP() ((long long)__builtin_amdgcn_s_memtime())
+#endif
     auto step = [&](int kt, float4 (&cur)[2 * RG]) __attribute__((always_inline)) {
         const int buf = kt & 1;
+#ifdef L3AC_SPLIT_STAMPS
+        const long long s0 = SPLIT_STAMP();
+#endif
         load_w(kt + 1 < last ? kt + 1 : last);
         u32x4 af[RG][3];
 #pragma unroll
@@ -345,7 +387,16 @@ __device__ __forceinline__ void gemm_split_body16(const GemmArgs& p, const int g
             af[h][2] = u32x4{x2, y2, z2, u2};
         }
         load_a(kt + 2 < last ? kt + 2 : last, cur);  // the registers are free again: two tiles ahead
+        // Keep these loads HERE.  Nothing reads them before the next iteration, so hipcc's scheduler sinks them to the end of the
+        // loop body — just in front of the s_waitcnt vmcnt(0) that opens the next step's split — and every k tile then waits a full
+        // memory latency for its A operand: 3.0-3.5 k of a wave's 6.6 k cycles per k tile (tools/split_stamps.py).
+        __builtin_amdgcn_sched_barrier(0);
         const unsigned char* ws = smem_split + buf * W_TILE;
+#ifdef L3AC_SPLIT_STAMPS
+        asm volatile("" : "+v"(af[0][0]), "+v"(af[RG - 1][2]));
+        const long long s1 = SPLIT_STAMP();
+        t_split += s1 - s0;
+#endif
         bf16x8 bq[2][3];
         read_b(ws, 0, bq[0]);
 #pragma unroll
@@ -364,15 +415,35 @@ __device__ __forceinline__ void gemm_split_body16(const GemmArgs& p, const int g
                 acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, acc[h][t], 0, 0, 0);
                 acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc[h][t], 0, 0, 0);
             }
+#ifndef L3AC_SPLIT_STAMPS
             if (t == 3) store_w(buf ^ 1);
+#endif
         }
+#ifdef L3AC_SPLIT_STAMPS
+        asm volatile("" : "+v"(acc[0][7]), "+v"(acc[RG - 1][7]));
+        const long long s2 = SPLIT_STAMP();
+        t_mfma += s2 - s1;
+        store_w(buf ^ 1);
+#endif
         __syncthreads();
+#ifdef L3AC_SPLIT_STAMPS
+        t_tail += SPLIT_STAMP() - s2;
+#endif
     };
     for (int kt = 0; kt < n_tiles; kt += 2) {
         step(kt, a_pre[0]);
         if (kt + 1 < n_tiles) step(kt + 1, a_pre[1]);
     }
-    gemm_epilogue16<RG>(p, acc, m0, n0, wave, ln, lg);
+#ifdef L3AC_SPLIT_STAMPS
+    const long long t_loop_end = SPLIT_STAMP();
+#endif
+    gemm_epilogue16<RG>(p, acc, m0, n0, wave, lane);
+#ifdef L3AC_SPLIT_STAMPS
+    if (lane == 0 && wave == 0 && blockIdx.x < 4096) {
+        long long* o = g_split_stamps + 8 * blockIdx.x;
+        o[0] = t_split, o[1] = t_mfma, o[2] = t_tail, o[3] = t_loop_end - t_begin, o[4] = SPLIT_STAMP() - t_loop_end, o[5] = n_tiles;
+    }
+#endif
 }
 
 // SHAPE: 16 = v_mfma_f32_16x16x32_bf16, 32 rows per wave (default); 32 = v_mfma_f32_32x32x16_bf16 (L3AC_SPLIT_MFMA=32);
@@ -391,6 +462,11 @@ std::atomic<int> g_split_enabled{-1};
 
 }  // namespace
 
+#ifdef L3AC_SPLIT_STAMPS
+extern "C" int l3ac_debug_split_stamps(long long* out, int n) {  // diagnostic builds only (not part of the ABI)
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_split_stamps), (size_t)n * sizeof(long long));
+}
+#endif
 bool gemm_split_enabled() {
     int v = g_split_enabled.load(std::memory_order_relaxed);
     if (v < 0) {
