@@ -446,14 +446,13 @@ __device__ __forceinline__ void gemm_split_body16(const GemmArgs& p, const int g
 #endif
 }
 
-// SHAPE: 16 = v_mfma_f32_16x16x32_bf16, 32 rows per wave (default); 32 = v_mfma_f32_32x32x16_bf16 (L3AC_SPLIT_MFMA=32);
-// 64 = 16x16x32 with 64 rows per wave, i.e. 256-row blocks at two per CU (L3AC_SPLIT_MFMA=64)
+// SHAPE: 16 = v_mfma_f32_16x16x32_bf16 (default); 32 = v_mfma_f32_32x32x16_bf16 (L3AC_SPLIT_MFMA=32).
+// (The 16x16x32 body is written for RG row groups of 16 per wave; RG = 4, i.e. 256-row blocks at two per CU, halves the LDS reads
+// and the W traffic per MFMA and was measured: +3 % on the K = 2048 shapes, -17 % on the K = 512 ones, whose epilogue it doubles.)
 template <bool KTAIL, int SHAPE>
-__global__ __launch_bounds__(THREADS, SHAPE == 64 ? 2 : 3) void gemm_split_kernel(const GemmArgs p, const int gp) {
+__global__ __launch_bounds__(THREADS, 3) void gemm_split_kernel(const GemmArgs p, const int gp) {
     if constexpr (SHAPE == 16)
         gemm_split_body16<KTAIL, 2>(p, gp);
-    else if constexpr (SHAPE == 64)
-        gemm_split_body16<KTAIL, 4>(p, gp);
     else
         gemm_split_body32<KTAIL>(p, gp);
 }
@@ -533,19 +532,12 @@ int launch_gemm_split(hipStream_t s, const GemmArgs& g) {
         return e ? std::atoi(e) : 0;
     }();
     const int gp = gp_env > 0 ? gp_env : 8;
-    static const int shape = [] {  // L3AC_SPLIT_MFMA=32: the 32x32x16 form; =64: 16x16x32 with 64 rows per wave (A/B runs)
+    static const bool shape32 = [] {  // L3AC_SPLIT_MFMA=32: the 32x32x16 form of the kernel (A/B runs)
         const char* e = std::getenv("L3AC_SPLIT_MFMA");
-        const int v = e ? std::atoi(e) : 16;
-        return v == 32 || v == 64 ? v : 16;
+        return e && std::atoi(e) == 32;
     }();
     const bool tail = g.k % BK != 0;
-    if (shape == 64) {
-        const int64_t blocks64 = ceil_div64(g.m, 2 * BM) * ceil_div64(g.n, BN);
-        if (tail)
-            hipLaunchKernelGGL((gemm_split_kernel<true, 64>), dim3((unsigned)blocks64), dim3(THREADS), 2 * W_TILE, s, g, gp);
-        else
-            hipLaunchKernelGGL((gemm_split_kernel<false, 64>), dim3((unsigned)blocks64), dim3(THREADS), 2 * W_TILE, s, g, gp);
-    } else if (shape == 32) {
+    if (shape32) {
         if (tail)
             hipLaunchKernelGGL((gemm_split_kernel<true, 32>), dim3((unsigned)blocks), dim3(THREADS), 2 * W_TILE, s, g, gp);
         else
