@@ -39,42 +39,50 @@ __device__ __forceinline__ float4 f4_fma(float4 a, float4 b, float4 c) {
     return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
 }
 
-template <int SRC, int NORM>
-__global__ __launch_bounds__(THREADS) void row_kernel(const RowArgs p, const int lpr) {
+// IDX: the integer type of row numbers and element offsets.  The launcher picks 32 bits whenever every tensor has fewer than 2^31
+// elements: with int64 the row / frames division and the address products are ~150 of the kernel's instructions per 16 bytes,
+// and the kernel ran at the speed of its integer arithmetic (3.2 TB/s), not of HBM.
+// LPR: the lane-group size as a compile-time constant for the sizes the network uses (0 = the run-time value): it folds the lane
+// decomposition and the group reductions' loops.
+// NCH: 16-byte chunks per lane (1 when c <= 4 lpr, else MAX_CH).
+template <int SRC, int NORM, class IDX, int LPR, int NCH>
+__global__ __launch_bounds__(THREADS) void row_kernel(const RowArgs p, const int lpr_rt) {
+    const int lpr = LPR ? LPR : lpr_rt;
     // lane groups never straddle a wave: 64 / lpr groups per wave, the remaining lanes (4 of 64 for lpr = 6 / 12) idle
     const int gpw = 64 / lpr;
     const int lane = threadIdx.x & 63;
     const int grp = lane / lpr;
     const int j = lane - grp * lpr;
-    const int64_t rows = p.batch * p.frames_out;
+    const IDX rows = (IDX)(p.batch * p.frames_out);
+    const IDX frames_out = (IDX)p.frames_out, frames_in = (IDX)p.frames_in, cc = (IDX)p.c;
     const int nchunk = p.c >> 2;
-    const int64_t wave_id = (int64_t)blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6);
-    const int64_t row_step = (int64_t)gridDim.x * (THREADS / 64) * gpw;
+    const IDX wave_id = (IDX)blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6);
+    const IDX row_step = (IDX)gridDim.x * (THREADS / 64) * gpw;
     // grid-stride over rows: a block handles many (a launch of one 96-B row per lane group is dispatch-bound); whole lane
     // groups enter and leave the loop together, so the group shuffles stay inside active lanes
-    for (int64_t row = grp < gpw ? wave_id * gpw + grp : rows; row < rows; row += row_step) {
+    for (IDX row = grp < gpw ? wave_id * gpw + grp : rows; row < rows; row += row_step) {
     const bool row_ok = true;
-    const int64_t b = row / p.frames_out;
-    const int64_t t = row % p.frames_out;
+    const IDX b = row / frames_out;
+    const IDX t = row - b * frames_out;
 
-    float4 v[MAX_CH];
-    bool ok[MAX_CH];
+    float4 v[NCH];
+    bool ok[NCH];
 #pragma unroll
-    for (int i = 0; i < MAX_CH; ++i) {
+    for (int i = 0; i < NCH; ++i) {
         const int chunk = j + i * lpr;
         ok[i] = row_ok && chunk < nchunk;
         v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (!ok[i]) continue;
         const int c0 = chunk << 2;
         if (SRC == SRC_PLAIN) {
-            v[i] = *reinterpret_cast<const float4*>(p.x + (b * p.frames_in + t) * p.c + c0);
+            v[i] = *reinterpret_cast<const float4*>(p.x + (size_t)((b * frames_in + t) * cc + (IDX)c0));
         } else if (SRC == SRC_DWCONV7) {
             float4 acc = *reinterpret_cast<const float4*>(p.dw_b + c0);
 #pragma unroll
             for (int tap = 0; tap < 7; ++tap) {
-                const int64_t ts = t + tap - 3;
+                const int64_t ts = (int64_t)t + tap - 3;
                 if (ts >= 0 && ts < p.frames_in) {
-                    const float4 xv = *reinterpret_cast<const float4*>(p.x + (b * p.frames_in + ts) * p.c + c0);
+                    const float4 xv = *reinterpret_cast<const float4*>(p.x + (size_t)((b * frames_in + (IDX)ts) * cc + (IDX)c0));
                     const float4 wv = *reinterpret_cast<const float4*>(p.dw_w + tap * p.c + c0);
                     acc = f4_fma(xv, wv, acc);
                 }
@@ -85,28 +93,28 @@ __global__ __launch_bounds__(THREADS) void row_kernel(const RowArgs p, const int
             const float rscale = (float)(1.0 / (double)p.scale);
             float src = __fsub_rn(__fmul_rn(rscale, (float)t + 0.5f), 0.5f);
             src = src < 0.f ? 0.f : src;
-            const int64_t i0 = (int64_t)src;
-            const int64_t i1 = i0 + (i0 < p.frames_in - 1 ? 1 : 0);
+            const IDX i0 = (IDX)src;
+            const IDX i1 = i0 + (i0 + 1 < frames_in ? 1 : 0);
             float l1 = src - (float)i0;
             l1 = fminf(fmaxf(l1, 0.f), 1.f);
             const float l0 = 1.f - l1;
-            const float4 x0 = *reinterpret_cast<const float4*>(p.x + (b * p.frames_in + i0) * p.c + c0);
-            const float4 x1 = *reinterpret_cast<const float4*>(p.x + (b * p.frames_in + i1) * p.c + c0);
+            const float4 x0 = *reinterpret_cast<const float4*>(p.x + (size_t)((b * frames_in + i0) * cc + (IDX)c0));
+            const float4 x1 = *reinterpret_cast<const float4*>(p.x + (size_t)((b * frames_in + i1) * cc + (IDX)c0));
             v[i] = make_float4(__fadd_rn(__fmul_rn(l0, x0.x), __fmul_rn(l1, x1.x)),
                                __fadd_rn(__fmul_rn(l0, x0.y), __fmul_rn(l1, x1.y)),
                                __fadd_rn(__fmul_rn(l0, x0.z), __fmul_rn(l1, x1.z)),
                                __fadd_rn(__fmul_rn(l0, x0.w), __fmul_rn(l1, x1.w)));
         } else {  // SRC_GATE
-            const float4 yraw = *reinterpret_cast<const float4*>(p.yi + (b * p.frames_in + t) * 4);
-            const float4 mean = *reinterpret_cast<const float4*>(p.stats + b * 8);
-            const float4 istd = *reinterpret_cast<const float4*>(p.stats + b * 8 + 4);
+            const float4 yraw = *reinterpret_cast<const float4*>(p.yi + (size_t)((b * frames_in + t) * 4));
+            const float4 mean = *reinterpret_cast<const float4*>(p.stats + (size_t)(b * 8));
+            const float4 istd = *reinterpret_cast<const float4*>(p.stats + (size_t)(b * 8 + 4));
             const float4 iw = *reinterpret_cast<const float4*>(p.in_w);
             const float4 ib = *reinterpret_cast<const float4*>(p.in_b);
             const float y0 = (yraw.x - mean.x) * istd.x * iw.x + ib.x;
             const float y1 = (yraw.y - mean.y) * istd.y * iw.y + ib.y;
             const float y2 = (yraw.z - mean.z) * istd.z * iw.z + ib.z;
             const float y3 = (yraw.w - mean.w) * istd.w * iw.w + ib.w;
-            const float4 xv = *reinterpret_cast<const float4*>(p.x + (b * p.frames_in + t) * p.c + c0);
+            const float4 xv = *reinterpret_cast<const float4*>(p.x + (size_t)((b * frames_in + t) * cc + (IDX)c0));
             const float4 gb = *reinterpret_cast<const float4*>(p.gate_b + c0);
             const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
             const float gbs[4] = {gb.x, gb.y, gb.z, gb.w};
@@ -124,11 +132,11 @@ __global__ __launch_bounds__(THREADS) void row_kernel(const RowArgs p, const int
     if (NORM != NORM_NONE) {
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAX_CH; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);  // masked chunks hold zeros
+        for (int i = 0; i < NCH; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);  // masked chunks hold zeros
         const float mean = group_sum(s, lpr, j) / (float)p.c;
         float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAX_CH; ++i) {
+        for (int i = 0; i < NCH; ++i) {
             if (ok[i]) {
                 const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
                 q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
@@ -139,7 +147,7 @@ __global__ __launch_bounds__(THREADS) void row_kernel(const RowArgs p, const int
         // per row + a multiply per element differs from the per-element division by at most ~1 ulp
         const float rstd = 1.0f / sqrtf(var + p.eps);
 #pragma unroll
-        for (int i = 0; i < MAX_CH; ++i) {
+        for (int i = 0; i < NCH; ++i) {
             if (!ok[i]) continue;
             const int c0 = (j + i * lpr) << 2;
             const float4 w = *reinterpret_cast<const float4*>(p.nw + c0);
@@ -154,8 +162,8 @@ __global__ __launch_bounds__(THREADS) void row_kernel(const RowArgs p, const int
         }
     }
 #pragma unroll
-    for (int i = 0; i < MAX_CH; ++i) {
-        if (ok[i]) *reinterpret_cast<float4*>(p.y + row * p.c + ((j + i * lpr) << 2)) = v[i];
+    for (int i = 0; i < NCH; ++i) {
+        if (ok[i]) *reinterpret_cast<float4*>(p.y + (size_t)(row * cc + (IDX)((j + i * lpr) << 2))) = v[i];
     }
     }  // row loop
 }
@@ -280,7 +288,27 @@ int launch_rows_t(hipStream_t s, const RowArgs& r, int lpr) {
     const double in_elems = (double)r.batch * r.frames_in * r.c, out_elems = (double)rows * r.c;
     ProfScope prof(s, names[SRC][NORM], (SRC == SRC_DWCONV7 ? 14.0 : 2.0) * out_elems + (NORM != NORM_NONE ? 8.0 * out_elems : 0.0),
                    4.0 * (in_elems + out_elems));
-    hipLaunchKernelGGL((row_kernel<SRC, NORM>), dim3((unsigned)blocks), dim3(THREADS), 0, s, r, lpr);
+    const bool small = (double)r.batch * r.frames_in * r.c < 2147483648.0 && out_elems < 2147483648.0 && rows + blocks * 256 < ((int64_t)1 << 31);
+#define L3AC_ROWS_LAUNCH(IDX_, LPR_)                                                                                             \
+    do {                                                                                                                         \
+        if (r.c <= 4 * lpr)                                                                                                      \
+            hipLaunchKernelGGL((row_kernel<SRC, NORM, IDX_, LPR_, 1>), dim3((unsigned)blocks), dim3(THREADS), 0, s, r, lpr);     \
+        else                                                                                                                     \
+            hipLaunchKernelGGL((row_kernel<SRC, NORM, IDX_, LPR_, MAX_CH>), dim3((unsigned)blocks), dim3(THREADS), 0, s, r, lpr); \
+    } while (0)
+    if (!small) {
+        L3AC_ROWS_LAUNCH(int64_t, 0);
+    } else {
+        switch (lpr) {
+            case 6: L3AC_ROWS_LAUNCH(unsigned, 6); break;     // 24 channels
+            case 12: L3AC_ROWS_LAUNCH(unsigned, 12); break;   // 48 / 96
+            case 32: L3AC_ROWS_LAUNCH(unsigned, 32); break;   // 128
+            case 48: L3AC_ROWS_LAUNCH(unsigned, 48); break;   // 192
+            case 64: L3AC_ROWS_LAUNCH(unsigned, 64); break;   // 256 / 512
+            default: L3AC_ROWS_LAUNCH(unsigned, 0); break;
+        }
+    }
+#undef L3AC_ROWS_LAUNCH
     L3AC_LAUNCH_CHECK();
     return L3AC_OK;
 }
