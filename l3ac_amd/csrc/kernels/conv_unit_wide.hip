@@ -599,12 +599,13 @@ __global__ __launch_bounds__(256) void dwconv_ln_split_kernel(const ConvUnitW w,
     float4 dww[7];
 #pragma unroll
     for (int tap = 0; tap < 7; ++tap) dww[tap] = *reinterpret_cast<const float4*>(w.dw_w + tap * C + 4 * q);
+    const int t_tile = (int)((tile * 32) % frames);  // one 64-bit modulo per thread, not one per frame (~100 instructions each)
 #pragma unroll 2
     for (int i = 0; i < 8; ++i) {
         const int lj = 8 * wv + i;
         const int64_t row = tile * 32 + lj;
         const bool ok = row < rows && lane_ok;
-        const int t = row < rows ? (int)(row % frames) : 0;
+        const int t = row < rows ? (int)((unsigned)(t_tile + lj) % (unsigned)frames) : 0;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (ok) {
             acc = dwb;
