@@ -600,19 +600,33 @@ __global__ __launch_bounds__(256) void dwconv_ln_split_kernel(const ConvUnitW w,
 #pragma unroll
     for (int tap = 0; tap < 7; ++tap) dww[tap] = *reinterpret_cast<const float4*>(w.dw_w + tap * C + 4 * q);
     const int t_tile = (int)((tile * 32) % frames);  // one 64-bit modulo per thread, not one per frame (~100 instructions each)
-#pragma unroll 2
+    // A wave's 8 frames are consecutive, so their 7-row windows overlap: a rolling register window loads each input row once
+    // (14 loads for 8 frames instead of 56).  A row belongs to the frame's clip iff its time index stays inside [0, frames).
+    const int lj0 = 8 * wv;
+    auto load_row = [&](int d) -> float4 {  // input row (first frame of the wave) + d, zero outside that row's clip or the tensor
+        const int64_t r = tile * 32 + lj0 + d;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane_ok && r >= 0 && r < rows) v = *reinterpret_cast<const float4*>(x + r * C + 4 * q);
+        return v;
+    };
+    float4 win[7];  // win[(k + 4) % 7] = row k - 3 ... the slot of input row d is (d + 7) % 7
+#pragma unroll
+    for (int d = -3; d <= 2; ++d) win[(d + 7) % 7] = load_row(d);
+#pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int lj = 8 * wv + i;
+        const int lj = lj0 + i;
         const int64_t row = tile * 32 + lj;
         const bool ok = row < rows && lane_ok;
         const int t = row < rows ? (int)((unsigned)(t_tile + lj) % (unsigned)frames) : 0;
+        win[(i + 3) % 7] = load_row(i + 3);  // overwrites row i - 4
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (ok) {
             acc = dwb;
 #pragma unroll
             for (int tap = 0; tap < 7; ++tap) {
-                float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (t + tap - 3 >= 0 && t + tap - 3 < frames) xv = *reinterpret_cast<const float4*>(x + (row + tap - 3) * C + 4 * q);
+                // rows of a neighbouring clip (t + tap - 3 outside [0, frames)) are the conv's zero padding
+                const bool in_clip = t + tap - 3 >= 0 && t + tap - 3 < frames;
+                const float4 xv = in_clip ? win[(i + tap - 3 + 7) % 7] : make_float4(0.f, 0.f, 0.f, 0.f);
                 acc.x = fmaf(xv.x, dww[tap].x, acc.x);
                 acc.y = fmaf(xv.y, dww[tap].y, acc.y);
                 acc.z = fmaf(xv.z, dww[tap].z, acc.z);
