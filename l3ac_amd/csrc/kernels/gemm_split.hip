@@ -346,9 +346,11 @@ __device__ __forceinline__ void gemm_split_body16(const GemmArgs& p, const int g
 #pragma unroll
         for (int i = 0; i < W_LOADS; ++i) *reinterpret_cast<u32x4*>(base + 16 * THREADS * i) = w_reg[i];
     };
+    // planes read in the order 2, 1, 0: the first MFMA of a column tile takes plane 0 of the weights, the YOUNGEST read, so the one
+    // s_waitcnt in front of it covers all three (LDS returns in order) instead of one wait per plane
     auto read_b = [&](const unsigned char* ws, int t, bf16x8 (&b)[3]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) b[pl] = *reinterpret_cast<const bf16x8*>(ws + pl * W_PLANE + tile_off(16 * t + ln, lg));
+        for (int pl = 2; pl >= 0; --pl) b[pl] = *reinterpret_cast<const bf16x8*>(ws + pl * W_PLANE + tile_off(16 * t + ln, lg));
     };
 
     f32x4a acc[RG][8];

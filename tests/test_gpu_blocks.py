@@ -203,6 +203,15 @@ def test_conv_units_wide_fused(full):
         ref = O.conv_unit(w, block, x)
         got = G.op_block(codec.network.context(), "l3ac_op_conv_unit", block, G.to_frames(x), (b, t, c))
         _close(f"{block} B={b} T={t}", G.from_frames(got), ref, atol=5e-5, rtol=5e-5)
+    # C = 128 (no shipped model has such a stage; the reference's default geometry does): 2 ring slots per product
+    codec128 = l3ac_amd.get_model(GOLDEN / "refdefault.toml", synthetic_seed=5)
+    codec128.network.to(device="cuda").eval()
+    w128 = W.folded_weights(codec128.network.state_dicts())
+    for block, b, t in (("decoder.blocks.4.0.module", 3, 1000), ("decoder.blocks.4.1.module", 40, 1000), ("decoder.blocks.4.1.module", 2, 31)):
+        x = _rand((b, 128, t), 300 + t)
+        ref = O.conv_unit(w128, block, x)
+        got = G.op_block(codec128.network.context(), "l3ac_op_conv_unit", block, G.to_frames(x), (b, t, 128))
+        _close(f"refdefault {block} B={b} T={t}", G.from_frames(got), ref, atol=5e-5, rtol=5e-5)
     # the same unit through the unfused route (dwconv+LN, two split GEMMs): the fused kernel may not be the less accurate one
     x = _rand((4, 256, 450), 999)
     block = "decoder.blocks.4.1.module"

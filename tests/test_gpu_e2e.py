@@ -18,7 +18,7 @@ FEAT_ATOL = 5e-4  # encoder / transformer feature tolerance, activations O(1)
 
 
 def _codec(tag, seed):
-    cfg = GOLDEN / "tiny.toml" if tag == "tiny" else tag
+    cfg = GOLDEN / f"{tag}.toml" if tag in ("tiny", "refdefault") else tag  # refdefault: the reference ModelConfig's default geometry
     codec = l3ac_amd.get_model(cfg, synthetic_seed=seed)
     codec.network.to(device="cuda").eval()
     return codec
@@ -31,7 +31,7 @@ def _err(name, got, ref):
 
 
 @pytest.mark.parametrize("tag,seed,batch,samples", [("tiny", 3, 3, 250), ("tiny", 3, 2, 1201), ("1kbps", 0, 2, 16000),
-                                                    ("3kbps", 0, 2, 16000), ("1kbps", 0, 1, 5000)])
+                                                    ("3kbps", 0, 2, 16000), ("1kbps", 0, 1, 5000), ("refdefault", 5, 2, 9000)])
 def test_submodules_against_oracle(tag, seed, batch, samples):
     codec = _codec(tag, seed)
     ctx = codec.network.context()
@@ -64,7 +64,9 @@ def test_submodules_against_oracle(tag, seed, batch, samples):
                                                     ("1k5bps", 1, 2, 8000),
                                                     # ragged sizes: one sample, one short of / one past a hop, a tile-unfriendly length
                                                     ("1kbps", 0, 1, 1), ("1kbps", 0, 2, 269), ("1kbps", 0, 1, 271), ("1kbps", 0, 5, 8191),
-                                                    ("3kbps", 0, 1, 97)])
+                                                    ("3kbps", 0, 1, 97),
+                                                    # the reference's default geometry: 128-channel fused stage, 64 / 32-channel units
+                                                    ("refdefault", 5, 3, 9000), ("refdefault", 5, 1, 46)])
 def test_encode_decode_against_oracle(tag, seed, batch, samples):
     codec = _codec(tag, seed)
     mc = codec.network.mc
