@@ -211,21 +211,41 @@ __global__ __launch_bounds__(64 * WAVES, 4) void legacy_unit_kernel(const Legacy
 //     image uses the accumulator's row order (split_sigma);
 //   * weight images hold only the C real rows: lanes of the padding rows read row C-1 (finite values whose products meet
 //     zero weights or are never stored).
-// MFMA cycles per 32 frames: (ceil(7C/16) + 2) * 6 * 32 vs (7C/2 + 16) * 64 for the fp32 kernel (C = 24: 2.5k vs 6.4k).
+// MFMA shape: v_mfma_f32_16x16x32_bf16 (DESIGN.md 3.1 'MFMA shape'; a timing-only substitution ran this kernel 18 % faster): a wave's 32
+// frames are two frame halves, the 32 (padded) hidden / output rows two 16-row tiles (the second holds C - 16 real rows); a k step
+// of the dilated conv is 4 groups of 8 channels, lane (n = lane & 15, kg = lane >> 4) taking group 4 s + kg.
+// MFMA cycles per 32 frames: (ceil(7C/32) * 2 NHH + NHH) * 2 * 6 * 16 vs (7C/2 + 16) * 64 for the fp32 kernel (C = 24: 2.7k vs 6.4k).
 template <int C>
 struct LSGeo {
     static constexpr int NG = C / 8;                // 8-channel groups per tap
     static constexpr int NGT = 7 * NG;              // groups in all
-    static constexpr int NS1 = (NGT + 1) / 2;       // k steps (16) of the dilated conv
-    static constexpr int NS2 = (C + 15) / 16;       // k steps of the 1x1 conv (hidden rows >= C are padding)
+    static constexpr int NS1 = (NGT + 3) / 4;       // k steps (32) of the dilated conv
+    static constexpr int NHH = (C + 15) / 16;       // 16-row tiles of hidden / output channels
+    static constexpr int rows_of(int hh) { return C - 16 * hh < 16 ? C - 16 * hh : 16; }  // real rows of tile hh
+    static constexpr int blk(int hh) { return 4 * rows_of(hh) * 16; }                       // bytes of one (tile, plane) fragment block
+    static constexpr int STEP_BYTES = 3 * (blk(0) + (NHH > 1 ? blk(1) : 0));               // all tiles and planes of one k step
+    static constexpr int off_of(int hh, int p) { return (hh == 0 ? 0 : 3 * blk(0)) + p * blk(hh); }
     static constexpr int PS = 2 * C + ((2 * C) % 32 == 16 ? 0 : 16);  // S plane row stride in bytes
-    static constexpr int W1_BYTES = NS1 * 3 * 2 * C * 16;
-    static constexpr int W2_BYTES = 2 * 3 * 2 * C * 16;
+    static constexpr int W1_BYTES = NS1 * STEP_BYTES;
+    static constexpr int W2_BYTES = STEP_BYTES;
     static constexpr int OFF_W2 = W1_BYTES;
     static constexpr int OFF_P = OFF_W2 + W2_BYTES;  // 32 x (alpha1, 1/alpha1, b1, b2)
     static constexpr int OFF_S = OFF_P + 512;
     static constexpr int lds_bytes(int dil) { return OFF_S + 3 * (FRAMES + 6 * dil) * PS; }
+    static_assert(C % 8 == 0 && C <= 32 && W1_BYTES % 16 == 0, "geometry");
 };
+
+typedef float f32x4_l __attribute__((ext_vector_type(4)));
+// acc += a . b over one k step of 32, operands as their three planes, the six plane products in mfma_split's order
+__device__ __forceinline__ f32x4_l mfma_split16(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4_l acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
+    return acc;
+}
 
 template <int C>
 __global__ __launch_bounds__(64 * WAVES, 4) void legacy_unit_split_kernel(const LegacyW w, const float* __restrict__ x,
@@ -277,11 +297,13 @@ __global__ __launch_bounds__(64 * WAVES, 4) void legacy_unit_split_kernel(const 
         *reinterpret_cast<float4*>(Ps + 4 * tid) =
             make_float4(ok ? w.a1[tid] : 1.f, ok ? w.ia1[tid] : 0.f, ok ? w.b1[tid] : 0.f, ok ? w.b2[tid] : 0.f);
     }
-    const int lj = lane & 31;
-    const int lh = lane >> 5;
+    const int ln = lane & 15;  // frame within a 16-frame half (B operand / accumulator column) or weight row within a 16-row tile
+    const int lg = lane >> 4;  // k group of a fragment; rows 4 lg .. 4 lg + 3 of an accumulator tile
     const int m0 = 32 * wave;
-    const int rc = lj < C ? lj : C - 1;           // weight-image row of this lane
-    const int wlane = (lh * C + rc) * 16;         // + (step * 3 + plane) * 2 * C * 16
+    // per-lane offset inside a (tile hh, plane) weight block: lanes of the padding rows read the tile's last real row
+    int wl[G::NHH];
+#pragma unroll
+    for (int hh = 0; hh < G::NHH; ++hh) wl[hh] = (lg * G::rows_of(hh) + (ln < G::rows_of(hh) ? ln : G::rows_of(hh) - 1)) * 16;
     const int dps = dil * G::PS;
 
     for (; tile < total_tiles; tile += gridDim.x) {
@@ -310,68 +332,108 @@ __global__ __launch_bounds__(64 * WAVES, 4) void legacy_unit_split_kernel(const 
 
         int woff = 0;  // opaque per tile: keeps the (tile-invariant) weight fragments in LDS instead of ~100 hoisted VGPRs
         asm volatile("" : "+s"(woff));
-        int lhv = lh;  // likewise opaque: the per-step S offsets (a select on the lane half) are recomputed, not hoisted and spilled
-        asm volatile("" : "+v"(lhv));
-        const unsigned char* W1t = W1b + woff + wlane;
-        const unsigned char* W2t = W2b + woff + wlane;
+        int lgv = lg;  // likewise opaque: the per-step S offsets (selects on the k group) are recomputed, not hoisted and spilled
+        asm volatile("" : "+v"(lgv));
+        const unsigned char* W1t = W1b + woff;
+        const unsigned char* W2t = W2b + woff;
         const float* Pt = Ps + woff;
         if (t0 + m0 < frames) {  // wave-uniform: a wave wholly beyond the clip only takes part in the barriers
             // ---- X^T[n][m] = b1[n] + sum_{tap,c} W1[n][tap][c] S[m + (tap - 3) dil][c] -------------------------
-            f32x16_t xacc;
+            // xt[hh][fh][i] = hidden row 16 hh + 4 lg + i at frame 16 fh + ln
+            f32x4_l xt[G::NHH][2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) xacc[r] = Pt[4 * rowmap(r, lh) + 2];
-            const unsigned char* sl = Sb + (m0 + lj) * G::PS;
+            for (int hh = 0; hh < G::NHH; ++hh) {
+                f32x4_l bv;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bv[i] = Pt[4 * (16 * hh + 4 * lg + i) + 2];
+                xt[hh][0] = bv;
+                xt[hh][1] = bv;
+            }
+            const unsigned char* sl0 = Sb + (m0 + ln) * G::PS;
 #pragma unroll
             for (int s = 0; s < G::NS1; ++s) {
-                const int g0 = 2 * s, g1 = 2 * s + 1 < G::NGT ? 2 * s + 1 : 0;  // the padding half re-reads group 0 (zero weights)
-                const int o0 = (g0 / G::NG) * dps + (g0 % G::NG) * 16;
-                const int o1 = (g1 / G::NG) * dps + (g1 % G::NG) * 16;
-                const unsigned char* sp = sl + (lhv ? o1 : o0);
-                bf16x8 sf[3], wf[3];
+                // group 4 s + kg of lane group kg: tap g / NG, channel group g % NG (groups past the end re-read group 0: zero weights)
+                int off = 0;
+#pragma unroll
+                for (int kg = 0; kg < 4; ++kg) {
+                    const int g = 4 * s + kg < G::NGT ? 4 * s + kg : 0;
+                    const int o = (g / G::NG) * dps + (g % G::NG) * 16;
+                    off = lgv == kg ? o : off;
+                }
+                bf16x8 sf[2][3], wf[G::NHH][3];
 #pragma unroll
                 for (int p = 0; p < 3; ++p) {
-                    sf[p] = *reinterpret_cast<const bf16x8*>(sp + p * splane);
-                    wf[p] = *reinterpret_cast<const bf16x8*>(W1t + (s * 3 + p) * 2 * C * 16);
-                }
-                xacc = mfma_split(wf, sf, xacc);
-            }
-            // ---- snake on the accumulator, split it, then Y^T[c][m] = b2[c] + sum_n W2[c][n] X^T[n][m] -----------
-            f32x16_t yacc;
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const float4 p0 = *reinterpret_cast<const float4*>(Pt + 4 * rowmap(r, lh));
-                const float4 p1 = *reinterpret_cast<const float4*>(Pt + 4 * rowmap(r + 1, lh));
-                f32x2 hv, al2, ia2;
-                hv.x = xacc[r]; hv.y = xacc[r + 1];
-                al2.x = p0.x; al2.y = p1.x;
-                ia2.x = p0.y; ia2.y = p1.y;
-                const f32x2 sv = snake_act2(hv, al2, ia2);  // padding rows (copies of row C-1) stay finite
-                xacc[r] = sv.x;
-                xacc[r + 1] = sv.y;
-                yacc[r] = p0.w;
-                yacc[r + 1] = p1.w;
+                    for (int fh = 0; fh < 2; ++fh) sf[fh][p] = *reinterpret_cast<const bf16x8*>(sl0 + fh * 16 * G::PS + off + p * splane);
+#pragma unroll
+                    for (int hh = 0; hh < G::NHH; ++hh)
+                        wf[hh][p] = *reinterpret_cast<const bf16x8*>(W1t + s * G::STEP_BYTES + G::off_of(hh, p) + wl[hh]);
+                }
+#pragma unroll
+                for (int hh = 0; hh < G::NHH; ++hh)
+#pragma unroll
+                    for (int fh = 0; fh < 2; ++fh) xt[hh][fh] = mfma_split16(wf[hh], sf[fh], xt[hh][fh]);
+            }
+            // ---- snake on the accumulators, split them, then Y^T[c][m] = b2[c] + sum_n W2[c][n] X^T[n][m] -----------
+            // the B operand of frame half fh: word 2 hh + ip = hidden rows 16 hh + 4 lg + 2 ip, + 1 (k order sigma(lg, j) = j < 4 ?
+            // 4 lg + j : 16 + 4 lg + j - 4, which the W2 image is built in); a missing second tile contributes zeros
+            unsigned xw[2][3][4];
+            f32x4_l yt[G::NHH][2];
+#pragma unroll
+            for (int fh = 0; fh < 2; ++fh)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) xw[fh][p][k] = 0u;
+#pragma unroll
+            for (int hh = 0; hh < G::NHH; ++hh) {
+#pragma unroll
+                for (int ip = 0; ip < 2; ++ip) {
+                    const float4 p0 = *reinterpret_cast<const float4*>(Pt + 4 * (16 * hh + 4 * lg + 2 * ip));
+                    const float4 p1 = *reinterpret_cast<const float4*>(Pt + 4 * (16 * hh + 4 * lg + 2 * ip + 1));
+                    f32x2 al2, ia2;
+                    al2.x = p0.x; al2.y = p1.x;
+                    ia2.x = p0.y; ia2.y = p1.y;
+#pragma unroll
+                    for (int fh = 0; fh < 2; ++fh) {
+                        f32x2 hv;
+                        hv.x = xt[hh][fh][2 * ip]; hv.y = xt[hh][fh][2 * ip + 1];
+                        const f32x2 sv = snake_act2(hv, al2, ia2);  // padding rows (copies of the last real row) stay finite
+                        split2(sv.x, sv.y, xw[fh][0][2 * hh + ip], xw[fh][1][2 * hh + ip], xw[fh][2][2 * hh + ip]);
+                        yt[hh][fh][2 * ip] = p0.w;
+                        yt[hh][fh][2 * ip + 1] = p1.w;
+                    }
+                }
             }
             bf16x8 xb[2][3];
-            split_acc_tile(xacc, xb);
 #pragma unroll
-            for (int s = 0; s < G::NS2; ++s) {
+            for (int fh = 0; fh < 2; ++fh)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    xb[fh][p] = __builtin_bit_cast(bf16x8, u32x4{xw[fh][p][0], xw[fh][p][1], xw[fh][p][2], xw[fh][p][3]});
+#pragma unroll
+            for (int rt = 0; rt < G::NHH; ++rt) {
                 bf16x8 wf[3];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) wf[p] = *reinterpret_cast<const bf16x8*>(W2t + (s * 3 + p) * 2 * C * 16);
-                yacc = mfma_split(wf, xb[s], yacc);
-            }
-            // ---- residual + store: lane (frame lj, half lh) owns channels 8 g + 4 lh + {0..3} ---------------
-            const int t = t0 + m0 + lj;
-            if (t < frames) {
-                const float* src = clip + (int64_t)t * C;
-                float* dst = y + ((int64_t)b * frames + t) * C;
+                for (int p = 0; p < 3; ++p) wf[p] = *reinterpret_cast<const bf16x8*>(W2t + G::off_of(rt, p) + wl[rt]);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int c0 = 8 * g + 4 * lh;
-                    if (c0 < C) {
-                        const float4 xr = *reinterpret_cast<const float4*>(src + c0);
-                        *reinterpret_cast<float4*>(dst + c0) = make_float4(xr.x + yacc[4 * g], xr.y + yacc[4 * g + 1],
-                                                                           xr.z + yacc[4 * g + 2], xr.w + yacc[4 * g + 3]);
+                for (int fh = 0; fh < 2; ++fh) yt[rt][fh] = mfma_split16(wf, xb[fh], yt[rt][fh]);
+            }
+            // ---- residual + store: lane (frame 16 fh + ln, row group lg) owns channels 16 rt + 4 lg + {0..3} ---------------
+#pragma unroll
+            for (int fh = 0; fh < 2; ++fh) {
+                const int t = t0 + m0 + 16 * fh + ln;
+                if (t < frames) {
+                    const float* src = clip + (int64_t)t * C;
+                    float* dst = y + ((int64_t)b * frames + t) * C;
+#pragma unroll
+                    for (int rt = 0; rt < G::NHH; ++rt) {
+                        const int c0 = 16 * rt + 4 * lg;
+                        if (c0 < C) {
+                            const float4 xr = *reinterpret_cast<const float4*>(src + c0);
+                            *reinterpret_cast<float4*>(dst + c0) = make_float4(xr.x + yt[rt][fh][0], xr.y + yt[rt][fh][1],
+                                                                               xr.z + yt[rt][fh][2], xr.w + yt[rt][fh][3]);
+                        }
                     }
                 }
             }
@@ -492,38 +554,58 @@ int launch_head_fused(hipStream_t s, const HeadW& w, const float* x, int batch, 
     }
 }
 
-// ---- host builders of the bf16x3 weight images (layouts: legacy_unit_split_kernel) ---------------------------------------
+// ---- host builders of the bf16x3 weight images (layouts: legacy_unit_split_kernel, LSGeo) -----------------------------
+// Fragment blocks of v_mfma_f32_16x16x32_bf16's A operand: per k step, 16-row tile hh and plane p one block of 4 k groups x rows(hh)
+// real rows x 16 B; lane (m, kg) reads (kg * rows + min(m, rows - 1)) * 16.
+namespace {
+struct LegacyImgGeo {
+    int c, nhh, rows[2], blk[2], step_bytes;
+    explicit LegacyImgGeo(int c_) : c(c_), nhh((c_ + 15) / 16) {
+        rows[0] = c < 16 ? c : 16;
+        rows[1] = c > 16 ? c - 16 : 0;
+        blk[0] = 4 * rows[0] * 16;
+        blk[1] = 4 * rows[1] * 16;
+        step_bytes = 3 * (blk[0] + blk[1]);
+    }
+    size_t at(int step, int hh, int p, int kg, int m, int j) const {
+        return (size_t)step * step_bytes + (hh == 0 ? 0 : 3 * blk[0]) + (size_t)p * blk[hh] + (size_t)(kg * rows[hh] + m) * 16 + 2 * j;
+    }
+};
+}  // namespace
+
+// W1 [C][7][C] (row r, tap, channel): k step s, k group kg = 8-channel group g = 4 s + kg = (tap g / NG, channels 8 (g % NG) ..)
 std::vector<unsigned char> legacy_w1_image(const float* w1, int c) {
-    const int ng = c / 8, ngt = 7 * ng, ns1 = (ngt + 1) / 2;
-    std::vector<unsigned char> img((size_t)ns1 * 3 * 2 * c * 16, 0);
+    const LegacyImgGeo geo(c);
+    const int ng = c / 8, ngt = 7 * ng, ns1 = (ngt + 3) / 4;
+    std::vector<unsigned char> img((size_t)ns1 * geo.step_bytes, 0);
     for (int s = 0; s < ns1; ++s)
-        for (int h = 0; h < 2; ++h) {
-            const int g = 2 * s + h;
-            if (g >= ngt) continue;  // zero padding of the last half step
+        for (int kg = 0; kg < 4; ++kg) {
+            const int g = 4 * s + kg;
+            if (g >= ngt) continue;  // zero padding of the last step
             const int tap = g / ng, cg = g % ng;
             for (int r = 0; r < c; ++r)
                 for (int j = 0; j < 8; ++j) {
                     uint16_t pl[3];
                     split3_host(w1[(size_t)r * 7 * c + (size_t)tap * c + 8 * cg + j], pl);
-                    for (int p = 0; p < 3; ++p)
-                        std::memcpy(img.data() + ((((size_t)s * 3 + p) * 2 + h) * c + r) * 16 + 2 * j, &pl[p], 2);
+                    for (int p = 0; p < 3; ++p) std::memcpy(img.data() + geo.at(s, r / 16, p, kg, r % 16, j), &pl[p], 2);
                 }
         }
     return img;
 }
 
+// W2 [C][C] (output row r, hidden n): one k step of 32 hidden rows in the order sigma(kg, j) = j < 4 ? 4 kg + j : 16 + 4 kg + j - 4
 std::vector<unsigned char> legacy_w2_image(const float* w2, int c) {
-    std::vector<unsigned char> img((size_t)2 * 3 * 2 * c * 16, 0);
-    for (int s = 0; s < 2; ++s)
-        for (int h = 0; h < 2; ++h)
-            for (int r = 0; r < c; ++r)
-                for (int j = 0; j < 8; ++j) {
-                    const int n = split_sigma(s, h, j);  // hidden channel this fragment element multiplies
-                    if (n >= c) continue;
-                    uint16_t pl[3];
-                    split3_host(w2[(size_t)r * c + n], pl);
-                    for (int p = 0; p < 3; ++p)
-                        std::memcpy(img.data() + ((((size_t)s * 3 + p) * 2 + h) * c + r) * 16 + 2 * j, &pl[p], 2);
-                }
+    const LegacyImgGeo geo(c);
+    std::vector<unsigned char> img((size_t)geo.step_bytes, 0);
+    for (int kg = 0; kg < 4; ++kg)
+        for (int j = 0; j < 8; ++j) {
+            const int n = j < 4 ? 4 * kg + j : 16 + 4 * kg + j - 4;  // hidden channel this fragment element multiplies
+            if (n >= c) continue;
+            for (int r = 0; r < c; ++r) {
+                uint16_t pl[3];
+                split3_host(w2[(size_t)r * c + n], pl);
+                for (int p = 0; p < 3; ++p) std::memcpy(img.data() + geo.at(0, r / 16, p, kg, r % 16, j), &pl[p], 2);
+            }
+        }
     return img;
 }
