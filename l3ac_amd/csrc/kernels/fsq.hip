@@ -231,20 +231,27 @@ __global__ __launch_bounds__(256) void vq_scan_kernel(const float* __restrict__ 
     const int c_begin = blockIdx.y * k_per_part;
     const int c_end = min(k, c_begin + k_per_part);
     const float* __restrict__ cb = codebook + (int64_t)c_begin * D;  // wave-uniform: scalar loads
-    // (measured and dropped: comparing only the minimum of a block of 4 codes with the running minimum and redoing the ordered
-    // update on a wave-uniform branch — 6.1 ms instead of 3.3 ms at K = 250 047, N = 42 752: with 128 queries per wave some lane
-    // improves in most blocks, and the branch splits the loop body)
-    auto visit = [&](const float (&cc)[D], int c) __attribute__((always_inline)) {
+    // The running state per query is (best distance, first code of the BLOCK that brought it): a block of CB codes costs its
+    // arithmetic, CB - 1 minimum instructions (v_min3 / v_min) and ONE compare + two selects, instead of a compare + two selects per
+    // code.  Strict '<' between blocks keeps the first block that reaches the final minimum; which of its codes it was is found
+    // afterwards by re-evaluating that one block (same instructions, hence the same bits) and taking the first code whose distance
+    // equals the minimum — the lowest index wins exact ties exactly as in the code-by-code scan.  (An earlier variant redid the
+    // ordered update inside the loop on a wave-uniform branch: 6.1 instead of 3.3 ms, some lane improves in most blocks.)
+    auto dist_of = [&](const float (&cc)[D], int j) __attribute__((always_inline)) -> float {
+        float t = q[j][0] - cc[0];
+        float dist = t * t;
+#pragma unroll
+        for (int d = 1; d < D; ++d) {
+            t = q[j][d] - cc[d];
+            dist = fmaf(t, t, dist);
+        }
+        return dist;
+    };
+    auto visit = [&](const float (&cc)[D], int c) __attribute__((always_inline)) {  // a block of one code (the slice's remainder)
 #pragma unroll
         for (int j = 0; j < QPL; ++j) {
-            float t = q[j][0] - cc[0];
-            float dist = t * t;
-#pragma unroll
-            for (int d = 1; d < D; ++d) {
-                t = q[j][d] - cc[d];
-                dist = fmaf(t, t, dist);
-            }
-            const bool lt = dist < best[j];  // strict: the lowest index wins an exact tie
+            const float dist = dist_of(cc, j);
+            const bool lt = dist < best[j];
             best[j] = lt ? dist : best[j];
             best_i[j] = lt ? c : best_i[j];
         }
@@ -264,7 +271,13 @@ __global__ __launch_bounds__(256) void vq_scan_kernel(const float* __restrict__ 
     };
     auto visit_block = [&](const float (&src)[CB][D], int c0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < CB; ++i) visit(src[i], c0 + i);
+        for (int j = 0; j < QPL; ++j) {
+            static_assert(CB == 4, "block minimum written for four codes");
+            const float m = fminf(__builtin_fminf(__builtin_fminf(dist_of(src[0], j), dist_of(src[1], j)), dist_of(src[2], j)), dist_of(src[3], j));
+            const bool lt = m < best[j];  // strict: the first block wins
+            best[j] = lt ? m : best[j];
+            best_i[j] = lt ? c0 : best_i[j];
+        }
         // (the running minima end every dependency chain of the block: naming them pins the block's arithmetic in front of the
         // wait + loads that follow — sched_barrier alone orders only what instruction selection has already put there)
 #pragma unroll
@@ -305,12 +318,28 @@ __global__ __launch_bounds__(256) void vq_scan_kernel(const float* __restrict__ 
         for (int d = 0; d < D; ++d) cc[d] = cb[d];
         visit(cc, c);
     }
+    // which code of the winning block: the first whose distance equals the minimum (codes past the slice do not take part)
 #pragma unroll
     for (int j = 0; j < QPL; ++j) {
         const int64_t qi = q0 + 64 * j;
         if (qi < n) {
+            int win = best_i[j];
+            if (win != 0x7fffffff) {
+                const int base = win;
+                bool found = false;
+#pragma unroll
+                for (int i = 0; i < CB; ++i) {
+                    const int ci = base + i < c_end ? base + i : c_end - 1;
+                    float cc[D];
+#pragma unroll
+                    for (int d = 0; d < D; ++d) cc[d] = codebook[(int64_t)ci * D + d];
+                    const bool hit = !found && base + i < c_end && dist_of(cc, j) == best[j];
+                    win = hit ? base + i : win;
+                    found = found || hit;
+                }
+            }
             part_dist[(int64_t)blockIdx.y * n + qi] = best[j];
-            part_idx[(int64_t)blockIdx.y * n + qi] = best_i[j];
+            part_idx[(int64_t)blockIdx.y * n + qi] = win;
         }
     }
 }
