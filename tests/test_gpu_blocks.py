@@ -395,3 +395,31 @@ def test_vq_argmin_matches_closed_form():
         best = d.argmin(1)
         gap = d.gather(1, got.long().unsqueeze(1)).squeeze(1) - d.gather(1, best.unsqueeze(1)).squeeze(1)
         assert (gap.abs() < 1e-6).all()
+
+
+def test_vq_argmin_scan_form_and_ties():
+    """The scan form (N >= 16384 queries: per-block minima, winner recovered afterwards) against the wavefront form on the same
+    queries, on a codebook with exact duplicates: both must return the LOWEST index among bit-identical distances, across block
+    (4 codes), slice and ragged-tail boundaries."""
+    g = torch.Generator().manual_seed(5)
+    for k, d in ((4999, 6), (1030, 3)):
+        base = torch.randn(k, d, generator=g)
+        cb = base.clone()
+        dup = torch.randperm(k, generator=g)[: k // 3]
+        src = torch.randint(0, k, (dup.numel(),), generator=g)
+        cb[dup] = cb[src]                                  # exact duplicates at arbitrary positions
+        cb[-1] = cb[0]                                     # ... including the very last code of the ragged tail
+        q = torch.randn(20000, d, generator=g)
+        q[:2000] = cb[torch.randint(0, k, (2000,), generator=g)]  # queries ON codes: zero distance, many ties
+        scan = G.vq_argmin(q.cuda(), cb.cuda()).cpu()
+        wave = torch.cat([G.vq_argmin(q[i:i + 5000].cuda(), cb.cuda()).cpu() for i in range(0, 20000, 5000)])
+        assert torch.equal(scan, wave)
+        # lowest index among identical rows: the winner is the first occurrence of its row
+        rows = {}
+        for i, r in enumerate(cb.numpy().tobytes()[j * 4 * d:(j + 1) * 4 * d] for j in range(k)):
+            rows.setdefault(r, i)
+        first = torch.tensor([rows[cb[i].numpy().tobytes()] for i in scan.tolist()])
+        assert torch.equal(first, scan.long())
+        dist = torch.cdist(q.double(), cb.double())
+        gap = dist.gather(1, scan.long().unsqueeze(1)).squeeze(1) - dist.min(1).values
+        assert (gap.abs() < 1e-5).all()
