@@ -421,7 +421,7 @@ __global__ __launch_bounds__(THREADS) void vq_argmin_combine_kernel(const float*
 
 constexpr int VQ_QPL = 4;       // queries per lane of the scan form
 constexpr int VQ_QW = 4;        // queries per wave of the wavefront form
-constexpr int64_t VQ_WAVE_MAX_N = 16384;  // below this many queries the wavefront form fills the chip better
+constexpr int64_t VQ_WAVE_MAX_N = 5120;  // below this many queries the wavefront form fills the chip better (measured crossover at K = 117 649: 4096-8192)
 
 template <int D>
 int launch_vq_t(hipStream_t s, const float* queries, int64_t n, const float* codebook, int k, int parts, int k_per_part,

@@ -398,7 +398,7 @@ def test_vq_argmin_matches_closed_form():
 
 
 def test_vq_argmin_scan_form_and_ties():
-    """The scan form (N >= 16384 queries: per-block minima, winner recovered afterwards) against the wavefront form on the same
+    """The scan form (N >= 5120 queries: per-block minima, winner recovered afterwards) against the wavefront form on the same
     queries, on a codebook with exact duplicates: both must return the LOWEST index among bit-identical distances, across block
     (4 codes), slice and ragged-tail boundaries."""
     g = torch.Generator().manual_seed(5)
