@@ -133,15 +133,19 @@ __global__ __launch_bounds__(64) void attention_kernel(const float* __restrict__
 //   the B operand of  O^T[d][query] += V^T[d][key] . P[key][query]  (reduction over the accumulator's row index).
 // ---------------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int KC = 128;        // keys per LDS chunk
+// KC: keys per LDS chunk = queries per workgroup (KC / 32 waves): 64 for clips of at most 64 frames (a 1 s chunk at 60 fps: half
+// the staging of the 128-key form), 192 for 129-192 frames (one workgroup and ONE staging pass per (clip, head) instead of two
+// workgroups and three), else 128.  Key tiles of 32 are visited in ascending order whatever KC is: the results do not depend on it.
 constexpr int KS_STRIDE = 36;  // K rows: 32 + 4 floats (odd number of 16-B slots)
-constexpr int VT_STRIDE = KC + 4;
 
 __device__ __forceinline__ int rowmap(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 
-__global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                            const float* __restrict__ table, int frames, int heads,
-                                                            int window, float scale) {
+template <int KC>
+__global__ __launch_bounds__(2 * KC) void attention_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                               const float* __restrict__ table, int frames, int heads,
+                                                               int window, float scale) {
+    constexpr int VT_STRIDE = KC + 4;
+    constexpr int THREADS_A = 2 * KC;
     __shared__ __attribute__((aligned(16))) float Ks[KC * KS_STRIDE];
     __shared__ __attribute__((aligned(16))) float Vt[32 * VT_STRIDE];
     extern __shared__ float bias_s[];
@@ -152,16 +156,16 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
     const int h = blockIdx.y, b = blockIdx.z;
     const int inner = heads * 32, ld = 3 * inner;
     const float* base = qkv + (int64_t)b * frames * ld + h * 32;
-    const int i0 = blockIdx.x * 128;                 // first query of the workgroup
+    const int i0 = blockIdx.x * KC;                  // first query of the workgroup
     const int q0 = i0 + 32 * wave;                   // first query of this wave
     const bool wave_active = q0 < frames;
     const int i = min(q0 + lj, frames - 1);          // this lane's query (clamped; inactive lanes never store)
     const bool q_ok = q0 + lj < frames;
     const int wi = i / window;
     const int jlo = (i0 / window) > 0 ? (i0 / window - 1) * window : 0;
-    const int jhi = min(frames - 1, i0 + 127);
+    const int jhi = min(frames - 1, i0 + KC - 1);
     const int n_bias = min(2 * window, jhi - jlo + 1);
-    for (int d = tid; d < n_bias; d += 256) bias_s[d] = table[(int64_t)h * 2 * window + d];
+    for (int d = tid; d < n_bias; d += THREADS_A) bias_s[d] = table[(int64_t)h * 2 * window + d];
 
     float qv[16];  // Q[i][8q + 4 lh + r] * dh^-0.5
 #pragma unroll
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
 
     for (int c0 = jlo; c0 <= jhi; c0 += KC) {
         __syncthreads();
-        for (int idx = tid; idx < KC * 8; idx += 256) {  // K rows and V^T of keys [c0, c0 + KC); zeros past jhi
+        for (int idx = tid; idx < KC * 8; idx += THREADS_A) {  // K rows and V^T of keys [c0, c0 + KC); zeros past jhi
             const int key = idx >> 3, d4 = (idx & 7) << 2;
             float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
             if (c0 + key <= jhi) {
@@ -264,9 +268,15 @@ int launch_attention(hipStream_t s, const float* qkv, float* out, const float* b
     const double pairs = frames <= window ? 0.5 * frames * (frames + 1.0) : 1.5 * (double)window * frames;
     ProfScope prof(s, "attention_kernel", 6.0 * dh * pairs * heads * batch, 4.0 * 4.0 * heads * dh * (double)batch * frames);
     if (dh == 32) {  // MFMA path
-        const size_t lds = (size_t)std::min(2 * window, std::min(frames, 128 + 2 * window)) * sizeof(float);
-        hipLaunchKernelGGL(attention_mfma_kernel, dim3((unsigned)ceil_div64(frames, 128), (unsigned)heads, (unsigned)batch),
-                           dim3(256), lds, s, qkv, out, bias_table, frames, heads, window, scale);
+        const int kc = frames <= 64 ? 64 : (frames > 128 && frames <= 192 ? 192 : 128);
+        const size_t lds = (size_t)std::min(2 * window, std::min(frames, kc + 2 * window)) * sizeof(float);
+        const dim3 grid_m((unsigned)ceil_div64(frames, kc), (unsigned)heads, (unsigned)batch);
+        if (kc == 64)
+            hipLaunchKernelGGL(attention_mfma_kernel<64>, grid_m, dim3(128), lds, s, qkv, out, bias_table, frames, heads, window, scale);
+        else if (kc == 192)
+            hipLaunchKernelGGL(attention_mfma_kernel<192>, grid_m, dim3(384), lds, s, qkv, out, bias_table, frames, heads, window, scale);
+        else
+            hipLaunchKernelGGL(attention_mfma_kernel<128>, grid_m, dim3(256), lds, s, qkv, out, bias_table, frames, heads, window, scale);
         L3AC_LAUNCH_CHECK();
         return L3AC_OK;
     }
