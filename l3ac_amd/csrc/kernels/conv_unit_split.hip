@@ -139,10 +139,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv_unit_split_kernel(const Co
         pre_src[it] = (row - 3) * C + 4 * ch;
         pre_dst[it] = i < G::ROWS * (G::XC / 4) ? row * G::XS + 4 * ch : -1;
     }
-    auto load_rows = [&](int64_t tl, int xh, float4 (&pre)[NPRE]) {
-        const bool ok = tl < n_tiles;
-        const int bb = ok ? (int)(tl / tiles_per_clip) : 0;
-        const int tt0 = ok ? (int)(tl % tiles_per_clip) * 32 : -(1 << 28);
+    // (clip, tile within the clip) of a tile index are carried incrementally from one pass to the next: the wave-uniform 64-bit
+    // tile / tiles_per_clip and % of the first version were ~100 scalar instructions each, four per tile and wave
+    auto load_rows = [&](bool ok, int bb_, int ti_, int xh, float4 (&pre)[NPRE]) {
+        const int bb = ok ? bb_ : 0;
+        const int tt0 = ok ? ti_ * 32 : -(1 << 28);
         const float* cl = x + ((int64_t)bb * frames + (ok ? tt0 : 0)) * C + xh * G::XC;
 #pragma unroll
         for (int it = 0; it < NPRE; ++it) {
@@ -158,17 +159,26 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv_unit_split_kernel(const Co
             if (pre_dst[it] >= 0) *reinterpret_cast<float4*>(xs + pre_dst[it]) = pre[it];
     };
     const int64_t tile_stride = (int64_t)gridDim.x * WAVES;
+    const int stride_b = (int)((unsigned)tile_stride / (unsigned)tiles_per_clip), stride_t = (int)((unsigned)tile_stride % (unsigned)tiles_per_clip);
+    const unsigned first_tile = (unsigned)blockIdx.x * WAVES + (unsigned)wave;  // (the launcher keeps n_tiles below 2^31)
+    int cur_b = (int)(first_tile / (unsigned)tiles_per_clip), cur_t = (int)(first_tile % (unsigned)tiles_per_clip);
     float4 pre[XH == 1 ? NPRE : 1];
-    if constexpr (XH == 1) load_rows((int64_t)blockIdx.x * WAVES + wave, 0, pre);
+    if constexpr (XH == 1) load_rows((int64_t)first_tile < n_tiles, cur_b, cur_t, 0, pre);
     int gchunk = 0;  // chunk steps taken so far (streamed variant): its parity selects the LDS buffer
 
     // every wave of the block runs the same number of iterations (the streamed variant has block barriers inside)
     for (int64_t base = (int64_t)blockIdx.x * WAVES; base < n_tiles; base += tile_stride) {
         const int64_t tile = base + wave;
         const bool tile_ok = tile < n_tiles;
-        const int b = tile_ok ? (int)(tile / tiles_per_clip) : 0;
-        const int t0 = tile_ok ? (int)(tile % tiles_per_clip) * 32 : 0;
+        const int b = tile_ok ? cur_b : 0;
+        const int t0 = tile_ok ? cur_t * 32 : 0;
         const float* clip = x + (int64_t)b * frames * C;
+        // the next pass's tile of this wave
+        int nxt_b = cur_b + stride_b, nxt_t = cur_t + stride_t;
+        if (nxt_t >= tiles_per_clip) {
+            nxt_t -= tiles_per_clip;
+            ++nxt_b;
+        }
 
         // ---- depth-wise conv k7 + LayerNorm for frame lj, channels k = 8q + 4 lh + r (as conv_unit_fused.hip) ----
         float a[4 * G::KQ];
@@ -191,7 +201,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv_unit_split_kernel(const Co
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if constexpr (XH == 1) load_rows(tile + tile_stride, 0, pre);
+            if constexpr (XH == 1) load_rows(tile + tile_stride < n_tiles, nxt_b, nxt_t, 0, pre);
 #pragma unroll
             for (int ql = 0; ql < G::KQ / XH; ++ql) {
                 const int q = xh * (G::KQ / XH) + ql;
@@ -342,6 +352,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv_unit_split_kernel(const Co
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        cur_b = nxt_b;
+        cur_t = nxt_t;
     }
 }
 
@@ -357,6 +369,7 @@ int launch_split(hipStream_t s, const ConvUnitW& w, const float* x, float* y, in
         configured = true;
     }
     const int64_t tiles = (int64_t)batch * ((frames + 31) / 32);
+    L3AC_REQUIRE(tiles < ((int64_t)1 << 31) - 65536, "conv_unit_split: too many tiles");
     const int per_cu = lds > 80 * 1024 ? 1 : 2;
     int64_t blocks = ceil_div64(tiles, WAVES);
     if (blocks > 256 * per_cu) blocks = 256 * per_cu;
