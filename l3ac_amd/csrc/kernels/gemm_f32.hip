@@ -58,10 +58,12 @@ __global__ __launch_bounds__(THREADS, BK == 16 ? 3 : 2) void gemm_f32_kernel(con
     // so all column tiles of one A row panel run on ONE XCD and the panel is fetched from HBM once, not 8 times.
     const int n_blocks = (p.n + BN - 1) / BN;
     const int64_t m_panels = (p.m + BM - 1) / BM;
-    const int64_t group = blockIdx.x / (8 * n_blocks);
-    const int64_t in_group = blockIdx.x % (8 * n_blocks);
-    const int64_t panels_here = (group * 8 + 8 <= m_panels) ? 8 : m_panels - group * 8;
-    const int64_t m0 = (group * 8 + in_group % panels_here) * BM;
+    // (32-bit on purpose: the 64-bit forms of these four wave-uniform divisions are ~100 scalar instructions each, a visible part of
+    // a short-K block's life; the launcher keeps the grid, hence every quotient, below 2^31)
+    const unsigned group = blockIdx.x / (unsigned)(8 * n_blocks);
+    const unsigned in_group = blockIdx.x % (unsigned)(8 * n_blocks);
+    const unsigned panels_here = ((int64_t)group * 8 + 8 <= m_panels) ? (unsigned)8 : (unsigned)(m_panels - (int64_t)group * 8);
+    const int64_t m0 = ((int64_t)group * 8 + in_group % panels_here) * BM;
     const int n0 = (int)(in_group / panels_here) * BN;
 
     // ---- staging roles: thread -> (chunk column cc, rows r0 + RP i) ---------------------------------
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(THREADS, BK == 16 ? 3 : 2) void gemm_f32_kernel(con
         const int64_t m = m0 + r0 + RP * i;
         a_ok[i] = m < p.m;
         const int64_t mm = a_ok[i] ? m : 0;
-        a_t[i] = CONV ? (int)(mm % p.frames) : 0;
+        a_t[i] = CONV ? (int)((unsigned)mm % (unsigned)p.frames) : 0;  // (m < 2^31: checked by the launcher)
         a_row[i] = p.a + mm * p.lda;
     }
     const float* w_row[WP];
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(THREADS, BK == 16 ? 3 : 2) void gemm_f32_kernel(con
             const int64_t m = m0 + r0 + RP * i;
             const int64_t mm = m < p.m ? m : 0;
             const float4 yraw = *reinterpret_cast<const float4*>(p.gate_yi + mm * 4);
-            const float* st = p.gate_stats + (mm / p.gate_frames) * 8;
+            const float* st = p.gate_stats + (size_t)((unsigned)mm / (unsigned)p.gate_frames) * 8;
             const float4 mean = *reinterpret_cast<const float4*>(st);
             const float4 istd = *reinterpret_cast<const float4*>(st + 4);
             yn[i] = make_float4((yraw.x - mean.x) * istd.x * iw.x + ib.x, (yraw.y - mean.y) * istd.y * iw.y + ib.y,
@@ -235,10 +237,12 @@ __global__ __launch_bounds__(THREADS, 3) void gemm_f32_dma_kernel(const GemmArgs
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_blocks = (p.n + BN - 1) / BN;
     const int64_t m_panels = (p.m + BM - 1) / BM;
-    const int64_t group = blockIdx.x / (8 * n_blocks);
-    const int64_t in_group = blockIdx.x % (8 * n_blocks);
-    const int64_t panels_here = (group * 8 + 8 <= m_panels) ? 8 : m_panels - group * 8;
-    const int64_t m0 = (group * 8 + in_group % panels_here) * BM;
+    // (32-bit on purpose: the 64-bit forms of these four wave-uniform divisions are ~100 scalar instructions each, a visible part of
+    // a short-K block's life; the launcher keeps the grid, hence every quotient, below 2^31)
+    const unsigned group = blockIdx.x / (unsigned)(8 * n_blocks);
+    const unsigned in_group = blockIdx.x % (unsigned)(8 * n_blocks);
+    const unsigned panels_here = ((int64_t)group * 8 + 8 <= m_panels) ? (unsigned)8 : (unsigned)(m_panels - (int64_t)group * 8);
+    const int64_t m0 = ((int64_t)group * 8 + in_group % panels_here) * BM;
     const int n0 = (int)(in_group / panels_here) * BN;
 
     // per-lane DMA sources (rows past the edge are clamped to row 0: they feed accumulators that are never stored)
@@ -388,6 +392,7 @@ int launch_gemm(hipStream_t s, const GemmArgs& g) {
                  (long long)g.ldw);
     L3AC_REQUIRE(((uintptr_t)g.a & 15) == 0 && ((uintptr_t)g.w & 15) == 0, "gemm: operands must be 16-byte aligned");
     const bool conv = g.taps > 1;
+    if (conv || g.gate_yi) L3AC_REQUIRE(g.m < ((int64_t)1 << 31), "gemm: implicit-conv / gated A needs m < 2^31 (32-bit row arithmetic)");
     // bf16x3 split route (gemm_split.hip).  The choice depends on the WEIGHT's shape only, never on m: a clip must give
     // bit-identical tokens and samples whether it is coded alone or inside a batch (tests: test_full_batch_properties).
     if (g.gate_yi) {

@@ -88,10 +88,12 @@ __device__ __forceinline__ void gemm_split_body32(const GemmArgs& p, const int g
     const int n_blocks = (p.n + BN - 1) / BN;
     const int64_t m_panels = (p.m + BM - 1) / BM;
     const int GP = gp;  // row panels per group (a multiple of the 8 XCDs)
-    const int64_t group = blockIdx.x / (GP * n_blocks);
-    const int64_t in_group = blockIdx.x % (GP * n_blocks);
-    const int64_t panels_here = (group * GP + GP <= m_panels) ? GP : m_panels - group * GP;
-    const int64_t m0 = (group * GP + in_group % panels_here) * BM;
+    // (32-bit on purpose: the 64-bit forms of these four wave-uniform divisions are ~100 scalar instructions each, a visible part of
+    // a short-K block's life; the launcher keeps the grid, hence every quotient, below 2^31)
+    const unsigned group = blockIdx.x / (unsigned)(GP * n_blocks);
+    const unsigned in_group = blockIdx.x % (unsigned)(GP * n_blocks);
+    const unsigned panels_here = ((int64_t)group * GP + GP <= m_panels) ? (unsigned)GP : (unsigned)(m_panels - (int64_t)group * GP);
+    const int64_t m0 = ((int64_t)group * GP + in_group % panels_here) * BM;
     const int n0 = (int)(in_group / panels_here) * BN;
     const int n_tiles = (p.k + BK - 1) / BK;
     const int last = n_tiles - 1;
@@ -306,10 +308,12 @@ __device__ __forceinline__ void gemm_split_body16(const GemmArgs& p, const int g
     const int n_blocks = (p.n + BN - 1) / BN;
     const int64_t m_panels = (p.m + BMW - 1) / BMW;
     const int GP = gp;
-    const int64_t group = blockIdx.x / (GP * n_blocks);
-    const int64_t in_group = blockIdx.x % (GP * n_blocks);
-    const int64_t panels_here = (group * GP + GP <= m_panels) ? GP : m_panels - group * GP;
-    const int64_t m0 = (group * GP + in_group % panels_here) * BMW;
+    // (32-bit on purpose: the 64-bit forms of these four wave-uniform divisions are ~100 scalar instructions each, a visible part of
+    // a short-K block's life; the launcher keeps the grid, hence every quotient, below 2^31)
+    const unsigned group = blockIdx.x / (unsigned)(GP * n_blocks);
+    const unsigned in_group = blockIdx.x % (unsigned)(GP * n_blocks);
+    const unsigned panels_here = ((int64_t)group * GP + GP <= m_panels) ? (unsigned)GP : (unsigned)(m_panels - (int64_t)group * GP);
+    const int64_t m0 = ((int64_t)group * GP + in_group % panels_here) * BMW;
     const int n0 = (int)(in_group / panels_here) * BN;
     const int n_tiles = (p.k + BK - 1) / BK;
     const int last = n_tiles - 1;
