@@ -439,11 +439,23 @@ def other_configs(dev, args):
     idx = torch.empty(n, dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
     nbytes = lib.l3ac_vq_argmin_scratch_bytes(n, k)
-    scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    scratch = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
     call = lambda: _capi.check(lib.l3ac_vq_argmin(queries.data_ptr(), n, codebook.data_ptr(), k, len(levels), idx.data_ptr(),
                                                   scratch.data_ptr(), nbytes, stream))
     steps = 5
     dt, _ = time_steps(call, steps, 2)
+    listed = int(scratch[:4].view(torch.int32).item())  # screened form: queries that took the full direct-form search
+    # the same call on the direct-form scan (the form the screened one must agree with on EVERY query, not only the clear ones)
+    lib.l3ac_set_vq_form(1)
+    try:
+        nb_scan = lib.l3ac_vq_argmin_scratch_bytes(n, k)
+        sc_scan = torch.empty(nb_scan, dtype=torch.uint8, device=dev)
+        idx_scan = torch.empty_like(idx)
+        call_scan = lambda: _capi.check(lib.l3ac_vq_argmin(queries.data_ptr(), n, codebook.data_ptr(), k, len(levels), idx_scan.data_ptr(),
+                                                           sc_scan.data_ptr(), nb_scan, stream))
+        dt_scan, _ = time_steps(call_scan, 3, 1)
+    finally:
+        lib.l3ac_set_vq_form(0)
     _, idx_ref, _ = O.fsq_quantize(z, levels)
     lvt = torch.tensor(levels, dtype=torch.float64)
     scaled = (torch.tanh(z.double()) + 1) / 2 * (lvt - 1)
@@ -455,7 +467,14 @@ def other_configs(dev, args):
                         "achieved": flop / ms / 1e9, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": flop / ms / 1e9 / PEAK_F32_TFLOPS,
                         "algorithmic_bytes": 24 * n + 24 * k + 4 * n, "gbs": (24 * n + 24 * k + 4 * n) / ms / 1e6,
                         "equal_to_closed_form_where_margin_gt_1e-4": bool(torch.equal(idx.cpu()[clear], idx_ref[clear])),
-                        "queries_compared": int(clear.sum())}
+                        "queries_compared": int(clear.sum()),
+                        "form": "screened: |c|^2 - 2 q.c per 32 x 32 tile on v_mfma_f32_32x32x2_f32 picks a block of 16 candidate codes per "
+                                "query, the direct form (the definition) decides among them; queries whose two best blocks are within "
+                                "128 u Qd take the full direct-form search",
+                        "matrix_pipe_gflop": 12.0 * n * k / 1e9, "matrix_pipe_frac": 12.0 * n * k / ms / 1e9 / PEAK_F32_TFLOPS,
+                        "queries_sent_to_full_search": listed,
+                        "direct_form_scan": {"ms": dt_scan / 3 * 1e3, "frac": flop / (dt_scan / 3 * 1e3) / 1e9 / PEAK_F32_TFLOPS,
+                                             "equal_on_every_query": bool(torch.equal(idx, idx_scan))}}
     return out
 
 

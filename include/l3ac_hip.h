@@ -143,11 +143,18 @@ int l3ac_fsq_decode(const int32_t* indices, int64_t n, int32_t feat, const int32
 /* Explicit-codebook nearest neighbour (the search FSQ is the closed form of):
  * queries [n][dim] (= tanh(latents)), codebook [k][dim] (= indices_to_codes(arange(k)), vq/fsq.py:80-81);
  * out_idx[i] = argmin_k ||q_i - c_k||^2, lowest k on exact ties.  dim <= 8.
+ * The result is DEFINED by dist = sum_d (q_d - c_d)^2 accumulated with fmaf in dimension order and strict '<' over
+ * increasing k; from 5 120 queries on the candidates are first screened on the fp32 matrix cores and then decided by
+ * exactly that arithmetic (kernels/fsq.hip, "screened form"), so every size returns the same bits.
  * `scratch` is a caller-owned device buffer of at least l3ac_vq_argmin_scratch_bytes(n, k) bytes (partial minima of the
- * codebook slices): the call allocates nothing and can be captured into a hipGraph. */
+ * codebook slices, code norms, the list of queries that need the full direct-form search): the call allocates nothing and
+ * can be captured into a hipGraph.  n < 2^31. */
 int64_t l3ac_vq_argmin_scratch_bytes(int64_t n, int32_t k);
 int l3ac_vq_argmin(const float* queries, int64_t n, const float* codebook, int32_t k, int32_t dim, int32_t* out_idx,
                    void* scratch, int64_t scratch_bytes, void* stream);
+/* Test hook, process-wide: form 1 runs the direct-form scan wherever the screened form would run (the two are compared by
+ * tests/test_gpu_blocks.py and timed side by side by tools/vq_argmin_bench.py); 0 = automatic.  Changes the scratch size. */
+void l3ac_set_vq_form(int32_t form);
 
 /* ---- token wire format (no reference counterpart: the reference keeps int32 indices, vq/fsq.py:68) ---------------
  * Per clip, token t occupies bits [t*bits, (t+1)*bits) of a little-endian bit stream, zero-padded to whole 32-bit

@@ -77,6 +77,7 @@ SIGNATURES = {
     "l3ac_op_decoder": (C.c_int, [_P, _P, _I32, _I32, _P, _P]),
     "l3ac_op_snake": (C.c_int, [_P, _P, _I64, _I32, _P, _I32, _P]),
     "l3ac_set_head_pretanh": (None, [_I32]),
+    "l3ac_set_vq_form": (None, [_I32]),
     "l3ac_gemm_f32": (C.c_int, [_P, _I64, _P, _P, _P, _I64, _I64, _I32, _I32, _P]),
     "l3ac_split3_host": (None, [_P, _I64, _P]),
     "l3ac_set_gemm_split": (None, [_I32]),

@@ -68,7 +68,11 @@ def _depfile_newest(dep: Path) -> float:
 # Flags of single sources.  conv_unit_wide.hip places single-issue vector instructions one by one into the gaps behind its
 # MFMAs; the SLP vectoriser would re-pack the per-element fp32 operations into v_pk_*_f32, which cost several times their
 # issue slot beside an MFMA (MI355X_MICROARCH.md, 'price of one filler beside MFMAs').
-PER_FILE_FLAGS = {"kernels/conv_unit_wide.hip": ["-fno-slp-vectorize"]}
+PER_FILE_FLAGS = {
+    "kernels/conv_unit_wide.hip": ["-fno-slp-vectorize"],
+    # vq_screen_kernel reduces every MFMA result on the vector unit at once: results in VGPRs, not AGPRs + 16 v_accvgpr_read
+    "kernels/fsq.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+}
 
 
 def _flag_stamp(hipcc: str, flags) -> str:

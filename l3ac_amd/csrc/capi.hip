@@ -478,6 +478,7 @@ void l3ac_split3_host(const float* x, int64_t n, uint16_t* planes) {
     }
 }
 
+void l3ac_set_vq_form(int32_t form) { vq_set_form(form); }
 void l3ac_set_head_pretanh(int32_t enable) { g_head_pretanh.store(enable != 0, std::memory_order_relaxed); }
 
 int l3ac_op_snake(const float* x, float* y, int64_t rows, int32_t c, const float* alpha, int32_t mode, void* stream) {

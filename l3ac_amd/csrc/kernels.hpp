@@ -162,5 +162,6 @@ int launch_pack_indices(hipStream_t s, const int32_t* idx, int batch, int n_tok,
 int launch_unpack_indices(hipStream_t s, const uint32_t* in, int batch, int n_tok, int bits, int words_per_clip, int32_t* idx);
 // explicit-codebook L2 argmin (kernels/fsq.hip): scratch = vq_argmin_scratch_bytes(n, k) bytes, caller-provided
 size_t vq_argmin_scratch_bytes(int64_t n, int k);
+void vq_set_form(int form);  // test hook l3ac_set_vq_form: 0 automatic, 1 the direct-form scan wherever the screened form would run
 int launch_vq_argmin(hipStream_t s, const float* queries, int64_t n, const float* codebook, int k, int dim, void* scratch,
                      int32_t* out_idx);

@@ -12,14 +12,17 @@
 // holds identical latents and finishes its own 8 output channels.  Everything after tanh is exact IEEE arithmetic,
 // so indices are bit-identical to the reference for identical activations.
 //
-// vq_scan_kernel / vq_wave_kernel — the explicit-codebook nearest-neighbour search FSQ is the closed form of:
-// see "explicit codebook search" below; lowest index wins exact ties.
+// vq_screen_kernel + vq_resolve_kernel / vq_scan_kernel / vq_wave_kernel — the explicit-codebook nearest-neighbour search FSQ
+// is the closed form of: see "explicit codebook search" and "screened form" below; lowest index wins exact ties.
+#include <atomic>
+
 #include "../kernels.hpp"
 
 namespace {
 
 constexpr int THREADS = 256;
 constexpr int MAXD = L3AC_MAX_LEVELS;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct FsqDev {
     const float* x;
@@ -204,9 +207,12 @@ int launch_fsq_t(hipStream_t s, const FsqDev& p) {
 // ---- explicit codebook search ----------------------------------------------------------------------
 // Brute-force L2 nearest neighbour, dist = sum_d (q_d - c_d)^2 accumulated with fmaf in dimension order, strict '<' while
 // the codes are visited in increasing index (the lowest index wins an exact tie): 3 D N K algorithmic FLOP, fp32-VALU-bound.
-// Two forms, both specialised on the true dimension (no padded FMAs) and both splitting the codebook into `parts` index
-// ranges whose (distance, index) minima a small second kernel combines in index order:
-//   vq_scan_kernel  (many queries)  QPL queries per lane in registers; the code coordinates are wave-uniform, so they come
+// Three forms, all specialised on the true dimension (no padded FMAs), all splitting the codebook into `parts` index ranges
+// whose partial results a small second kernel combines in index order, all returning the same bits:
+//   vq_screen_kernel (many queries: the default from 5 120 on) see "screened form" below: scores on the fp32 matrix pipe pick
+//                   16 candidates per query, the arithmetic above decides among them.
+//   vq_scan_kernel  (many queries; l3ac_set_vq_form(1): the direct form at scale, the reference the screened form is tested
+//                   against)  QPL queries per lane in registers; the code coordinates are wave-uniform, so they come
 //                   through the SCALAR unit (s_load) and enter the VALU instructions as SGPR operands: no LDS staging, no
 //                   barrier, nothing but 2 D + 3 vector instructions per (query, code) pair.
 //   vq_wave_kernel  (few queries: a streaming chunk has 60)  the codebook slice is dealt over the 64 LANES, QW queries per
@@ -344,16 +350,21 @@ __global__ __launch_bounds__(256) void vq_scan_kernel(const float* __restrict__ 
     }
 }
 
+// `list` != null: the queries are list[0 .. *list_n - 1] (numbers into `queries`), results are stored per list SLOT and
+// `n` is only the slot stride of the partial arrays: the exact pass of the screened form, whose length the host does not know.
 template <int D, int QW>
 __global__ __launch_bounds__(256) void vq_wave_kernel(const float* __restrict__ queries, int64_t n, const float* __restrict__ codebook,
-                                                     int k, int k_per_part, float* __restrict__ part_dist, int32_t* __restrict__ part_idx) {
+                                                     int k, int k_per_part, float* __restrict__ part_dist, int32_t* __restrict__ part_idx,
+                                                     const int32_t* __restrict__ list, const int32_t* __restrict__ list_n) {
     const int lane = threadIdx.x & 63;
-    const int64_t qbase = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * QW;  // wave-uniform
-    if (qbase >= n) return;
+    const int64_t n_here = list ? (int64_t)*list_n : n;
+    // (a listed run's length is not known to the host: its grid is a fixed number of wave columns that stride over the list)
+    for (int64_t qbase = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * QW; qbase < n_here; qbase += (int64_t)gridDim.x * 4 * QW) {
     float q[QW][D];
 #pragma unroll
     for (int j = 0; j < QW; ++j) {
-        const int64_t qi = qbase + j < n ? qbase + j : n - 1;
+        const int64_t slot = qbase + j < n_here ? qbase + j : n_here - 1;
+        const int64_t qi = list ? (int64_t)list[slot] : slot;
 #pragma unroll
         for (int d = 0; d < D; ++d) q[j][d] = queries[qi * D + d];  // uniform address: every lane holds the query
     }
@@ -366,10 +377,7 @@ __global__ __launch_bounds__(256) void vq_wave_kernel(const float* __restrict__ 
     }
     const int c_begin = blockIdx.y * k_per_part;
     const int c_end = min(k, c_begin + k_per_part);
-    for (int c = c_begin + lane; c < c_end; c += 64) {  // a lane's codes come in increasing index: strict '<' keeps its lowest
-        float cc[D];
-#pragma unroll
-        for (int d = 0; d < D; ++d) cc[d] = codebook[(int64_t)c * D + d];
+    auto visit = [&](const float (&cc)[D], int c) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < QW; ++j) {
             float t = q[j][0] - cc[0];
@@ -383,6 +391,26 @@ __global__ __launch_bounds__(256) void vq_wave_kernel(const float* __restrict__ 
             best[j] = lt ? dist : best[j];
             best_i[j] = lt ? c : best_i[j];
         }
+    };
+    // a lane's codes come in increasing index (strict '<' keeps its lowest); four of them are requested at a time: with few
+    // waves per SIMD (a streaming chunk, the listed queries of the screened form) the loop runs at the speed of its loads
+    constexpr int UC = 4;
+    int c = c_begin + lane;
+    for (; c + 64 * (UC - 1) < c_end; c += 64 * UC) {
+        float cc[UC][D];
+#pragma unroll
+        for (int u = 0; u < UC; ++u)
+#pragma unroll
+            for (int d = 0; d < D; ++d) cc[u][d] = codebook[(int64_t)(c + 64 * u) * D + d];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < UC; ++u) visit(cc[u], c + 64 * u);
+    }
+    for (; c < c_end; c += 64) {
+        float cc[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) cc[d] = codebook[(int64_t)c * D + d];
+        visit(cc, c);
     }
     // wavefront-level argmin: (distance, index) pairs combined over the 64 lanes, the lower index winning equal distances
 #pragma unroll
@@ -395,26 +423,268 @@ __global__ __launch_bounds__(256) void vq_wave_kernel(const float* __restrict__ 
             best[j] = take ? od : best[j];
             best_i[j] = take ? oi : best_i[j];
         }
-        if (lane == 0 && qbase + j < n) {
+        if (lane == 0 && qbase + j < n_here) {
             part_dist[(int64_t)blockIdx.y * n + qbase + j] = best[j];
             part_idx[(int64_t)blockIdx.y * n + qbase + j] = best_i[j];
         }
+    }
     }
 }
 
 __global__ __launch_bounds__(THREADS) void vq_argmin_combine_kernel(const float* __restrict__ part_dist,
                                                                    const int32_t* __restrict__ part_idx, int64_t n,
-                                                                   int parts, int32_t* __restrict__ out_idx) {
-    const int64_t qi = (int64_t)blockIdx.x * THREADS + threadIdx.x;
-    if (qi >= n) return;
-    float best = part_dist[qi];
-    int best_i = part_idx[qi];
-    for (int p = 1; p < parts; ++p) {  // parts are in increasing index order: strict '<' keeps the lowest index
-        const float d = part_dist[(int64_t)p * n + qi];
-        if (d < best) {
-            best = d;
-            best_i = part_idx[(int64_t)p * n + qi];
+                                                                   int parts, int32_t* __restrict__ out_idx,
+                                                                   const int32_t* __restrict__ list, const int32_t* __restrict__ list_n) {
+    // 64 queries (list slots when there is a list) per block and round; the four waves take every fourth slice each — a single
+    // chain of `parts` dependent-looking loads per query ran at one memory latency per slice — and wave 0 merges the four.
+    // Slices are in increasing index order: among equal distances the lowest slice holds the lowest index.
+    __shared__ float s_d[3][64];
+    __shared__ int s_p[3][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t n_here = list ? (int64_t)*list_n : n;
+    for (int64_t base = (int64_t)blockIdx.x * 64; base < n_here; base += (int64_t)gridDim.x * 64) {  // block-uniform
+        const int64_t qi = base + lane;
+        const int64_t qc = qi < n_here ? qi : n_here - 1;
+        float best = INFINITY;
+        int best_p = 0x7fffffff;
+#pragma unroll 4
+        for (int p = w; p < parts; p += 4) {
+            const float d = part_dist[(int64_t)p * n + qc];
+            const bool lt = d < best;
+            best = lt ? d : best;
+            best_p = lt ? p : best_p;
         }
+        if (w > 0) {
+            s_d[w - 1][lane] = best;
+            s_p[w - 1][lane] = best_p;
+        }
+        __syncthreads();
+        if (w == 0 && qi < n_here) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float d = s_d[i][lane];
+                const int pp = s_p[i][lane];
+                const bool take = d < best || (d == best && pp < best_p);
+                best = take ? d : best;
+                best_p = take ? pp : best_p;
+            }
+            // (no slice below +inf: the first slice's entry, as a chain over the slices would have kept)
+            out_idx[list ? (int64_t)list[qi] : qi] = part_idx[(int64_t)(best_p == 0x7fffffff ? 0 : best_p) * n + qi];
+        }
+        __syncthreads();
+    }
+}
+
+// ---- screened form (many queries) ------------------------------------------------------------------
+// The direct-form search above is the DEFINITION of the result; what costs 2 D + 1 vector instructions per (query, code)
+// there is found here on the fp32 matrix pipe: score(q, c) = |c|^2 - 2 q.c (= dist - |q|^2) for a tile of 32 codes x 32
+// queries is D / 2 v_mfma_f32_32x32x2_f32 (exact fp32 FMAs, the code norms enter as the accumulator's initial value), and
+// the vector unit only keeps, per query, the smallest and second smallest BLOCK minimum (a block = the 16 codes of a tile one
+// lane holds) and which block the smallest came from: 12 instructions per 16 pairs.  The scores are not the oracle's
+// arithmetic, so they decide nothing by themselves: with u = 2^-24 and Qd = sum_d (|q_d| + max|c|)^2, the direct-form
+// distance is within 11 u Qd and the score within 16 u Qd of the exact value, hence the direct-form winner's score is at most
+// 2 (11 + 16) = 54 u Qd above the smallest score; the threshold used is 128 u Qd (it would still hold if the matrix pipe's
+// accumulation were twice as inexact as an fmaf chain).  vq_resolve_kernel therefore
+//   * second block minimum - smallest > 128 u Qd: the direct-form winner lies in the winning block: its (at most 16) codes are
+//     evaluated with the direct form in index order, strict '<': the same bits and the same tie rule as the scan;
+//   * otherwise (near-ties across blocks, exact duplicates, non-finite data): the query goes on a list, and the direct-form
+//     wave kernel searches the WHOLE codebook for the listed queries.
+// Either way every returned index is the direct form's, bit for bit (tests/test_gpu_blocks.py compares the two forms on
+// duplicated codebooks); on the FSQ grids ~0.6 % of the queries take the second route.
+template <int D>
+__device__ __forceinline__ float vq_dist(const float (&q)[D], const float (&cc)[D]) {
+    float t = q[0] - cc[0];
+    float dist = t * t;
+#pragma unroll
+    for (int d = 1; d < D; ++d) {
+        t = q[d] - cc[d];
+        dist = fmaf(t, t, dist);
+    }
+    return dist;
+}
+
+constexpr int VQ_HDR_FLOATS = 64;  // scratch header: [0] listed-query counter (int), [1] max |c_d| (float bits, >= 0)
+
+// norms[c] = |c|^2 for c < k, +inf for the padding codes of the last tile; header[1] = max |c_d|
+template <int D>
+__global__ __launch_bounds__(THREADS) void vq_norms_kernel(const float* __restrict__ codebook, int k, int k_padded,
+                                                          float* __restrict__ norms, unsigned* __restrict__ header) {
+    const int c = blockIdx.x * THREADS + threadIdx.x;
+    float cmax = 0.f;
+    if (c < k_padded) {
+        float nn = INFINITY;
+        if (c < k) {
+            float cc[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                cc[d] = codebook[(int64_t)c * D + d];
+                cmax = fmaxf(cmax, fabsf(cc[d]));
+            }
+            nn = cc[0] * cc[0];
+#pragma unroll
+            for (int d = 1; d < D; ++d) nn = fmaf(cc[d], cc[d], nn);
+        }
+        norms[c] = nn;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, m, 64));
+    // non-negative floats order as their bits; the plain read only skips atomics that could not raise the maximum
+    if ((threadIdx.x & 63) == 0 && __float_as_uint(cmax) > __builtin_nontemporal_load(header + 1)) atomicMax(header + 1, __float_as_uint(cmax));
+}
+
+constexpr int VQ_SCREEN_NQ = 8;  // query tiles (of 32) per wave: the code operand and the norms are loaded once for all of them
+                                 // (8: 1.24 ms, 4: 1.28 ms at K = 250 047, N = 42 752)
+
+template <int D, int NQ>
+__global__ __launch_bounds__(256) void vq_screen_kernel(const float* __restrict__ queries, int64_t n, const float* __restrict__ codebook,
+                                                       const float* __restrict__ norms, int k, int tiles_per_part,
+                                                       float* __restrict__ part_b, float* __restrict__ part_sb,
+                                                       int32_t* __restrict__ part_blk) {
+    constexpr int KS = (D + 1) / 2;  // k = 2 per MFMA: lane (i = lane & 31, kk = lane >> 5) supplies element (i, kk) of both operands
+    const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5;
+    const int64_t qw = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (32 * NQ);
+    if (qw >= n) return;  // wave-uniform
+    float bq[NQ][KS];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const int64_t qi = qw + 32 * j + col;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) bq[j][s] = (qi < n && 2 * s + h < D) ? -2.0f * queries[qi * D + 2 * s + h] : 0.f;
+    }
+    float b[NQ], sb[NQ];
+    int blk[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        b[j] = INFINITY;
+        sb[j] = INFINITY;
+        blk[j] = 0;
+    }
+    const int n_tiles = (k + 31) >> 5;
+    const int t_begin = blockIdx.y * tiles_per_part;
+    const int t_end = min(n_tiles, t_begin + tiles_per_part);
+    if (t_begin >= t_end) return;
+    // The operands of tile t + 1 are requested before tile t is evaluated.  Rows past the codebook's end read its last row:
+    // their norm is +inf, so is their score.  (Odd D: the missing coordinate of the last k-step is a zero on both sides.)
+    float a_nx[KS];
+    float4 cn_nx[4];
+    auto fetch = [&](int t) __attribute__((always_inline)) {
+        const float* row = codebook + (int64_t)min(t * 32 + col, k - 1) * D;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            if (2 * s + 1 < D) {
+                a_nx[s] = row[2 * s + h];
+            } else {  // odd D, last k-step: coordinate D - 1 for h = 0, nothing for h = 1
+                a_nx[s] = row[2 * s];
+                a_nx[s] = h ? 0.f : a_nx[s];
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) cn_nx[g] = *reinterpret_cast<const float4*>(norms + t * 32 + 8 * g + 4 * h);
+    };
+    fetch(t_begin);
+    for (int t = t_begin; t < t_end; ++t) {
+        float a[KS];
+        f32x16 cn;  // accumulator register r of lane (col, h) is code row 8 (r / 4) + 4 h + r % 4 of the tile
+#pragma unroll
+        for (int s = 0; s < KS; ++s) a[s] = a_nx[s];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            cn[4 * g + 0] = cn_nx[g].x; cn[4 * g + 1] = cn_nx[g].y; cn[4 * g + 2] = cn_nx[g].z; cn[4 * g + 3] = cn_nx[g].w;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(t + 1 < t_end ? t + 1 : t);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], bq[j][0], cn, 0, 0, 0);
+#pragma unroll
+            for (int s = 1; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bq[j][s], acc, 0, 0, 0);
+            // (minimumNumber is the hardware's v_min / v_min3 as it stands: fminf would first quiet every operand with a v_max)
+            float m = __builtin_elementwise_minimumnum(__builtin_elementwise_minimumnum(acc[0], acc[1]), acc[2]);
+#pragma unroll
+            for (int r = 3; r < 15; r += 2) m = __builtin_elementwise_minimumnum(__builtin_elementwise_minimumnum(m, acc[r]), acc[r + 1]);
+            m = __builtin_elementwise_minimumnum(m, acc[15]);
+            sb[j] = __builtin_amdgcn_fmed3f(b[j], m, sb[j]);  // b <= sb always: the median is the new second smallest
+            blk[j] = m < b[j] ? t : blk[j];
+            b[j] = __builtin_elementwise_minimumnum(b[j], m);
+        }
+    }
+    // the two half-waves hold the two halves of every tile for the same 32 queries
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const float ob = __shfl_xor(b[j], 32, 64);
+        const float osb = __shfl_xor(sb[j], 32, 64);
+        const int oblk = __shfl_xor(blk[j], 32, 64);
+        const bool mine = b[j] < ob || (b[j] == ob && h == 0);
+        const float nb = __builtin_fminf(b[j], ob);
+        const float nsb = __builtin_fminf(__builtin_fmaxf(b[j], ob), __builtin_fminf(sb[j], osb));
+        const int nblk = mine ? 2 * blk[j] + h : 2 * oblk + (1 - h);
+        const int64_t qi = qw + 32 * j + col;
+        if (h == 0 && qi < n) {
+            part_b[(int64_t)blockIdx.y * n + qi] = nb;
+            part_sb[(int64_t)blockIdx.y * n + qi] = nsb;
+            part_blk[(int64_t)blockIdx.y * n + qi] = nblk;
+        }
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(THREADS) void vq_resolve_kernel(const float* __restrict__ queries, int64_t n, const float* __restrict__ codebook,
+                                                            int k, int parts, const float* __restrict__ part_b,
+                                                            const float* __restrict__ part_sb, const int32_t* __restrict__ part_blk,
+                                                            int32_t* __restrict__ header, int32_t* __restrict__ list,
+                                                            int32_t* __restrict__ out_idx) {
+    // 64 queries per block; the four waves merge every fourth slice each, wave 0 merges the four results and decides
+    __shared__ float s_b[3][64], s_sb[3][64];
+    __shared__ int s_blk[3][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t qi = (int64_t)blockIdx.x * 64 + lane;
+    const int64_t qc = qi < n ? qi : n - 1;
+    float b = INFINITY, sb = INFINITY;
+    int blk = 0;
+    auto merge = [&](float pb, float psb, int pblk) __attribute__((always_inline)) {
+        sb = fminf(fmaxf(b, pb), fminf(sb, psb));
+        blk = pb < b ? pblk : blk;
+        b = fminf(b, pb);
+    };
+    for (int p = w; p < parts; p += 4) merge(part_b[(int64_t)p * n + qc], part_sb[(int64_t)p * n + qc], part_blk[(int64_t)p * n + qc]);
+    if (w > 0) {
+        s_b[w - 1][lane] = b;
+        s_sb[w - 1][lane] = sb;
+        s_blk[w - 1][lane] = blk;
+    }
+    __syncthreads();
+    if (w > 0 || qi >= n) return;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) merge(s_b[i][lane], s_sb[i][lane], s_blk[i][lane]);
+    float q[D];
+    const float cmax = __int_as_float(header[1]);
+    float qd = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        q[d] = queries[qi * D + d];
+        const float e = fabsf(q[d]) + cmax;
+        qd = fmaf(e, e, qd);
+    }
+    const float tol = fmaf(0x1p-17f, qd, 1e-35f);  // 128 u Qd
+    if (!(sb - b > tol)) {  // also every non-finite case
+        list[atomicAdd(header, 1)] = (int32_t)qi;
+        return;
+    }
+    const int base = (blk >> 1) * 32 + 4 * (blk & 1);
+    float best = INFINITY;
+    int best_i = 0x7fffffff;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {  // increasing index
+        const int c = base + 8 * (r >> 2) + (r & 3);
+        const int cl = c < k ? c : k - 1;
+        float cc[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) cc[d] = codebook[(int64_t)cl * D + d];
+        const float dist = vq_dist<D>(q, cc);
+        const bool lt = c < k && dist < best;
+        best = lt ? dist : best;
+        best_i = lt ? c : best_i;
     }
     out_idx[qi] = best_i;
 }
@@ -423,17 +693,159 @@ constexpr int VQ_QPL = 4;       // queries per lane of the scan form
 constexpr int VQ_QW = 4;        // queries per wave of the wavefront form
 constexpr int64_t VQ_WAVE_MAX_N = 5120;  // below this many queries the wavefront form fills the chip better (measured crossover at K = 117 649: 4096-8192)
 
-template <int D>
-int launch_vq_t(hipStream_t s, const float* queries, int64_t n, const float* codebook, int k, int parts, int k_per_part,
-                float* part_dist, int32_t* part_idx, bool wave_form) {
-    if (wave_form) {
-        const dim3 grid((unsigned)ceil_div64(n, 4 * VQ_QW), (unsigned)parts);
-        hipLaunchKernelGGL((vq_wave_kernel<D, VQ_QW>), grid, dim3(256), 0, s, queries, n, codebook, k, k_per_part, part_dist, part_idx);
-    } else {
-        const dim3 grid((unsigned)ceil_div64(n, 4 * 64 * VQ_QPL), (unsigned)parts);
-        hipLaunchKernelGGL((vq_scan_kernel<D, VQ_QPL>), grid, dim3(256), 0, s, queries, n, codebook, k, k_per_part, part_dist, part_idx);
+enum VqForm { VQ_WAVE, VQ_SCAN, VQ_SCREEN };
+
+struct VqPlan {
+    VqForm form;
+    int parts;           // codebook index ranges of the first kernel
+    int k_per_part;      // (screened form: a multiple of 32)
+    int parts_exact;     // screened form: index ranges of the exact pass over the listed queries
+    int k_padded;        // screened form: k rounded up to whole tiles
+    size_t off_norms, off_list, off_a, off_b, off_c, off_xd, off_xi, bytes;  // scratch layout (bytes)
+};
+
+std::atomic<int> g_vq_force_scan{0};  // test hook l3ac_set_vq_form
+constexpr int VQ_SCREEN_ROUNDS = 8;
+constexpr int VQ_SCREEN_WGS_PER_CU = 3;  // <= 168 registers per lane
+constexpr int VQ_SCREEN_LDS = (160 * 1024 / VQ_SCREEN_WGS_PER_CU) & ~255;  // requested, not used: pins that many workgroups per CU
+
+int device_cu_count() {
+    static const int cus = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    return cus;
+}
+
+VqForm vq_form(int64_t n) {
+    if (n < VQ_WAVE_MAX_N) return VQ_WAVE;
+    return g_vq_force_scan.load(std::memory_order_relaxed) ? VQ_SCAN : VQ_SCREEN;
+}
+
+// How the codebook is cut: enough (query group, slice) work items for ~8 waves per SIMD at the scan form, ~4 at the wave form,
+// ~16 rounds of waves at the screened form
+VqPlan vq_plan(int64_t n, int k) {
+    VqPlan pl{};
+    pl.form = vq_form(n);
+    auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    if (pl.form == VQ_SCREEN) {
+        // Work items (4 waves = 4 * 32 NQ queries, one index range) are equal in cost, so their number is made to FILL a whole
+        // number of rounds of the chip (VQ_SCREEN_WGS_PER_CU workgroups per CU run at a time: the launch pins that with its LDS
+        // request): 4 200 items on 1 024 places take five rounds, 4 032 take four.
+        const int n_tiles = (k + 31) / 32;
+        const int64_t groups_q = ceil_div64(n, 4 * 32 * VQ_SCREEN_NQ);
+        const int64_t places = (int64_t)device_cu_count() * VQ_SCREEN_WGS_PER_CU;
+        int64_t parts = (VQ_SCREEN_ROUNDS * places) / groups_q;  // rounded down: at most ROUNDS full rounds
+        const int64_t max_parts = ceil_div64(n_tiles, 16);
+        if (parts > max_parts) parts = max_parts;
+        if (parts < 1) parts = 1;
+        const int tiles_per_part = (int)ceil_div64(n_tiles, parts);
+        pl.parts = (int)ceil_div64(n_tiles, tiles_per_part);
+        pl.k_per_part = tiles_per_part * 32;
+        pl.k_padded = n_tiles * 32;
+        // the exact pass runs after the partial minima have been consumed and reuses their 12 n parts bytes (8 n per range)
+        int64_t pe = ceil_div64(k, 512);
+        const int64_t pe_max = (int64_t)pl.parts * 3 / 2;
+        if (pe > pe_max) pe = pe_max;
+        if (pe > 256) pe = 256;
+        if (pe < 1) pe = 1;
+        pl.parts_exact = (int)pe;
+        size_t off = align(VQ_HDR_FLOATS * 4);
+        pl.off_norms = off; off = align(off + (size_t)pl.k_padded * 4);
+        pl.off_list = off;  off = align(off + (size_t)n * 4);
+        const size_t third = align((size_t)pl.parts * n * 4);
+        size_t exact = align((size_t)pl.parts_exact * n * 4);
+        pl.off_a = off;
+        pl.off_b = off + third;
+        pl.off_c = off + 2 * third;
+        pl.off_xd = off;
+        pl.off_xi = off + exact;
+        off += (3 * third > 2 * exact ? 3 * third : 2 * exact);
+        pl.bytes = off;
+        return pl;
     }
-    L3AC_LAUNCH_CHECK();
+    const bool wave_form = pl.form == VQ_WAVE;
+    const int64_t waves_q = wave_form ? ceil_div64(n, VQ_QW) : ceil_div64(n, 64 * VQ_QPL);
+    int64_t parts = ceil_div64(wave_form ? 4096 : 8192, waves_q);
+    const int64_t max_parts = ceil_div64(k, wave_form ? 1024 : 512);  // a slice should still amortise its prologue
+    if (parts > max_parts) parts = max_parts;
+    if (parts < 1) parts = 1;
+    pl.parts = (int)parts;
+    pl.k_per_part = (int)ceil_div64(k, parts);
+    pl.off_a = 0;
+    pl.off_b = (size_t)pl.parts * n * 4;
+    pl.bytes = (size_t)pl.parts * n * 8;
+    return pl;
+}
+
+template <int D>
+int launch_vq_t(hipStream_t s, const float* queries, int64_t n, const float* codebook, int k, const VqPlan& pl, char* scratch,
+                int32_t* out_idx) {
+    const double flop = 3.0 * D * (double)n * k, bytes = 4.0 * ((double)n * D + (double)k * D + n);
+    if (pl.form != VQ_SCREEN) {
+        float* part_dist = reinterpret_cast<float*>(scratch + pl.off_a);
+        int32_t* part_idx = reinterpret_cast<int32_t*>(scratch + pl.off_b);
+        {
+            ProfScope prof(s, pl.form == VQ_WAVE ? "vq_wave_kernel" : "vq_scan_kernel", flop, bytes);
+            if (pl.form == VQ_WAVE) {
+                const dim3 grid((unsigned)ceil_div64(n, 4 * VQ_QW), (unsigned)pl.parts);
+                hipLaunchKernelGGL((vq_wave_kernel<D, VQ_QW>), grid, dim3(256), 0, s, queries, n, codebook, k, pl.k_per_part, part_dist,
+                                   part_idx, (const int32_t*)nullptr, (const int32_t*)nullptr);
+            } else {
+                const dim3 grid((unsigned)ceil_div64(n, 4 * 64 * VQ_QPL), (unsigned)pl.parts);
+                hipLaunchKernelGGL((vq_scan_kernel<D, VQ_QPL>), grid, dim3(256), 0, s, queries, n, codebook, k, pl.k_per_part, part_dist,
+                                   part_idx);
+            }
+            L3AC_LAUNCH_CHECK();
+        }
+        const int64_t cblocks = ceil_div64(n, 64);
+        hipLaunchKernelGGL(vq_argmin_combine_kernel, dim3((unsigned)(cblocks < 4096 ? cblocks : 4096)), dim3(THREADS), 0, s, part_dist, part_idx,
+                           n, pl.parts, out_idx, (const int32_t*)nullptr, (const int32_t*)nullptr);
+        L3AC_LAUNCH_CHECK();
+        return L3AC_OK;
+    }
+    int32_t* header = reinterpret_cast<int32_t*>(scratch);
+    float* norms = reinterpret_cast<float*>(scratch + pl.off_norms);
+    int32_t* list = reinterpret_cast<int32_t*>(scratch + pl.off_list);
+    float* part_b = reinterpret_cast<float*>(scratch + pl.off_a);
+    float* part_sb = reinterpret_cast<float*>(scratch + pl.off_b);
+    int32_t* part_blk = reinterpret_cast<int32_t*>(scratch + pl.off_c);
+    float* x_dist = reinterpret_cast<float*>(scratch + pl.off_xd);
+    int32_t* x_idx = reinterpret_cast<int32_t*>(scratch + pl.off_xi);
+    L3AC_HIP_CHECK(hipMemsetAsync(header, 0, VQ_HDR_FLOATS * 4, s));
+    {
+        ProfScope prof(s, "vq_norms_kernel", 2.0 * D * k, 4.0 * (D + 1) * k);
+        hipLaunchKernelGGL((vq_norms_kernel<D>), dim3((unsigned)ceil_div64(pl.k_padded, THREADS)), dim3(THREADS), 0, s, codebook, k,
+                           pl.k_padded, norms, reinterpret_cast<unsigned*>(header));
+        L3AC_LAUNCH_CHECK();
+    }
+    {
+        ProfScope prof(s, "vq_screen_kernel", flop, bytes);
+        const dim3 grid((unsigned)ceil_div64(n, 4 * 32 * VQ_SCREEN_NQ), (unsigned)pl.parts);
+        hipLaunchKernelGGL((vq_screen_kernel<D, VQ_SCREEN_NQ>), grid, dim3(256), VQ_SCREEN_LDS, s, queries, n, codebook, norms, k,
+                           pl.k_per_part / 32, part_b, part_sb, part_blk);
+        L3AC_LAUNCH_CHECK();
+    }
+    {
+        ProfScope prof(s, "vq_resolve_kernel", 3.0 * D * 16 * (double)n, 12.0 * pl.parts * (double)n);
+        hipLaunchKernelGGL((vq_resolve_kernel<D>), dim3((unsigned)ceil_div64(n, 64)), dim3(THREADS), 0, s, queries, n, codebook, k,
+                           pl.parts, part_b, part_sb, part_blk, header, list, out_idx);
+        L3AC_LAUNCH_CHECK();
+    }
+    {   // the listed queries, direct form over the whole codebook (blocks past the list's end return at once)
+        ProfScope prof(s, "vq_wave_kernel", 0.0, 0.0);
+        const int kpp = (int)ceil_div64(k, pl.parts_exact);
+        const int64_t cols = ceil_div64(n, 4 * VQ_QW);
+        const dim3 grid((unsigned)(cols < 64 ? cols : 64), (unsigned)pl.parts_exact);
+        hipLaunchKernelGGL((vq_wave_kernel<D, VQ_QW>), grid, dim3(256), 0, s, queries, n, codebook, k, kpp, x_dist, x_idx,
+                           (const int32_t*)list, (const int32_t*)header);
+        L3AC_LAUNCH_CHECK();
+        const int64_t cblocks = ceil_div64(n, 64);
+        hipLaunchKernelGGL(vq_argmin_combine_kernel, dim3((unsigned)(cblocks < 64 ? cblocks : 64)), dim3(THREADS), 0, s, x_dist, x_idx, n,
+                           pl.parts_exact, out_idx, (const int32_t*)list, (const int32_t*)header);
+        L3AC_LAUNCH_CHECK();
+    }
     return L3AC_OK;
 }
 
@@ -474,43 +886,25 @@ int launch_fsq(hipStream_t s, const FsqArgs& a) {
     }
 }
 
-// How the codebook is cut: enough (query group, slice) work items for ~8 waves per SIMD at the scan form, ~4 at the wave form
-int vq_argmin_parts(int64_t n, int k) {
-    const bool wave_form = n < VQ_WAVE_MAX_N;
-    const int64_t waves_q = wave_form ? ceil_div64(n, VQ_QW) : ceil_div64(n, 64 * VQ_QPL);
-    int64_t parts = ceil_div64(wave_form ? 4096 : 8192, waves_q);
-    const int64_t max_parts = ceil_div64(k, wave_form ? 1024 : 512);  // a slice should still amortise its prologue
-    if (parts > max_parts) parts = max_parts;
-    if (parts < 1) parts = 1;
-    return (int)parts;
-}
-size_t vq_argmin_scratch_bytes(int64_t n, int k) { return (size_t)vq_argmin_parts(n, k) * (size_t)n * 8; }
+void vq_set_form(int form) { g_vq_force_scan.store(form == 1, std::memory_order_relaxed); }
+size_t vq_argmin_scratch_bytes(int64_t n, int k) { return vq_plan(n, k).bytes; }
 
-// scratch = vq_argmin_scratch_bytes(n, k) bytes (partial distances, then partial indices)
+// scratch = vq_argmin_scratch_bytes(n, k) bytes
 int launch_vq_argmin(hipStream_t s, const float* queries, int64_t n, const float* codebook, int k, int dim, void* scratch,
                      int32_t* out_idx) {
     L3AC_REQUIRE(dim >= 1 && dim <= 8 && k > 0 && n >= 0, "vq_argmin: bad shape (dim=%d k=%d)", dim, k);
+    L3AC_REQUIRE(n < ((int64_t)1 << 31), "vq_argmin: %lld queries exceed the 32-bit query numbers of one call", (long long)n);
     if (n == 0) return L3AC_OK;
-    const int parts = vq_argmin_parts(n, k);
-    const int k_per_part = (int)ceil_div64(k, parts);
-    float* part_dist = reinterpret_cast<float*>(scratch);
-    int32_t* part_idx = reinterpret_cast<int32_t*>(part_dist + (size_t)parts * n);
-    const bool wave_form = n < VQ_WAVE_MAX_N;
-    {
-        ProfScope prof(s, wave_form ? "vq_wave_kernel" : "vq_scan_kernel", 3.0 * dim * (double)n * k, 4.0 * ((double)n * dim + (double)k * dim + n));
-        switch (dim) {
-            case 1: L3AC_TRY(launch_vq_t<1>(s, queries, n, codebook, k, parts, k_per_part, part_dist, part_idx, wave_form)); break;
-            case 2: L3AC_TRY(launch_vq_t<2>(s, queries, n, codebook, k, parts, k_per_part, part_dist, part_idx, wave_form)); break;
-            case 3: L3AC_TRY(launch_vq_t<3>(s, queries, n, codebook, k, parts, k_per_part, part_dist, part_idx, wave_form)); break;
-            case 4: L3AC_TRY(launch_vq_t<4>(s, queries, n, codebook, k, parts, k_per_part, part_dist, part_idx, wave_form)); break;
-            case 5: L3AC_TRY(launch_vq_t<5>(s, queries, n, codebook, k, parts, k_per_part, part_dist, part_idx, wave_form)); break;
-            case 6: L3AC_TRY(launch_vq_t<6>(s, queries, n, codebook, k, parts, k_per_part, part_dist, part_idx, wave_form)); break;
-            case 7: L3AC_TRY(launch_vq_t<7>(s, queries, n, codebook, k, parts, k_per_part, part_dist, part_idx, wave_form)); break;
-            default: L3AC_TRY(launch_vq_t<8>(s, queries, n, codebook, k, parts, k_per_part, part_dist, part_idx, wave_form)); break;
-        }
+    const VqPlan pl = vq_plan(n, k);
+    char* sc = reinterpret_cast<char*>(scratch);
+    switch (dim) {
+        case 1: return launch_vq_t<1>(s, queries, n, codebook, k, pl, sc, out_idx);
+        case 2: return launch_vq_t<2>(s, queries, n, codebook, k, pl, sc, out_idx);
+        case 3: return launch_vq_t<3>(s, queries, n, codebook, k, pl, sc, out_idx);
+        case 4: return launch_vq_t<4>(s, queries, n, codebook, k, pl, sc, out_idx);
+        case 5: return launch_vq_t<5>(s, queries, n, codebook, k, pl, sc, out_idx);
+        case 6: return launch_vq_t<6>(s, queries, n, codebook, k, pl, sc, out_idx);
+        case 7: return launch_vq_t<7>(s, queries, n, codebook, k, pl, sc, out_idx);
+        default: return launch_vq_t<8>(s, queries, n, codebook, k, pl, sc, out_idx);
     }
-    hipLaunchKernelGGL(vq_argmin_combine_kernel, dim3((unsigned)ceil_div64(n, THREADS)), dim3(THREADS), 0, s, part_dist,
-                       part_idx, n, parts, out_idx);
-    L3AC_LAUNCH_CHECK();
-    return L3AC_OK;
 }

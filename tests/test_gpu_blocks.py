@@ -398,11 +398,12 @@ def test_vq_argmin_matches_closed_form():
 
 
 def test_vq_argmin_scan_form_and_ties():
-    """The scan form (N >= 5120 queries: per-block minima, winner recovered afterwards) against the wavefront form on the same
-    queries, on a codebook with exact duplicates: both must return the LOWEST index among bit-identical distances, across block
-    (4 codes), slice and ragged-tail boundaries."""
+    """The two many-query forms (N >= 5120) against the wavefront form on the same queries, on a codebook with exact duplicates:
+    the direct-form scan (per-block minima, winner recovered afterwards) and the screened form (matrix-core scores choose a block of
+    16 candidates or send the query to the full direct-form search) must both return the LOWEST index among bit-identical
+    distances, across block, tile, slice and ragged-tail boundaries, for every dimension's template."""
     g = torch.Generator().manual_seed(5)
-    for k, d in ((4999, 6), (1030, 3)):
+    for k, d in ((4999, 6), (1030, 3), (777, 1), (2050, 8), (640, 5)):
         base = torch.randn(k, d, generator=g)
         cb = base.clone()
         dup = torch.randperm(k, generator=g)[: k // 3]
@@ -411,9 +412,14 @@ def test_vq_argmin_scan_form_and_ties():
         cb[-1] = cb[0]                                     # ... including the very last code of the ragged tail
         q = torch.randn(20000, d, generator=g)
         q[:2000] = cb[torch.randint(0, k, (2000,), generator=g)]  # queries ON codes: zero distance, many ties
-        scan = G.vq_argmin(q.cuda(), cb.cuda()).cpu()
+        q[2000:2100] = 0.5 * (cb[:100] + cb[100:200])      # queries midway between two codes: near-ties of the scores
+        info = {}
+        screen = G.vq_argmin(q.cuda(), cb.cuda(), info=info).cpu()
+        scan = G.vq_argmin(q.cuda(), cb.cuda(), form=1).cpu()
         wave = torch.cat([G.vq_argmin(q[i:i + 5000].cuda(), cb.cuda()).cpu() for i in range(0, 20000, 5000)])
         assert torch.equal(scan, wave)
+        assert torch.equal(screen, wave), f"k={k} d={d}: {(screen != wave).sum().item()} differ"
+        assert 0 < info["listed"] < 20000                  # duplicates went to the full search, clear winners did not
         # lowest index among identical rows: the winner is the first occurrence of its row
         rows = {}
         for i, r in enumerate(cb.numpy().tobytes()[j * 4 * d:(j + 1) * 4 * d] for j in range(k)):
@@ -423,3 +429,29 @@ def test_vq_argmin_scan_form_and_ties():
         dist = torch.cdist(q.double(), cb.double())
         gap = dist.gather(1, scan.long().unsqueeze(1)).squeeze(1) - dist.min(1).values
         assert (gap.abs() < 1e-5).all()
+
+
+def test_vq_argmin_screened_form_fsq_grids():
+    """Screened form == direct-form scan, every query, on the two FSQ codebooks at the headline batch's query counts — including
+    queries placed exactly on and one ulp around the half-way planes between grid points, where the matrix-core scores of two
+    codes agree to the last bits — and the share of queries that needed the full direct-form search stays small."""
+    for levels, n in (([7] * 6, 15360), ([9, 9, 9, 7, 7, 7], 42752)):
+        g = torch.Generator().manual_seed(23)
+        cb = O.codebook(levels)
+        q = torch.tanh(torch.randn(n, len(levels), generator=g) * 1.2)
+        lv = torch.tensor(levels, dtype=torch.float32)
+        half = (torch.randint(0, 6, (3000, len(levels)), generator=g).float() + 0.5) / (lv - 1) * 2 - 1  # half-way planes
+        pick = torch.rand(3000, len(levels), generator=g) < 0.3
+        q[:3000] = torch.where(pick, half, q[:3000])
+        q[3000:4000] = torch.nextafter(q[:1000], torch.ones(()))
+        q[4000:5000] = torch.nextafter(q[:1000], -torch.ones(()))
+        info = {}
+        screen = G.vq_argmin(q.cuda(), cb.cuda(), info=info).cpu()
+        scan = G.vq_argmin(q.cuda(), cb.cuda(), form=1).cpu()
+        assert torch.equal(screen, scan), f"levels={levels}: {(screen != scan).sum().item()} differ"
+        assert info["listed"] < 5000 + 0.03 * n, info
+    # non-finite and huge queries take the full search and return what the scan returns
+    q = torch.randn(6000, 6)
+    q[5] = float("nan"); q[6, 2] = float("inf"); q[7] = 1e30; q[8] = -3e38
+    cb = O.codebook([7] * 6)
+    assert torch.equal(G.vq_argmin(q.cuda(), cb.cuda()).cpu(), G.vq_argmin(q.cuda(), cb.cuda(), form=1).cpu())
