@@ -26,6 +26,8 @@
 //     chunks XOR-swizzled exactly as the LDS tile wants them, so a k tile of a column block is 24 KB contiguous in
 //     HBM/L2 and is copied to LDS verbatim (coalesced 1 KB per wave instruction), double-buffered.
 //   * XCD-aware block -> tile order as in gemm_f32.hip.
+#include <type_traits>
+
 #include "../kernels.hpp"
 #include "device_math.hpp"
 #include "gemm_epilogue.hpp"
@@ -295,7 +297,10 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmArgs& p, f32x4a (&acc)
 #ifdef L3AC_SPLIT_STAMPS  // diagnostic build (tools/split_stamps.py): per-phase s_memtime sums of wave 0 of the first 4096 blocks
 __device__ long long g_split_stamps[8 * 4096];
 #endif
-template <bool KTAIL, int RG>
+// DEEP: the W tiles are requested TWO k tiles ahead through two register sets (the same MFMAs in the same order: same bits).
+// With one block per CU — a single clip's products: 8-32 blocks — nothing else covers the half k tile between a W request and
+// its LDS store, and every k tile waited ~1.5 us for it; the 24 extra registers would cost the full grids their third block per CU.
+template <bool KTAIL, int RG, bool DEEP>
 __device__ __forceinline__ void gemm_split_body16(const GemmArgs& p, const int gp) {
     constexpr int WM = 16 * RG;   // rows per wave
     constexpr int BMW = 4 * WM;   // rows per block
@@ -328,7 +333,7 @@ __device__ __forceinline__ void gemm_split_body16(const GemmArgs& p, const int g
     const unsigned char* w_src = p.w_img + (int64_t)(n0 / BN) * n_tiles * W_TILE + 16 * tid;
 
     float4 a_pre[2][2 * RG];  // [k tile parity][row group x 2 float4]
-    u32x4 w_reg[W_LOADS];
+    u32x4 w_reg[DEEP ? 2 : 1][W_LOADS];
     auto load_a = [&](int kt, float4 (&dst)[2 * RG]) __attribute__((always_inline)) {
         int o = kt * BK;
         if (KTAIL) {  // the last tile's groups beyond k re-read the row's last valid group: finite values on the image's zero padding
@@ -341,15 +346,18 @@ __device__ __forceinline__ void gemm_split_body16(const GemmArgs& p, const int g
             dst[2 * h + 1] = *reinterpret_cast<const float4*>(a_row[h] + o + 4);
         }
     };
-    auto load_w = [&](int kt) __attribute__((always_inline)) {
+    auto load_w = [&](int kt, auto set) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < W_LOADS; ++i) w_reg[i] = *reinterpret_cast<const u32x4*>(w_src + (int64_t)kt * W_TILE + 16 * THREADS * i);
+        for (int i = 0; i < W_LOADS; ++i)
+            w_reg[decltype(set)::value][i] = *reinterpret_cast<const u32x4*>(w_src + (int64_t)kt * W_TILE + 16 * THREADS * i);
     };
-    auto store_w = [&](int buf) __attribute__((always_inline)) {
+    auto store_w = [&](int buf, auto set) __attribute__((always_inline)) {
         unsigned char* base = smem_split + buf * W_TILE + 16 * tid;
 #pragma unroll
-        for (int i = 0; i < W_LOADS; ++i) *reinterpret_cast<u32x4*>(base + 16 * THREADS * i) = w_reg[i];
+        for (int i = 0; i < W_LOADS; ++i) *reinterpret_cast<u32x4*>(base + 16 * THREADS * i) = w_reg[decltype(set)::value][i];
     };
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, DEEP ? 1 : 0>;
     // planes read in the order 2, 1, 0: the first MFMA of a column tile takes plane 0 of the weights, the YOUNGEST read, so the one
     // s_waitcnt in front of it covers all three (LDS returns in order) instead of one wait per plane
     auto read_b = [&](const unsigned char* ws, int t, bf16x8 (&b)[3]) __attribute__((always_inline)) {
@@ -365,8 +373,9 @@ __device__ __forceinline__ void gemm_split_body16(const GemmArgs& p, const int g
 
     load_a(0, a_pre[0]);
     load_a(last < 1 ? last : 1, a_pre[1]);
-    load_w(0);
-    store_w(0);
+    load_w(0, Set0{});
+    store_w(0, Set0{});
+    if (DEEP) load_w(last < 1 ? last : 1, Set1{});  // tile 1 waits in the second set for step 0's store
     __syncthreads();
     // straight-line body: tile indices are clamped instead of branched on, which keeps hipcc's s_waitcnt counts exact
 #ifdef L3AC_SPLIT_STAMPS
@@ -374,12 +383,19 @@ __device__ __forceinline__ void gemm_split_body16(const GemmArgs& p, const int g
     const long long t_begin = (long long)__builtin_amdgcn_s_memtime();
 #define SPLIT_STAMP() ((long long)__builtin_amdgcn_s_memtime())
 #endif
-    auto step = [&](int kt, float4 (&cur)[2 * RG]) __attribute__((always_inline)) {
+    // (odd: the step's parity — which register set receives this step's W request and which one is stored)
+    auto step = [&](int kt, float4 (&cur)[2 * RG], auto odd) __attribute__((always_inline)) {
+        using Mine = std::integral_constant<int, DEEP ? decltype(odd)::value : 0>;       // receives tile kt + 2 (DEEP) / kt + 1
+        using Next = std::integral_constant<int, DEEP ? 1 - decltype(odd)::value : 0>;   // holds tile kt + 1: stored in this step
         const int buf = kt & 1;
 #ifdef L3AC_SPLIT_STAMPS
         const long long s0 = SPLIT_STAMP();
 #endif
-        load_w(kt + 1 < last ? kt + 1 : last);
+        if (DEEP) {  // (tile kt + 1 was requested during step kt - 1 / in the prologue)
+            load_w(kt + 2 < last ? kt + 2 : last, Mine{});
+        } else {
+            load_w(kt + 1 < last ? kt + 1 : last, Mine{});
+        }
         u32x4 af[RG][3];
 #pragma unroll
         for (int h = 0; h < RG; ++h) {
@@ -403,6 +419,35 @@ __device__ __forceinline__ void gemm_split_body16(const GemmArgs& p, const int g
         const long long s1 = SPLIT_STAMP();
         t_split += s1 - s0;
 #endif
+        if constexpr (DEEP) {
+            // Alone on its SIMD a wave issues the six products of one accumulator one MFMA latency apart (~36 instead of 16 cycles:
+            // 3.5 k of a k tile's 3.7 k cycles).  Two column tiles x RG row groups are therefore kept in flight: four accumulators
+            // take turns, each one's own order of products unchanged (same bits).
+            constexpr int UT = 4 / RG;  // column tiles taken together
+            bf16x8 bq[2 * UT][3];
+#pragma unroll
+            for (int u = 0; u < UT; ++u) read_b(ws, u, bq[u]);
+            constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+            for (int t = 0; t < 8; t += UT) {
+                const int cur = (t / UT) & 1;
+                if (t + UT < 8) {
+#pragma unroll
+                    for (int u = 0; u < UT; ++u) read_b(ws, t + UT + u, bq[UT * (cur ^ 1) + u]);
+                }
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+#pragma unroll
+                    for (int u = 0; u < UT; ++u)
+#pragma unroll
+                        for (int h = 0; h < RG; ++h)
+                            acc[h][t + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[h][PA[q]]),
+                                                                                   bq[UT * cur + u][PB[q]], acc[h][t + u], 0, 0, 0);
+#ifndef L3AC_SPLIT_STAMPS
+                if (t + UT == 4) store_w(buf ^ 1, Next{});
+#endif
+            }
+        } else {
         bf16x8 bq[2][3];
         read_b(ws, 0, bq[0]);
 #pragma unroll
@@ -422,14 +467,15 @@ __device__ __forceinline__ void gemm_split_body16(const GemmArgs& p, const int g
                 acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc[h][t], 0, 0, 0);
             }
 #ifndef L3AC_SPLIT_STAMPS
-            if (t == 3) store_w(buf ^ 1);
+            if (t == 3) store_w(buf ^ 1, Next{});
 #endif
+        }
         }
 #ifdef L3AC_SPLIT_STAMPS
         asm volatile("" : "+v"(acc[0][7]), "+v"(acc[RG - 1][7]));
         const long long s2 = SPLIT_STAMP();
         t_mfma += s2 - s1;
-        store_w(buf ^ 1);
+        store_w(buf ^ 1, Next{});
 #endif
         __syncthreads();
 #ifdef L3AC_SPLIT_STAMPS
@@ -437,8 +483,8 @@ __device__ __forceinline__ void gemm_split_body16(const GemmArgs& p, const int g
 #endif
     };
     for (int kt = 0; kt < n_tiles; kt += 2) {
-        step(kt, a_pre[0]);
-        if (kt + 1 < n_tiles) step(kt + 1, a_pre[1]);
+        step(kt, a_pre[0], std::integral_constant<int, 0>{});
+        if (kt + 1 < n_tiles) step(kt + 1, a_pre[1], std::integral_constant<int, 1>{});
     }
 #ifdef L3AC_SPLIT_STAMPS
     const long long t_loop_end = SPLIT_STAMP();
@@ -458,9 +504,14 @@ __device__ __forceinline__ void gemm_split_body16(const GemmArgs& p, const int g
 template <bool KTAIL, int SHAPE>
 __global__ __launch_bounds__(THREADS, 3) void gemm_split_kernel(const GemmArgs p, const int gp) {
     if constexpr (SHAPE == 16)
-        gemm_split_body16<KTAIL, 2>(p, gp);
+        gemm_split_body16<KTAIL, 2, false>(p, gp);
     else
         gemm_split_body32<KTAIL>(p, gp);
+}
+// the grid leaves CUs idle (a single clip, a streaming chunk): W requested two k tiles ahead
+template <bool KTAIL>
+__global__ __launch_bounds__(THREADS, 2) void gemm_split_kernel_few_blocks(const GemmArgs p, const int gp) {
+    gemm_split_body16<KTAIL, 1, true>(p, gp);  // 64-row blocks: twice the blocks, half the MFMAs per k tile and block
 }
 
 std::atomic<int> g_split_enabled{-1};
@@ -543,7 +594,18 @@ int launch_gemm_split(hipStream_t s, const GemmArgs& g) {
         return e && std::atoi(e) == 32;
     }();
     const bool tail = g.k % BK != 0;
-    if (shape32) {
+    static const int cus = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    if (!shape32 && blocks <= cus) {
+        const unsigned few = (unsigned)(ceil_div64(g.m, BM / 2) * ceil_div64(g.n, BN));
+        if (tail)
+            hipLaunchKernelGGL((gemm_split_kernel_few_blocks<true>), dim3(few), dim3(THREADS), 2 * W_TILE, s, g, gp);
+        else
+            hipLaunchKernelGGL((gemm_split_kernel_few_blocks<false>), dim3(few), dim3(THREADS), 2 * W_TILE, s, g, gp);
+    } else if (shape32) {
         if (tail)
             hipLaunchKernelGGL((gemm_split_kernel<true, 32>), dim3((unsigned)blocks), dim3(THREADS), 2 * W_TILE, s, g, gp);
         else
