@@ -18,7 +18,10 @@ constexpr int TILE = 256;
 constexpr int HALO = 47;  // 3 (conv) + 22 (avg 45) + 22 (max 45)
 
 
-template <int D0>
+// UNR: unroll of the 80-channel loop.  4 when the grid leaves the SIMDs a single wave each (one clip): the loop then runs at the
+// latency of its scalar weight loads, and four iterations' loads in flight are worth 76 -> 59 us; with 8 waves per SIMD (a batch)
+// the loads are covered anyway and the extra registers cost a wave of occupancy.  Same fmaf order either way.
+template <int D0, int UNR>
 __global__ __launch_bounds__(TILE) void first_block_kernel(const FirstBlockW w, const float* __restrict__ audio,
                                                           int64_t audio_stride, int samples, int frames,
                                                           float* __restrict__ y) {
@@ -97,6 +100,7 @@ __global__ __launch_bounds__(TILE) void first_block_kernel(const FirstBlockW w, 
     float out[D0];
 #pragma unroll
     for (int d = 0; d < D0; ++d) out[d] = w.b2[d];
+#pragma unroll UNR
     for (int o = 0; o < 80; ++o) {
         float s = w.b1[o];
 #pragma unroll
@@ -123,9 +127,13 @@ int launch_first_block(hipStream_t s, const FirstBlockW& w, const float* audio, 
     const dim3 grid((unsigned)ceil_div64(frames, TILE), (unsigned)batch);
     ProfScope prof(s, "first_block_kernel", 2.0 * (140.0 + 1600.0 + 81.0 * w.d0 + 164.0) * batch * frames,
                    4.0 * ((double)batch * samples + (double)batch * frames * w.d0));
+    const bool few = (int64_t)grid.x * grid.y <= 512;  // at most two workgroups per CU
     switch (w.d0) {
-#define L3AC_FB_CASE(D) \
-    case D: hipLaunchKernelGGL((first_block_kernel<D>), grid, dim3(TILE), 0, s, w, audio, audio_stride, samples, frames, y); break
+#define L3AC_FB_CASE(D)                                                                                                       \
+    case D:                                                                                                                   \
+        if (few) hipLaunchKernelGGL((first_block_kernel<D, 4>), grid, dim3(TILE), 0, s, w, audio, audio_stride, samples, frames, y); \
+        else hipLaunchKernelGGL((first_block_kernel<D, 1>), grid, dim3(TILE), 0, s, w, audio, audio_stride, samples, frames, y);    \
+        break
         L3AC_FB_CASE(8);
         L3AC_FB_CASE(16);
         L3AC_FB_CASE(24);

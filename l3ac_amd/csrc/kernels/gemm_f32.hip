@@ -413,7 +413,10 @@ int launch_gemm(hipStream_t s, const GemmArgs& g) {
         const char* e = std::getenv("L3AC_GEMM_BK");
         return e ? std::atoi(e) : 0;
     }();
-    const int bk = (bk_override == 16 || bk_override == 32) && !g.gate_yi ? bk_override : 16;  // the gated kernel exists for 16 only
+    int bk = (bk_override == 16 || bk_override == 32) && !g.gate_yi ? bk_override : 16;  // the gated kernel exists for 16 only
+    // A grid that leaves CUs idle (a single clip) runs at one block per CU: nothing covers a k tile's fetch -> LDS -> barrier chain,
+    // so take half as many of them (same k order inside every group of 8: same bits)
+    if (!bk_override && !g.gate_yi && ceil_div64(g.m, BM) * ceil_div64(g.n, 32) <= 256) bk = 32;
 #define L3AC_GEMM_LAUNCH(NT_, CONV_) (bk == 16 ? launch_one<NT_, CONV_, 16>(s, g) : launch_one<NT_, CONV_, 32>(s, g))
     if (g.epi == EPI_GEGLU) {
         L3AC_REQUIRE(g.n % 64 == 0 && !conv, "gemm: GEGLU epilogue needs interleaved 64-column tiles");
