@@ -65,8 +65,10 @@ def test_gemm_split_accuracy():
     """bf16x3 split GEMM (gemm_split.hip) against fp64: its error must stay within the fp32-MFMA kernel's own error
     budget and, in rms, not exceed the exact-fp32 kernel's error on the same operands."""
     torch.manual_seed(0)
+    # (grids of <= 256 blocks of 128 x 128 run the few-blocks variant of the kernel, larger ones the full-grid kernel: both are
+    # covered, each with a ragged N and a K tail)
     for (m, n, k, heavy) in [(1000, 192, 32, False), (257, 256, 1024, False), (129, 512, 2048, True), (1000, 200, 344, False),
-                             (384, 704, 128, True), (4096, 1024, 256, False)]:
+                             (384, 704, 128, True), (4096, 1024, 256, False), (20000, 200, 344, False), (17000, 512, 256, True)]:
         a, w, b = _rand((m, k), 1), _rand((n, k), 2, 0.1), _rand((n,), 3)
         if heavy:  # wide dynamic range inside one dot product
             a = a * torch.exp(3.0 * _rand((m, k), 4))
