@@ -59,6 +59,7 @@ int launch_gemm(hipStream_t s, const GemmArgs& g);
 bool gemm_split_enabled();                 // L3AC_GEMM_SPLIT (default 1) or the last gemm_split_set_enabled()
 void gemm_split_set_enabled(bool on);
 bool gemm_split_eligible(int n, int k);
+bool gemm_split_conv_ok(const struct GemmArgs& g);  // taps > 1 on the split route: cin % 32 == 0, plain frame-major rows
 int64_t gemm_split_image_bytes(int n, int k);
 void gemm_split_image_host(const float* w, int64_t ldw, int n, int k, unsigned char* img);  // img: host buffer
 int launch_gemm_split_image(hipStream_t s, const float* w, int64_t ldw, int n, int k, unsigned char* img);  // device

@@ -300,8 +300,11 @@ __device__ long long g_split_stamps[8 * 4096];
 // DEEP: the W tiles are requested TWO k tiles ahead through two register sets (the same MFMAs in the same order: same bits).
 // With one block per CU — a single clip's products: 8-32 blocks — nothing else covers the half k tile between a W request and
 // its LDS store, and every k tile waited ~1.5 us for it; the 24 extra registers would cost the full grids their third block per CU.
-template <bool KTAIL, int RG, bool DEEP>
+// CONV: A is an implicit 1-D convolution over the frames of a clip (GemmArgs::taps / dil / cin / frames, cin % 32 == 0 so that a k
+// tile lies inside one tap): k tile kt reads channels [c0, c0 + 32) of frame t + (tap - taps / 2) * dil, zeros outside the clip.
+template <bool KTAIL, int RG, bool DEEP, bool CONV = false>
 __device__ __forceinline__ void gemm_split_body16(const GemmArgs& p, const int gp) {
+    static_assert(!(CONV && KTAIL), "the implicit-conv A operand has whole k tiles (cin % 32 == 0)");
     constexpr int WM = 16 * RG;   // rows per wave
     constexpr int BMW = 4 * WM;   // rows per block
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_split[];
@@ -325,11 +328,16 @@ __device__ __forceinline__ void gemm_split_body16(const GemmArgs& p, const int g
 
     // rows past the edge are clamped to row 0: they only feed accumulators that are never stored
     const float* a_row[RG];
+    int a_t[RG];  // CONV: the row's frame inside its clip
 #pragma unroll
     for (int h = 0; h < RG; ++h) {
         const int64_t row = m0 + WM * wave + 16 * h + ln;
-        a_row[h] = p.a + (row < p.m ? row : 0) * p.lda + 8 * lg;
+        const int64_t rr = row < p.m ? row : 0;
+        a_row[h] = p.a + rr * p.lda + 8 * lg;
+        a_t[h] = CONV ? (int)((unsigned)rr % (unsigned)p.frames) : 0;  // (m < 2^31: checked by the launcher)
     }
+    const int conv_tiles_per_tap = CONV ? p.cin / BK : 1;
+    const int conv_half = CONV ? p.taps >> 1 : 0;
     const unsigned char* w_src = p.w_img + (int64_t)(n0 / BN) * n_tiles * W_TILE + 16 * tid;
 
     float4 a_pre[2][2 * RG];  // [k tile parity][row group x 2 float4]
@@ -339,6 +347,21 @@ __device__ __forceinline__ void gemm_split_body16(const GemmArgs& p, const int g
         if (KTAIL) {  // the last tile's groups beyond k re-read the row's last valid group: finite values on the image's zero padding
             const int kmax = p.k - 8 - 8 * lg;
             o = o < kmax ? o : kmax;
+        }
+        if constexpr (CONV) {
+            const int tap = kt / conv_tiles_per_tap;  // wave-uniform
+            const int shift = (tap - conv_half) * p.dil;
+            const int64_t delta = (int64_t)shift * p.lda + (int64_t)(kt - tap * conv_tiles_per_tap) * BK;
+#pragma unroll
+            for (int h = 0; h < RG; ++h) {
+                const int t = a_t[h] + shift;
+                const bool ok = t >= 0 && t < (int)p.frames;
+                const float* src = a_row[h] + (ok ? delta : 0);  // (outside the clip: any valid address, the values are dropped)
+                const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
+                dst[2 * h] = ok ? v0 : make_float4(0.f, 0.f, 0.f, 0.f);
+                dst[2 * h + 1] = ok ? v1 : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            return;
         }
 #pragma unroll
         for (int h = 0; h < RG; ++h) {
@@ -508,6 +531,13 @@ __global__ __launch_bounds__(THREADS, 3) void gemm_split_kernel(const GemmArgs p
     else
         gemm_split_body32<KTAIL>(p, gp);
 }
+// the implicit-convolution A operand (a kernel of its own in the profiles: its A path differs)
+__global__ __launch_bounds__(THREADS, 3) void gemm_split_conv_kernel(const GemmArgs p, const int gp) {
+    gemm_split_body16<false, 2, false, true>(p, gp);
+}
+__global__ __launch_bounds__(THREADS, 2) void gemm_split_conv_kernel_few_blocks(const GemmArgs p, const int gp) {
+    gemm_split_body16<false, 1, true, true>(p, gp);
+}
 // the grid leaves CUs idle (a single clip, a streaming chunk): W requested two k tiles ahead
 template <bool KTAIL>
 __global__ __launch_bounds__(THREADS, 2) void gemm_split_kernel_few_blocks(const GemmArgs p, const int gp) {
@@ -537,6 +567,10 @@ void gemm_split_set_enabled(bool on) { g_split_enabled.store(on ? 1 : 0, std::me
 // n < 192 would be a single 128-column block per row panel: too few workgroups at the transformer's row counts, where
 // the exact kernel's narrower tiles win (measured: 128 x 344 and 128 x 192 weights, 26 vs 45 TFLOP/s at 15360 rows)
 bool gemm_split_eligible(int n, int k) { return n >= 192 && k >= 32 && k % 8 == 0; }
+// implicit-conv A operand (taps > 1): whole k tiles inside a tap, 32-bit row arithmetic
+bool gemm_split_conv_ok(const GemmArgs& g) {
+    return g.cin > 0 && g.cin % BK == 0 && g.k == g.taps * g.cin && g.frames > 0 && g.m % g.frames == 0 && g.m < ((int64_t)1 << 31) && g.lda == g.cin;
+}
 
 int64_t gemm_split_image_bytes(int n, int k) { return (int64_t)((n + BN - 1) / BN) * ((k + BK - 1) / BK) * W_TILE; }
 
@@ -570,7 +604,9 @@ int launch_gemm_split_image(hipStream_t s, const float* w, int64_t ldw, int n, i
 
 int launch_gemm_split(hipStream_t s, const GemmArgs& g) {
     L3AC_REQUIRE(g.a && g.w_img && g.c, "split gemm: null operand");
-    L3AC_REQUIRE(g.taps == 1 && gemm_split_eligible(g.n, g.k), "split gemm: unsupported shape n=%d k=%d taps=%d", g.n, g.k, g.taps);
+    const bool conv = g.taps > 1;
+    L3AC_REQUIRE(gemm_split_eligible(g.n, g.k) && (!conv || gemm_split_conv_ok(g)), "split gemm: unsupported shape n=%d k=%d taps=%d cin=%d",
+                 g.n, g.k, g.taps, g.cin);
     L3AC_REQUIRE(g.lda % 4 == 0 && ((uintptr_t)g.a & 15) == 0 && ((uintptr_t)g.w_img & 15) == 0, "split gemm: operands must be 16-byte aligned");
     if (g.epi == EPI_GEGLU) L3AC_REQUIRE(g.n % 64 == 0, "split gemm: GEGLU epilogue needs interleaved 64-column tiles");
     if (g.epi == EPI_BIAS_RES) L3AC_REQUIRE(g.res, "split gemm: residual epilogue without residual");
@@ -580,7 +616,7 @@ int launch_gemm_split(hipStream_t s, const GemmArgs& g) {
     if (blocks <= 0) return L3AC_OK;
     L3AC_REQUIRE(blocks < (int64_t)1 << 31, "split gemm: grid too large (m=%lld n=%d)", (long long)g.m, g.n);
     char name[64];
-    std::snprintf(name, sizeof(name), "gemm_split_kernel %lldx%dx%d e%d", (long long)g.m, g.n, g.k, g.epi);
+    std::snprintf(name, sizeof(name), "%s %lldx%dx%d e%d", conv ? "gemm_split_conv_kernel" : "gemm_split_kernel", (long long)g.m, g.n, g.k, g.epi);
     const double c_cols = g.epi == EPI_GEGLU ? (double)g.ldc : (double)g.n;
     ProfScope prof(s, name, 2.0 * (double)g.m * g.n * g.k,
                    4.0 * ((double)g.m * g.k + (double)g.m * c_cols * (g.epi == EPI_BIAS_RES ? 2.0 : 1.0)) + 6.0 * (double)g.n * g.k);
@@ -599,7 +635,13 @@ int launch_gemm_split(hipStream_t s, const GemmArgs& g) {
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
         return v;
     }();
-    if (!shape32 && blocks <= cus) {
+    if (conv) {  // (whole k tiles: no tail; the 16x16x32 form only)
+        if (blocks <= cus)
+            hipLaunchKernelGGL(gemm_split_conv_kernel_few_blocks, dim3((unsigned)(ceil_div64(g.m, BM / 2) * ceil_div64(g.n, BN))), dim3(THREADS),
+                               2 * W_TILE, s, g, gp);
+        else
+            hipLaunchKernelGGL(gemm_split_conv_kernel, dim3((unsigned)blocks), dim3(THREADS), 2 * W_TILE, s, g, gp);
+    } else if (!shape32 && blocks <= cus) {
         const unsigned few = (unsigned)(ceil_div64(g.m, BM / 2) * ceil_div64(g.n, BN));
         if (tail)
             hipLaunchKernelGGL((gemm_split_kernel_few_blocks<true>), dim3(few), dim3(THREADS), 2 * W_TILE, s, g, gp);

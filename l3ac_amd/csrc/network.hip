@@ -312,7 +312,7 @@ int network_build(l3ac_ctx* ctx, const l3ac_tensor* tensors, int n_tensors) {
     // ---- decoder (modules.py:135-201) -----------------------------------------------------------------
     ctx->dec_in.cin = c.feature_dim;
     ctx->dec_in.cout = c.dec_dims[0];
-    ctx->dec_in.w = b.conv("decoder.blocks.0.weight", c.dec_dims[0], c.feature_dim, 3);
+    ctx->dec_in.w = b.gemm(b.conv("decoder.blocks.0.weight", c.dec_dims[0], c.feature_dim, 3), c.dec_dims[0], 3 * c.feature_dim);
     ctx->dec_in.b = b.copy("decoder.blocks.0.bias", c.dec_dims[0]);
     ctx->dec_units.assign(c.n_dec - 1, {});
     ctx->dec_enh.assign(c.n_dec - 1, {});
