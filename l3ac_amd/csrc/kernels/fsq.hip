@@ -505,6 +505,8 @@ __device__ __forceinline__ float vq_dist(const float (&q)[D], const float (&cc)[
 
 constexpr int VQ_HDR_FLOATS = 64;  // scratch header: [0] listed-query counter (int), [1] max |c_d| (float bits, >= 0)
 
+__global__ void vq_header_reset_kernel(int32_t* __restrict__ header) { header[threadIdx.x] = 0; }
+
 // norms[c] = |c|^2 for c < k, +inf for the padding codes of the last tile; header[1] = max |c_d|
 template <int D>
 __global__ __launch_bounds__(THREADS) void vq_norms_kernel(const float* __restrict__ codebook, int k, int k_padded,
@@ -813,7 +815,10 @@ int launch_vq_t(hipStream_t s, const float* queries, int64_t n, const float* cod
     int32_t* part_blk = reinterpret_cast<int32_t*>(scratch + pl.off_c);
     float* x_dist = reinterpret_cast<float*>(scratch + pl.off_xd);
     int32_t* x_idx = reinterpret_cast<int32_t*>(scratch + pl.off_xi);
-    L3AC_HIP_CHECK(hipMemsetAsync(header, 0, VQ_HDR_FLOATS * 4, s));
+    // (a kernel, not hipMemsetAsync: captured into a hipGraph the memset node ran on the first replay only — the counter kept
+    // growing, the list overflowed: tests/test_gpu_blocks.py::test_vq_argmin_graph_capture)
+    hipLaunchKernelGGL(vq_header_reset_kernel, dim3(1), dim3(VQ_HDR_FLOATS), 0, s, header);
+    L3AC_LAUNCH_CHECK();
     {
         ProfScope prof(s, "vq_norms_kernel", 2.0 * D * k, 4.0 * (D + 1) * k);
         hipLaunchKernelGGL((vq_norms_kernel<D>), dim3((unsigned)ceil_div64(pl.k_padded, THREADS)), dim3(THREADS), 0, s, codebook, k,

@@ -457,3 +457,36 @@ def test_vq_argmin_screened_form_fsq_grids():
     q[5] = float("nan"); q[6, 2] = float("inf"); q[7] = 1e30; q[8] = -3e38
     cb = O.codebook([7] * 6)
     assert torch.equal(G.vq_argmin(q.cuda(), cb.cuda()).cpu(), G.vq_argmin(q.cuda(), cb.cuda(), form=1).cpu())
+
+
+def test_vq_argmin_graph_capture():
+    """include/l3ac_hip.h: l3ac_vq_argmin allocates nothing and can be captured into a hipGraph — for both forms (the screened
+    form's listed-query pass sizes itself from a device counter): replays on new queries in the same buffers equal eager calls."""
+    from l3ac_amd import _capi
+    lib = _capi.load_library()
+    cb = O.codebook([7] * 6).cuda()
+    k = cb.shape[0]
+    for n in (60, 6000):
+        g = torch.Generator().manual_seed(n)
+        sets = [torch.tanh(torch.randn(n, 6, generator=g) * 1.2).cuda() for _ in range(3)]
+        sets[1][: n // 3] = cb[torch.randint(0, k, (n // 3,), generator=g).cuda()]  # queries on codes: many go to the full search
+        eager = [G.vq_argmin(q, cb) for q in sets]
+        q_static = sets[0].clone()
+        out = torch.empty(n, dtype=torch.int32, device="cuda")
+        nbytes = lib.l3ac_vq_argmin_scratch_bytes(n, k)
+        scratch = torch.zeros(max(nbytes, 4), dtype=torch.uint8, device="cuda")
+        call = lambda: _capi.check(lib.l3ac_vq_argmin(q_static.data_ptr(), n, cb.data_ptr(), k, 6, out.data_ptr(), scratch.data_ptr(),
+                                                      nbytes, torch.cuda.current_stream().cuda_stream))
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            call()
+        torch.cuda.current_stream().wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            call()
+        for i in (1, 2, 0):
+            q_static.copy_(sets[i])
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, eager[i]), f"n={n} set {i}"

@@ -513,6 +513,20 @@ def test_streaming_chunks_and_graph_capture():
         torch.cuda.synchronize()
         assert torch.equal(ind["indices"], eager[i][1]["indices"])
         assert torch.equal(wave, eager_wave[i])
+    # the decode-from-features entry copies its input into the workspace (a device-to-device copy node): replayed repeatedly too
+    static_q = eager[0][0].clone()
+    eager_wave_q = [codec.decode_audio(e[0]) for e in eager]
+    with torch.cuda.stream(s):
+        codec.decode_audio(static_q)
+    torch.cuda.current_stream().wait_stream(s)
+    graph2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph2):
+        wave_q = codec.decode_audio(static_q)
+    for i in (3, 1, 4, 1):
+        static_q.copy_(eager[i][0])
+        graph2.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(wave_q, eager_wave_q[i])
 
 
 def test_token_bit_packing_roundtrip():
