@@ -557,3 +557,31 @@ def test_token_bit_packing_roundtrip():
     assert packed.shape[1] * 8 / 1.0125 <= 1024 + 8  # 60 tokens * 17 bits = 1020 bits for 1.0125 s ~ 998 bps + padding
     wave = codec.decode_audio(indices=l3ac_amd.unpack_indices(packed, 60, 17))
     assert torch.equal(wave, codec.decode_audio(indices=ind["indices"]))
+
+
+def test_two_streams_alternate_on_one_context():
+    """include/l3ac_hip.h: a context belongs to one call at a time, and a call on another stream than the previous one first waits
+    for it (hipStreamWaitEvent) — so two torch streams may alternate on one codec without host synchronisation in between and without
+    racing on the shared workspace: every result equals the single-stream one."""
+    codec = _codec("1kbps", 0)
+    xs = [seeded_audio(3, 12000 + 500 * i).cuda() for i in range(4)]
+    ref = []
+    for x in xs:
+        q, ind = codec.encode_audio(x)
+        ref.append((ind["indices"].clone(), codec.decode_audio(indices=ind["indices"]).clone()))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    got = []
+    for rep in range(3):
+        for i, x in enumerate(xs):
+            st = streams[i & 1]
+            with torch.cuda.stream(st):
+                q, ind = codec.encode_audio(x)
+            other = streams[1 - (i & 1)]
+            other.wait_stream(st)  # (the decode below consumes tensors produced on `st`: ordinary producer/consumer ordering)
+            with torch.cuda.stream(other):
+                wave = codec.decode_audio(indices=ind["indices"])
+            got.append((i, ind["indices"], wave))
+    torch.cuda.synchronize()
+    for i, idx, wave in got:
+        assert torch.equal(idx, ref[i][0]) and torch.equal(wave, ref[i][1]), f"clip set {i}"
