@@ -114,6 +114,47 @@ def attach_traffic(roof, profiles_dir, workload_key):
         roof.update(traffic=None, traffic_source=None)
 
 
+def launch_command(n_gpus, argv, port=None):
+    """The command and environment `python bench.py --gpus N` starts for N > 1: torch.distributed.run, one rank per GPU,
+    rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    import socket
+    if port is None:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + list(argv)
+    env = {"MASTER_ADDR": "127.0.0.1", "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+           "OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS", "8")}
+    return cmd, env
+
+
+def self_launch(args):
+    """Run the N-rank bench as child processes of this (GPU-untouched) one; rank 0's JSON line is relayed as the LAST
+    line of stdout, everything else the children print goes to stderr; returns the launcher's exit code."""
+    import subprocess
+    cmd, env = launch_command(args.gpus, [a for a in sys.argv[1:] if a != "--print-launch"])
+    if args.print_launch:
+        print(json.dumps({"cmd": cmd, "env": env}))
+        return 0
+    n_dev = torch.cuda.device_count()  # counting devices does not initialise the GPU
+    if n_dev < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but this node exposes {n_dev} GPU(s)", file=sys.stderr)
+        return 2
+    proc = subprocess.run(cmd, env={**os.environ, **env}, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in proc.stdout.splitlines() if l.strip()]
+    json_line = next((l for l in reversed(lines) if l.lstrip().startswith('{"metric"')), None)
+    for l in lines:
+        if l is not json_line:
+            print(l, file=sys.stderr)
+    if json_line is not None:
+        print(json_line, flush=True)
+    elif proc.returncode == 0:
+        print("bench.py: the ranks exited 0 but printed no JSON line", file=sys.stderr)
+        return 1
+    return proc.returncode
+
+
 def time_steps(run, steps, warmup, drain=lambda: None):
     for _ in range(warmup):
         run()
@@ -154,14 +195,18 @@ def main():
                          "exact: every product on the fp32 MFMA instruction")
     ap.add_argument("--profiles-dir", default=str(REPO / "profiles" / "r02"),
                     help="directory whose traffic.json (rocprofv3 PMC summary of this workload) is attached as roofline.traffic")
+    ap.add_argument("--print-launch", action="store_true",
+                    help="with --gpus N > 1 and no WORLD_SIZE: print the torch.distributed.run command this would start, and exit")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start one fresh process per GPU BEFORE anything here touches the GPU (a process
+        # that has initialised HIP must never be replaced by exec; children are started, their exit code is returned)
+        raise SystemExit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     import torch.distributed as dist
 

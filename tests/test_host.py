@@ -218,3 +218,27 @@ def test_chunk_bookkeeping_matches_the_reference_restatement():
     assert plan(270, 5 * 16000, 1) == (79920, 270)  # reference geometry at 1kbps: window rounded to hops, one hop of overlap
     with pytest.raises(ValueError):
         plan(270, 1000, 4)
+
+
+def test_bench_self_launch_command():
+    """`python bench.py --gpus N` (no WORLD_SIZE) starts torch.distributed.run itself, one rank per GPU, rendezvous on
+    127.0.0.1: the command it would run, without touching a GPU (BASELINE.json config 4)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--print-launch"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr
+    plan = json.loads(r.stdout.strip().splitlines()[-1])
+    cmd = plan["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=2" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    script = cmd.index(str(REPO / "bench.py"))
+    assert cmd[script + 1:] == ["--gpus", "2", "--steps", "3", "--warmup", "1"]  # the ranks get the same flags, minus --print-launch
+    assert plan["env"]["MASTER_ADDR"] == "127.0.0.1" and plan["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # a rank started by the launcher (WORLD_SIZE set) with a mismatching --gpus still refuses
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       env={**env, "WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0"}, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=4" in (r.stderr + r.stdout)
