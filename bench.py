@@ -483,24 +483,20 @@ def other_configs(dev, args):
     codebook = O.codebook(levels).to(dev).contiguous()
     idx = torch.empty(n, dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
-    nbytes = lib.l3ac_vq_argmin_scratch_bytes(n, k)
+    nbytes = lib.l3ac_vq_argmin_scratch_bytes(n, k, 0)
     scratch = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
     call = lambda: _capi.check(lib.l3ac_vq_argmin(queries.data_ptr(), n, codebook.data_ptr(), k, len(levels), idx.data_ptr(),
-                                                  scratch.data_ptr(), nbytes, stream))
+                                                  scratch.data_ptr(), nbytes, 0, stream))
     steps = 5
     dt, _ = time_steps(call, steps, 2)
     listed = int(scratch[:4].view(torch.int32).item())  # screened form: queries that took the full direct-form search
     # the same call on the direct-form scan (the form the screened one must agree with on EVERY query, not only the clear ones)
-    lib.l3ac_set_vq_form(1)
-    try:
-        nb_scan = lib.l3ac_vq_argmin_scratch_bytes(n, k)
-        sc_scan = torch.empty(nb_scan, dtype=torch.uint8, device=dev)
-        idx_scan = torch.empty_like(idx)
-        call_scan = lambda: _capi.check(lib.l3ac_vq_argmin(queries.data_ptr(), n, codebook.data_ptr(), k, len(levels), idx_scan.data_ptr(),
-                                                           sc_scan.data_ptr(), nb_scan, stream))
-        dt_scan, _ = time_steps(call_scan, 3, 1)
-    finally:
-        lib.l3ac_set_vq_form(0)
+    nb_scan = lib.l3ac_vq_argmin_scratch_bytes(n, k, 1)
+    sc_scan = torch.empty(nb_scan, dtype=torch.uint8, device=dev)
+    idx_scan = torch.empty_like(idx)
+    call_scan = lambda: _capi.check(lib.l3ac_vq_argmin(queries.data_ptr(), n, codebook.data_ptr(), k, len(levels), idx_scan.data_ptr(),
+                                                       sc_scan.data_ptr(), nb_scan, 1, stream))
+    dt_scan, _ = time_steps(call_scan, 3, 1)
     _, idx_ref, _ = O.fsq_quantize(z, levels)
     lvt = torch.tensor(levels, dtype=torch.float64)
     scaled = (torch.tanh(z.double()) + 1) / 2 * (lvt - 1)

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define L3AC_ABI_VERSION 2
+#define L3AC_ABI_VERSION 3
 #define L3AC_MAX_STAGES 8
 #define L3AC_MAX_LEVELS 8
 
@@ -146,15 +146,15 @@ int l3ac_fsq_decode(const int32_t* indices, int64_t n, int32_t feat, const int32
  * The result is DEFINED by dist = sum_d (q_d - c_d)^2 accumulated with fmaf in dimension order and strict '<' over
  * increasing k; from 5 120 queries on the candidates are first screened on the fp32 matrix cores and then decided by
  * exactly that arithmetic (kernels/fsq.hip, "screened form"), so every size returns the same bits.
- * `scratch` is a caller-owned device buffer of at least l3ac_vq_argmin_scratch_bytes(n, k) bytes (partial minima of the
- * codebook slices, code norms, the list of queries that need the full direct-form search): the call allocates nothing and
- * can be captured into a hipGraph.  n < 2^31. */
-int64_t l3ac_vq_argmin_scratch_bytes(int64_t n, int32_t k);
+ * `scratch` is a caller-owned device buffer of at least l3ac_vq_argmin_scratch_bytes(n, k, form) bytes (partial minima of
+ * the codebook slices, code norms, the list of queries that need the full direct-form search): the call allocates nothing
+ * and can be captured into a hipGraph.  n < 2^31.
+ * `form`: 0 = automatic; 1 = the direct-form scan wherever the screened form would run (the two are compared by
+ * tests/test_gpu_blocks.py and timed side by side by tools/vq_argmin_bench.py).  An argument of the call, not library state:
+ * nothing another thread does can change what a call — or a graph captured from it — computes. */
+int64_t l3ac_vq_argmin_scratch_bytes(int64_t n, int32_t k, int32_t form);
 int l3ac_vq_argmin(const float* queries, int64_t n, const float* codebook, int32_t k, int32_t dim, int32_t* out_idx,
-                   void* scratch, int64_t scratch_bytes, void* stream);
-/* Test hook, process-wide: form 1 runs the direct-form scan wherever the screened form would run (the two are compared by
- * tests/test_gpu_blocks.py and timed side by side by tools/vq_argmin_bench.py); 0 = automatic.  Changes the scratch size. */
-void l3ac_set_vq_form(int32_t form);
+                   void* scratch, int64_t scratch_bytes, int32_t form, void* stream);
 
 /* ---- token wire format (no reference counterpart: the reference keeps int32 indices, vq/fsq.py:68) ---------------
  * Per clip, token t occupies bits [t*bits, (t+1)*bits) of a little-endian bit stream, zero-padded to whole 32-bit
@@ -197,9 +197,10 @@ int l3ac_op_decoder(l3ac_ctx* ctx, const float* feature, int32_t batch, int32_t 
  * mode bit 1: y = sin(x)^2 alone (the kernels' own sine; alpha is not used).
  * A test entry (it synchronises and allocates): the pipeline applies snake inside its GEMM / unit kernels. */
 int l3ac_op_snake(const float* x, float* y, int64_t rows, int32_t c, const float* alpha, int32_t mode, void* stream);
-/* Test hook, process-wide: while enabled the output head (modules.py:192-194) stores the Conv1d(c -> 1, k7) result BEFORE
- * the final tanh, so that decoder parity can be checked where tanh's saturation does not hide it. */
-void l3ac_set_head_pretanh(int32_t enable);
+/* Validation switch of ONE context: while enabled its output head (modules.py:192-194) stores the Conv1d(c -> 1, k7) result
+ * BEFORE the final tanh, so that decoder parity can be checked where tanh's saturation does not hide it.  Like every
+ * call on a context, not to be issued while another thread uses (or captures a graph on) the same context. */
+int l3ac_ctx_set_head_pretanh(l3ac_ctx* ctx, int32_t enable);
 
 /* ---- per-launch profile (measurement aid; reference has no counterpart) -------------------------------
  * Between l3ac_profile_begin() and l3ac_profile_end() every kernel launched by the calling thread is bracketed
@@ -225,15 +226,17 @@ int l3ac_gemm_f32(const float* a, int64_t lda, const float* w, const float* bias
  * Every fp32 operand is split exactly into three bf16 planes (3 x 8 significant bits = the 24-bit significand) and the
  * product is the six plane products of order <= 2, accumulated in fp32: error vs fp64 no larger than the fp32 fmaf
  * chain's (tests/test_gpu_blocks.py::test_gemm_split_accuracy), at 2.67x fewer matrix-core cycles.  The network's large
- * channel contractions use it by default; l3ac_set_gemm_split(0) (or L3AC_GEMM_SPLIT=0 in the environment) routes
- * every product through the exact v_mfma_f32_32x32x2_f32 kernel instead.  Process-wide switch.
+ * channel contractions use it by default.  The route is a property of the CONTEXT: l3ac_ctx_set_gemm_split(ctx, 0)
+ * routes every later product of that context through the exact v_mfma_f32_32x32x2_f32 kernel instead (a context starts on
+ * the split route unless L3AC_GEMM_SPLIT=0 is in the environment when it is created); other contexts, and graphs already
+ * captured from this one, are not affected.
  * (reference counterpart: none — torch.nn.functional.linear / conv1d on fp32 tensors.) */
 /* The split itself, on the HOST (no GPU needed; this is what builds the weight images): planes [3][n] bf16 bit patterns with
  * x[i] == bf16(planes[0][i]) + bf16(planes[1][i]) + bf16(planes[2][i]) exactly for every finite fp32 x[i]
  * (tests/test_host.py::test_bf16x3_split_is_exact). */
 void l3ac_split3_host(const float* x, int64_t n, uint16_t* planes);
-void l3ac_set_gemm_split(int32_t enable);
-int32_t l3ac_get_gemm_split(void);
+int l3ac_ctx_set_gemm_split(l3ac_ctx* ctx, int32_t enable);
+int32_t l3ac_ctx_get_gemm_split(const l3ac_ctx* ctx);
 /* Weight image for l3ac_gemm_split_f32: w [n][k] fp32 -> `image` (device, l3ac_gemm_split_image_bytes(n, k) bytes;
  * 0 = shape not eligible: needs n >= 192, k >= 32, k % 8 == 0). */
 int64_t l3ac_gemm_split_image_bytes(int32_t n, int32_t k);

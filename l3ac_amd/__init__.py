@@ -18,6 +18,8 @@ from __future__ import annotations
 
 import logging
 import math
+import os
+import weakref
 from pathlib import Path
 from typing import Optional
 
@@ -34,6 +36,12 @@ __version__ = "0.1.0"
 
 log = logging.getLogger("L3AC")
 
+# GEMM route: state of each Network's own HIP context.  The module-level setter below keeps the
+# round-1/2 convenience (one call switches every live network and the default of later ones) without any process-wide
+# state inside the library.
+_default_gemm_split = os.environ.get("L3AC_GEMM_SPLIT", "1") not in ("0", "")
+_networks: "weakref.WeakSet[Network]" = weakref.WeakSet()
+
 
 class Network:
     """Stands where the reference's ``EnCodec`` nn.Module stands (``codec.network``): holds the weights and the
@@ -48,6 +56,8 @@ class Network:
         # literal two-pass formula is evaluated (correct for any input) and min_grn_norm() reports the smallest g seen, i.e.
         # whether the fast path would have been exact for the data that went through.
         self.grn_exact = False
+        self.gemm_split = _default_gemm_split
+        _networks.add(self)
         self._state_dicts = None
         self._folded = None
         self._ctx: Optional[_capi.Context] = None
@@ -110,6 +120,16 @@ class Network:
         if self._folded is None:
             raise RuntimeError("no weights loaded (get_model / load_state_dicts first)")
         self._ctx = _capi.Context(self.mc, self._folded, self.device.index, grn_exact=self.grn_exact)
+        self._ctx.set_gemm_split(self.gemm_split)
+
+    def set_gemm_split(self, enable: bool) -> "Network":
+        """Route of THIS network's context: True = the large fp32 contractions as exact bf16x3 operand splits on the bf16 matrix
+        cores (default), False = every product on the exact fp32 MFMA instruction.  Not to be called while another thread
+        runs or captures a graph on this network."""
+        self.gemm_split = bool(enable)
+        if self._ctx is not None:
+            self._ctx.set_gemm_split(self.gemm_split)
+        return self
 
     def _drop_ctx(self):
         if self._ctx is not None:
@@ -215,11 +235,10 @@ class L3AC:
         audio = torch.empty((b, n_tok * mc.hop_length), dtype=torch.float32, device=src.device)
         with torch.cuda.device(src.device):
             stream = torch.cuda.current_stream(src.device).cuda_stream
-            if validate and i_ptr is not None:
-                ctx.bad_index_count(reset=True)
+            before = ctx.bad_index_count() if validate and i_ptr is not None else 0  # cumulative counter: read, never reset here
             _capi.check(ctx.lib.l3ac_decode(ctx.handle, f_ptr, i_ptr, b, n_tok, audio.data_ptr(), stream))
             if validate and i_ptr is not None:
-                bad = ctx.bad_index_count(reset=True)
+                bad = ctx.bad_index_count() - before
                 if bad:
                     raise ValueError(f"{bad} of {b * n_tok} indices lie outside [0, {mc.codebook_size}): corrupted token stream")
         del keep
@@ -240,12 +259,17 @@ class L3AC:
         return out
 
     @torch.no_grad()
-    def extract_unit(self, audio_data: torch.Tensor, process_window: int = 10 * 16000, prefix_tokens: Optional[int] = None):
+    def extract_unit(self, audio_data: torch.Tensor, process_window: int = 5 * 16000, prefix_tokens: Optional[int] = None):
         """Encode a clip of any length window by window: (1, T) audio -> (ChunkData of indices, ChunkData of q_feature), the
-        return structure of reference ``Codec.extract_unit`` (codec.py:124-147).  Unlike the reference, every chunk goes
-        through the whole encode path (``en_encoder`` included) and overlaps its predecessor by ``prefix_tokens`` tokens
-        (default: the local attention's window, i.e. its look-back) instead of one hop; equal-length chunks are batched
-        through one ``encode_audio`` call.  ``.data`` of either result is the merged token stream."""
+        return structure and the default ``process_window`` of reference ``Codec.extract_unit`` (codec.py:124-147).  Unlike
+        the reference, every chunk goes through the whole encode path (``en_encoder`` included); equal-length chunks are
+        batched through one ``encode_audio`` call.  ``.data`` of either result is the merged token stream.
+
+        ``prefix_tokens`` is the overlap of a chunk with its predecessor, in tokens.  **The default differs from the
+        reference's**: the local attention's window (its look-back, ``en_coder_window_size`` tokens) instead of ONE hop, so
+        the returned ``ChunkData.prefix_len`` is that window, not 1.  ``prefix_tokens=1`` gives exactly the reference's chunk
+        geometry (``chunk_len = process_window // hop`` tokens, ``prefix_len = 1``): such ChunkData can be merged / decoded by
+        reference code with the same arguments, and the reference's by ``decode_unit`` here."""
         assert audio_data.dim() == 2 and len(audio_data) == 1, "Only support batch size 1"  # codec.py:133
         mc = self.network.mc
         hop = mc.hop_length
@@ -282,13 +306,19 @@ class L3AC:
 
 
 def set_gemm_split(enable: bool) -> None:
-    """Process-wide: route the large fp32 channel contractions through the bf16x3 split-operand kernel (default, fp32
-    accuracy on the bf16 matrix cores) or through the exact v_mfma_f32_32x32x2_f32 kernel (include/l3ac_hip.h)."""
-    _capi.load_library().l3ac_set_gemm_split(int(bool(enable)))
+    """Route the large fp32 channel contractions of EVERY live network (and of networks created later) through the bf16x3
+    split-operand kernels (default, fp32 accuracy on the bf16 matrix cores) or through the exact v_mfma_f32_32x32x2_f32
+    kernel.  The state itself lives in each network's context (``Network.set_gemm_split``, l3ac_ctx_set_gemm_split): graphs
+    already captured keep the route they were captured on."""
+    global _default_gemm_split
+    _default_gemm_split = bool(enable)
+    for net in list(_networks):
+        net.set_gemm_split(enable)
 
 
 def get_gemm_split() -> bool:
-    return bool(_capi.load_library().l3ac_get_gemm_split())
+    """The route networks created from now on start with (and, after ``set_gemm_split``, the route of every live one)."""
+    return _default_gemm_split
 
 
 def bits_per_token(mc) -> int:

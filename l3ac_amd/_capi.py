@@ -9,7 +9,7 @@ import os
 
 # L3AC_LIB_PATH: load another build of the same library (experiment builds under tools/experiments/_build); default in-tree
 LIB_PATH = Path(os.environ.get("L3AC_LIB_PATH") or Path(__file__).resolve().parent / "libl3ac_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_STAGES = 8
 MAX_LEVELS = 8
 
@@ -60,8 +60,8 @@ SIGNATURES = {
     "l3ac_fsq_forward": (C.c_int, [_P, _I64, _I32, C.POINTER(_I32), _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "l3ac_fsq_quantize_act": (C.c_int, [_P, _I64, _I32, C.POINTER(_I32), _I32, _P, _P, _P, _P, _P, _P]),
     "l3ac_fsq_decode": (C.c_int, [_P, _I64, _I32, C.POINTER(_I32), _I32, _P, _P, _P, _P]),
-    "l3ac_vq_argmin_scratch_bytes": (_I64, [_I64, _I32]),
-    "l3ac_vq_argmin": (C.c_int, [_P, _I64, _P, _I32, _I32, _P, _P, _I64, _P]),
+    "l3ac_vq_argmin_scratch_bytes": (_I64, [_I64, _I32, _I32]),
+    "l3ac_vq_argmin": (C.c_int, [_P, _I64, _P, _I32, _I32, _P, _P, _I64, _I32, _P]),
     "l3ac_op_first_block": (C.c_int, [_P, _P, _I32, _I32, _P, _P]),
     "l3ac_op_conv_unit": (C.c_int, [_P, C.c_char_p, _P, _I32, _I32, _P, _P]),
     "l3ac_op_down_layer": (C.c_int, [_P, C.c_char_p, _P, _I32, _I32, _P, _P]),
@@ -76,12 +76,11 @@ SIGNATURES = {
     "l3ac_op_en_decoder": (C.c_int, [_P, _P, _I32, _I32, _P, _P]),
     "l3ac_op_decoder": (C.c_int, [_P, _P, _I32, _I32, _P, _P]),
     "l3ac_op_snake": (C.c_int, [_P, _P, _I64, _I32, _P, _I32, _P]),
-    "l3ac_set_head_pretanh": (None, [_I32]),
-    "l3ac_set_vq_form": (None, [_I32]),
+    "l3ac_ctx_set_head_pretanh": (C.c_int, [_P, _I32]),
     "l3ac_gemm_f32": (C.c_int, [_P, _I64, _P, _P, _P, _I64, _I64, _I32, _I32, _P]),
     "l3ac_split3_host": (None, [_P, _I64, _P]),
-    "l3ac_set_gemm_split": (None, [_I32]),
-    "l3ac_get_gemm_split": (_I32, []),
+    "l3ac_ctx_set_gemm_split": (C.c_int, [_P, _I32]),
+    "l3ac_ctx_get_gemm_split": (_I32, [_P]),
     "l3ac_gemm_split_image_bytes": (_I64, [_I32, _I32]),
     "l3ac_gemm_split_image": (C.c_int, [_P, _I32, _I32, _P, _P]),
     "l3ac_gemm_split_f32": (C.c_int, [_P, _I64, _P, _P, _P, _I64, _I64, _I32, _I32, _P]),
@@ -227,3 +226,13 @@ class Context:
 
     def reserve(self, batch: int, samples: int) -> None:
         check(self.lib.l3ac_reserve(self.handle, batch, samples))
+
+    # ---- route switches: state of THIS context only (include/l3ac_hip.h) -----------------------------------
+    def set_gemm_split(self, enable: bool) -> None:
+        check(self.lib.l3ac_ctx_set_gemm_split(self.handle, int(bool(enable))))
+
+    def get_gemm_split(self) -> bool:
+        return bool(self.lib.l3ac_ctx_get_gemm_split(self.handle))
+
+    def set_head_pretanh(self, enable: bool) -> None:
+        check(self.lib.l3ac_ctx_set_head_pretanh(self.handle, int(bool(enable))))

@@ -73,6 +73,36 @@ PER_FILE_FLAGS = {
     # vq_screen_kernel reduces every MFMA result on the vector unit at once: results in VGPRs, not AGPRs + 16 v_accvgpr_read
     "kernels/fsq.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
 }
+OPTIONAL_FLAG_FILES = {"kernels/fsq.hip"}  # flags that only affect speed: probed, dropped when hipcc does not know them
+
+
+_probe_cache = {}
+
+
+def _flags_supported(hipcc: str, extra) -> bool:
+    """Whether this hipcc accepts `extra` (compiling an empty translation unit): optional, performance-only flags are
+    dropped on toolchains that do not know them instead of failing the whole build."""
+    key = (hipcc, tuple(extra))
+    if key not in _probe_cache:
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            src = Path(td) / "probe.hip"
+            src.write_text("#include <hip/hip_runtime.h>\n__global__ void probe() {}\n")
+            r = subprocess.run([hipcc, f"--offload-arch={ARCH}", *extra, "-c", str(src), "-o", str(Path(td) / "probe.o")],
+                               capture_output=True, text=True)
+            base = subprocess.run([hipcc, f"--offload-arch={ARCH}", "-c", str(src), "-o", str(Path(td) / "probe0.o")],
+                                  capture_output=True, text=True)
+        # (if even the plain probe fails, the probe itself is broken: keep the flags and let the real compile speak)
+        _probe_cache[key] = r.returncode == 0 or base.returncode != 0
+    return _probe_cache[key]
+
+
+def _per_file_flags(hipcc: str, src: str):
+    extra = PER_FILE_FLAGS.get(src, [])
+    if src in OPTIONAL_FLAG_FILES and extra and not _flags_supported(hipcc, extra):
+        print(f"[build] hipcc does not accept {' '.join(extra)}: {src} is built without it (slower vq_screen_kernel)", file=sys.stderr)
+        return []
+    return extra
 
 
 def _flag_stamp(hipcc: str, flags) -> str:
@@ -80,7 +110,7 @@ def _flag_stamp(hipcc: str, flags) -> str:
     and the compiler version.  A change forces a full rebuild."""
     import hashlib
     ver = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout
-    per_file = "\n".join(f"{k}: {' '.join(v)}" for k, v in sorted(PER_FILE_FLAGS.items()))
+    per_file = "\n".join(f"{k}: {' '.join(_per_file_flags(hipcc, k))}" for k in sorted(PER_FILE_FLAGS))  # as probed
     return hashlib.sha256(("\n".join(flags) + "\n" + per_file + "\n" + ver).encode()).hexdigest()
 
 
@@ -106,7 +136,7 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
             newest = max(s.stat().st_mtime, _depfile_newest(d) if d.exists() else hdr_time)
             stale = o.stat().st_mtime < newest
         if stale:
-            jobs.append([hipcc, *flags, *PER_FILE_FLAGS.get(src, []), "-MD", "-MF", str(d), "-c", str(s), "-o", str(o)])
+            jobs.append([hipcc, *flags, *_per_file_flags(hipcc, src), "-MD", "-MF", str(d), "-c", str(s), "-o", str(o)])
 
     def run(cmd):
         if verbose:
@@ -120,11 +150,19 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
     with ThreadPoolExecutor(max_workers=min(4, os.cpu_count() or 1)) as pool:
         list(pool.map(run, jobs))
     stamp_file.write_text(stamp + "\n")
-    if jobs or not LIB_PATH.exists():
+    linked = bool(jobs) or not LIB_PATH.exists()
+    if linked:
         run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(LIB_PATH), *map(str, objs)])
+    global last_build_report
+    last_build_report = {"objects": len(objs), "compiled": len(jobs), "reused": len(objs) - len(jobs), "linked": linked,
+                         "forced": bool(force)}
     return LIB_PATH
+
+
+last_build_report = None  # what the last build_library() call did: {"objects", "compiled", "reused", "linked", "forced"}
 
 
 if __name__ == "__main__":
     path = build_library(force="--force" in sys.argv, verbose=True)
-    print(f"built {path} ({path.stat().st_size / 1e6:.1f} MB)")
+    r = last_build_report
+    print(f"built {path} ({path.stat().st_size / 1e6:.1f} MB): {r['compiled']} of {r['objects']} objects compiled, {r['reused']} reused")

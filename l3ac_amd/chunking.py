@@ -3,8 +3,9 @@ chunk plan of the corrected long-audio path (``L3AC.extract_unit`` / ``L3AC.deco
 
 The reference's ``extract_unit`` / ``decode_unit`` (codec.py:124-156) cut a clip into windows that overlap their predecessor
 by ONE hop, run ``Codec.compress`` on each — which skips ``en_encoder`` / ``en_decoder`` entirely — and glue the pieces with
-``ChunkData``.  Here the same bookkeeping is kept (same class, same ``data`` / ``chunk_data`` semantics, along the LAST
-dimension so that token features ``(T, C)`` are handled by transposition at the call site), but every chunk goes through
+``ChunkData``.  Here the same bookkeeping is kept (same class, same ``data`` / ``chunk_data`` semantics, along ``dim`` —
+default 0, the reference's: a waveform ``(T,)``, indices ``(T_tok,)`` or token features ``(T_tok, C)`` are all cut along their
+first dimension), but every chunk goes through
 the full path (encoder -> en_encoder -> quantizer, en_decoder -> decoder) and the overlap is a parameter whose default is the
 local attention's look-back (one window of tokens), since the transformer — not the one-hop conv halo — is what carries
 context across a cut.

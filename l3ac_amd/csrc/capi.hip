@@ -1,4 +1,5 @@
 // extern "C" entry points of libl3ac_hip.so (include/l3ac_hip.h).
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstring>
@@ -20,9 +21,16 @@ void l3ac_set_error(const char* fmt, ...) {
     g_last_error = buf;
 }
 
-#include <atomic>
-static std::atomic<int> g_head_pretanh{0};
-bool head_pretanh_enabled() { return g_head_pretanh.load(std::memory_order_relaxed) != 0; }
+int l3ac_device_cu_count() {  // per device ordinal: several devices may be driven from one process
+    static int cus[L3AC_MAX_DEVICES] = {};
+    const int slot = l3ac_device_slot();
+    if (cus[slot] <= 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cus[slot] = v;
+    }
+    return cus[slot];
+}
 
 static thread_local Profiler* g_profiler = nullptr;
 Profiler* l3ac_current_profiler() { return g_profiler; }
@@ -113,6 +121,7 @@ int l3ac_create(const l3ac_config* cfg, const l3ac_tensor* tensors, int32_t n_te
     L3AC_REQUIRE(ctx, "out of host memory");
     ctx->cfg = *cfg;
     ctx->device = device;
+    ctx->gemm_split = gemm_split_default();
     DeviceGuard guard(device);
     int rc = guard.ok ? network_build(ctx, tensors, n_tensors) : L3AC_EHIP;
     if (rc == L3AC_OK && hipEventCreateWithFlags(&ctx->ws_done, hipEventDisableTiming) != hipSuccess) {
@@ -253,16 +262,19 @@ int l3ac_fsq_decode(const int32_t* indices, int64_t n, int32_t feat, const int32
     return launch_fsq((hipStream_t)stream, f);
 }
 
-int64_t l3ac_vq_argmin_scratch_bytes(int64_t n, int32_t k) { return (n > 0 && k > 0) ? (int64_t)vq_argmin_scratch_bytes(n, k) : 0; }
+int64_t l3ac_vq_argmin_scratch_bytes(int64_t n, int32_t k, int32_t form) {
+    return (n > 0 && k > 0) ? (int64_t)vq_argmin_scratch_bytes(n, k, form) : 0;
+}
 
 int l3ac_vq_argmin(const float* queries, int64_t n, const float* codebook, int32_t k, int32_t dim, int32_t* out_idx,
-                   void* scratch, int64_t scratch_bytes, void* stream) {
+                   void* scratch, int64_t scratch_bytes, int32_t form, void* stream) {
     L3AC_REQUIRE(queries && codebook && out_idx, "vq_argmin: null buffer");
     if (n == 0) return L3AC_OK;
-    L3AC_REQUIRE(scratch && k > 0 && scratch_bytes >= (int64_t)vq_argmin_scratch_bytes(n, k),
+    L3AC_REQUIRE(form == 0 || form == 1, "vq_argmin: form must be 0 (automatic) or 1 (direct-form scan)");
+    L3AC_REQUIRE(scratch && k > 0 && scratch_bytes >= (int64_t)vq_argmin_scratch_bytes(n, k, form),
                  "vq_argmin: scratch of %lld bytes needed (l3ac_vq_argmin_scratch_bytes), %lld given",
-                 (long long)(k > 0 ? vq_argmin_scratch_bytes(n, k) : 0), (long long)scratch_bytes);
-    return launch_vq_argmin((hipStream_t)stream, queries, n, codebook, k, dim, scratch, out_idx);
+                 (long long)(k > 0 ? vq_argmin_scratch_bytes(n, k, form) : 0), (long long)scratch_bytes);
+    return launch_vq_argmin((hipStream_t)stream, queries, n, codebook, k, dim, scratch, out_idx, form);
 }
 
 // ---- per-block parity entry points --------------------------------------------------------------------
@@ -271,10 +283,12 @@ int l3ac_op_first_block(l3ac_ctx* ctx, const float* audio, int32_t batch, int32_
     return launch_first_block((hipStream_t)stream, ctx->first, audio, samples, batch, samples, samples, y);
 }
 
+// (h: 4C floats per row, or the wide ConvUnit front end's planes of whole 32-frame tiles when that is more)
 #define L3AC_OP_SCRATCH(c_max)                                                                                    \
     L3AC_TRY(workspace_ensure(ctx, (size_t)batch * frames * (c_max), (size_t)batch * frames * (c_max),           \
-                              (size_t)batch * frames * 4 * (c_max), (size_t)batch * frames * 4, (size_t)batch,   \
-                              (hipStream_t)stream))
+                              std::max((size_t)batch * frames * 4 * (c_max),                                      \
+                                       (conv_unit_wide_scratch_bytes((c_max), (int64_t)batch * frames) + 3) / 4), \
+                              (size_t)batch * frames * 4, (size_t)batch, (hipStream_t)stream))
 
 int l3ac_op_conv_unit(l3ac_ctx* ctx, const char* block, const float* x, int32_t batch, int32_t frames, float* y,
                       void* stream) {
@@ -478,8 +492,11 @@ void l3ac_split3_host(const float* x, int64_t n, uint16_t* planes) {
     }
 }
 
-void l3ac_set_vq_form(int32_t form) { vq_set_form(form); }
-void l3ac_set_head_pretanh(int32_t enable) { g_head_pretanh.store(enable != 0, std::memory_order_relaxed); }
+int l3ac_ctx_set_head_pretanh(l3ac_ctx* ctx, int32_t enable) {
+    L3AC_REQUIRE(ctx != nullptr, "null context");
+    ctx->head_pretanh = enable != 0;
+    return L3AC_OK;
+}
 
 int l3ac_op_snake(const float* x, float* y, int64_t rows, int32_t c, const float* alpha, int32_t mode, void* stream) {
     L3AC_REQUIRE(x && y && alpha && rows >= 0 && c > 0 && c % 4 == 0 && c <= 4096 && mode >= 0 && mode <= 3, "op_snake: bad arguments");
@@ -501,8 +518,12 @@ int l3ac_op_snake(const float* x, float* y, int64_t rows, int32_t c, const float
     return rc;
 }
 
-void l3ac_set_gemm_split(int32_t enable) { gemm_split_set_enabled(enable != 0); }
-int32_t l3ac_get_gemm_split(void) { return gemm_split_enabled() ? 1 : 0; }
+int l3ac_ctx_set_gemm_split(l3ac_ctx* ctx, int32_t enable) {
+    L3AC_REQUIRE(ctx != nullptr, "null context");
+    ctx->gemm_split = enable != 0;
+    return L3AC_OK;
+}
+int32_t l3ac_ctx_get_gemm_split(const l3ac_ctx* ctx) { return ctx && ctx->gemm_split ? 1 : 0; }
 
 int64_t l3ac_gemm_split_image_bytes(int32_t n, int32_t k) {
     return (n > 0 && k > 0 && gemm_split_eligible(n, k)) ? gemm_split_image_bytes(n, k) : 0;

@@ -37,6 +37,21 @@ void l3ac_set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
     } while (0)
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Launch-side state that is a property of the DEVICE (function attributes set with hipFuncSetAttribute, the CU count) is
+// kept per device ordinal: the header allows one context per device, i.e. several devices in one process.
+constexpr int L3AC_MAX_DEVICES = 64;
+static inline int l3ac_device_slot() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= L3AC_MAX_DEVICES) d = 0;
+    return d;
+}
+struct PerDeviceOnce {  // `if (once.first()) { ...configure...; once.done(); }` — per device of the calling thread
+    bool flag[L3AC_MAX_DEVICES] = {};
+    bool first() const { return !flag[l3ac_device_slot()]; }
+    void done() { flag[l3ac_device_slot()] = true; }
+};
+int l3ac_device_cu_count();  // multiprocessor count of the current device (cached per device; 256 if the query fails)
 static inline int64_t round_up64(int64_t a, int64_t b) { return ceil_div64(a, b) * b; }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -56,8 +56,8 @@ int launch_gemm(hipStream_t s, const GemmArgs& g);
 
 // bf16x3 split-operand GEMM (kernels/gemm_split.hip)
 #define L3AC_SPLIT_TILE_BYTES 24576  // one k tile (32) of one column block (128): 3 planes x 128 rows x 64 B
-bool gemm_split_enabled();                 // L3AC_GEMM_SPLIT (default 1) or the last gemm_split_set_enabled()
-void gemm_split_set_enabled(bool on);
+bool gemm_split_default();                 // L3AC_GEMM_SPLIT (default 1): the route a new context starts on; the route of a
+                                           // launch is its GemmArgs::w_img (null = exact fp32 MFMA kernel)
 bool gemm_split_eligible(int n, int k);
 bool gemm_split_conv_ok(const struct GemmArgs& g);  // taps > 1 on the split route: cin % 32 == 0, plain frame-major rows
 int64_t gemm_split_image_bytes(int n, int k);
@@ -103,8 +103,6 @@ int launch_rows(hipStream_t s, const RowArgs& r);
 // elementwise
 int launch_snake(hipStream_t s, const float* x, float* y, int64_t rows, int c, const float* alpha,
                  const float* inv_alpha, int mode = 0);  // mode: see snake_kernel
-// test hook (l3ac_set_head_pretanh): the output head stores the Conv1d(c -> 1, k7) result BEFORE the final tanh
-bool head_pretanh_enabled();
 int launch_geglu(hipStream_t s, const float* h, int64_t ldh, float* y, int64_t ldy, int64_t rows, int inner);
 int launch_grn_sumsq(hipStream_t s, const float* h, int64_t batch, int64_t per_clip, float* sumsq);
 int launch_grn_apply(hipStream_t s, float* h, int64_t batch, int64_t frames, int c, const float* sumsq,
@@ -132,8 +130,9 @@ int launch_enhance_branches(hipStream_t s, const EnhanceW& w, const float* x, in
 int launch_enhance_stats(hipStream_t s, const float* yi, int batch, int frames, float* stats);
 
 // output head (modules.py:190-195 after the Snake1d): conv 24 -> 1 k7 pad 3, tanh
+// pretanh (validation, l3ac_ctx_set_head_pretanh): store the conv result BEFORE the final tanh
 int launch_head(hipStream_t s, const float* x, int batch, int frames, int c, const float* w /*[7][c]*/,
-                const float* b, float* audio);
+                const float* b, float* audio, bool pretanh = false);
 
 // causal local attention, look-back one window (local_attention.LocalAttention); qkv [rows][3*heads*dh]
 int launch_attention(hipStream_t s, const float* qkv, float* out, const float* bias_table /*[heads][2*window]*/,
@@ -162,7 +161,7 @@ int launch_fsq(hipStream_t s, const FsqArgs& a);
 int launch_pack_indices(hipStream_t s, const int32_t* idx, int batch, int n_tok, int bits, uint32_t* out, int words_per_clip);
 int launch_unpack_indices(hipStream_t s, const uint32_t* in, int batch, int n_tok, int bits, int words_per_clip, int32_t* idx);
 // explicit-codebook L2 argmin (kernels/fsq.hip): scratch = vq_argmin_scratch_bytes(n, k) bytes, caller-provided
-size_t vq_argmin_scratch_bytes(int64_t n, int k);
-void vq_set_form(int form);  // test hook l3ac_set_vq_form: 0 automatic, 1 the direct-form scan wherever the screened form would run
+size_t vq_argmin_scratch_bytes(int64_t n, int k, int form = 0);
+// form: 0 automatic, 1 the direct-form scan wherever the screened form would run (the reference the screened form is tested against)
 int launch_vq_argmin(hipStream_t s, const float* queries, int64_t n, const float* codebook, int k, int dim, void* scratch,
-                     int32_t* out_idx);
+                     int32_t* out_idx, int form = 0);

@@ -372,11 +372,11 @@ int launch_fused(hipStream_t s, const ConvUnitW& w, const float* x, float* y, in
     using G = Geo<C, HC, XH>;
     const size_t lds = (size_t)G::lds_floats(WAVES) * sizeof(float);
     static_assert(G::lds_floats(WAVES) * sizeof(float) <= 160 * 1024, "LDS budget exceeded");
-    static bool configured = false;
-    if (!configured) {
+    static PerDeviceOnce configured;
+    if (configured.first()) {
         L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_unit_fused_kernel<C, WAVES, HC, XH>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = true;
+        configured.done();
     }
     const int64_t tiles = (int64_t)batch * ((frames + 31) / 32);
     const int per_cu = lds > 80 * 1024 ? 1 : 2;
@@ -395,9 +395,9 @@ int launch_fused(hipStream_t s, const ConvUnitW& w, const float* x, float* y, in
 bool conv_unit_fused_supported(int c) { return c == 24 || c == 48 || c == 96; }
 
 // In-place use is NOT allowed: a neighbouring wave's halo rows could already have been overwritten.
-int launch_conv_unit_fused(hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames) {
+int launch_conv_unit_fused(hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames, bool split) {
     L3AC_REQUIRE(x != y, "conv_unit_fused: in-place operation is not supported");
-    if (w.w1_img && w.w2_img && gemm_split_enabled()) return launch_conv_unit_split(s, w, x, y, batch, frames);
+    if (split && w.w1_img && w.w2_img) return launch_conv_unit_split(s, w, x, y, batch, frames);
     switch (w.c) {
         case 24: return launch_fused<24, 8, 96, 1>(s, w, x, y, batch, frames, "conv_unit_fused_kernel<24>");
         case 48: return launch_fused<48, 8, 192, 1>(s, w, x, y, batch, frames, "conv_unit_fused_kernel<48>");

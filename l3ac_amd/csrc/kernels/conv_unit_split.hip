@@ -362,11 +362,11 @@ int launch_split(hipStream_t s, const ConvUnitW& w, const float* x, float* y, in
     using G = SGeo<C, HC, XH>;
     const size_t lds = (size_t)G::lds_floats(WAVES) * sizeof(float);
     static_assert(G::lds_floats(WAVES) * sizeof(float) <= 160 * 1024, "LDS budget exceeded");
-    static bool configured = false;
-    if (!configured) {
+    static PerDeviceOnce configured;
+    if (configured.first()) {
         L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_unit_split_kernel<C, WAVES, HC, XH>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = true;
+        configured.done();
     }
     const int64_t tiles = (int64_t)batch * ((frames + 31) / 32);
     L3AC_REQUIRE(tiles < ((int64_t)1 << 31) - 65536, "conv_unit_split: too many tiles");

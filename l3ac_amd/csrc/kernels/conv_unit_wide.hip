@@ -662,11 +662,11 @@ template <int C>
 int launch_wide(hipStream_t s, const ConvUnitW& w, const float* x, float* y, unsigned char* planes, int64_t rows, int frames, const char* name,
                 const char* name_front) {
     using G = WGeo<C>;
-    static bool configured = false;
-    if (!configured) {
+    static PerDeviceOnce configured;
+    if (configured.first()) {
         L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_unit_wide_kernel<C>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
-        configured = true;
+        configured.done();
     }
     {
         ProfScope prof(s, name_front, (double)rows * 30.0 * C, (double)rows * 10.0 * C);
@@ -695,10 +695,13 @@ bool conv_unit_wide_supported(int c) { return c == 128 || c == 192 || c == 256; 
 // scratch the pair of kernels needs: the split LayerNorm output of `rows` frames (whole 32-frame tiles), 6 bytes per element
 size_t conv_unit_wide_scratch_bytes(int c, int64_t rows) { return (size_t)ceil_div64(rows, 32) * 32 * (size_t)c * 6; }
 
-// x must not alias y; `planes` = conv_unit_wide_scratch_bytes(c, batch * frames) bytes of scratch
-int launch_conv_unit_wide(hipStream_t s, const ConvUnitW& w, const float* x, float* y, unsigned char* planes, int batch, int frames) {
+// x must not alias y; `planes` = at least conv_unit_wide_scratch_bytes(c, batch * frames) bytes of scratch (checked)
+int launch_conv_unit_wide(hipStream_t s, const ConvUnitW& w, const float* x, float* y, unsigned char* planes, size_t planes_bytes, int batch,
+                          int frames) {
     L3AC_REQUIRE(x != y && w.wide_img && planes && batch > 0 && frames > 0, "conv_unit_wide: bad arguments");
     const int64_t rows = (int64_t)batch * frames;
+    L3AC_REQUIRE(planes_bytes >= conv_unit_wide_scratch_bytes(w.c, rows), "conv_unit_wide: scratch of %zu bytes, %zu needed (C=%d, %lld rows)",
+                 planes_bytes, conv_unit_wide_scratch_bytes(w.c, rows), w.c, (long long)rows);
     L3AC_REQUIRE(ceil_div64(rows, 4) < ((int64_t)1 << 31), "conv_unit_wide: too many rows");
     switch (w.c) {
         case 128: return launch_wide<128>(s, w, x, y, planes, rows, frames, "conv_unit_wide_kernel<128>", "dwconv_ln_split_kernel<128>");

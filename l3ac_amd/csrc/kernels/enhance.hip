@@ -176,11 +176,11 @@ int launch_enhance_stats(hipStream_t s, const float* yi, int batch, int frames, 
 }
 
 int launch_head(hipStream_t s, const float* x, int batch, int frames, int c, const float* w, const float* b,
-                float* audio) {
+                float* audio, bool pretanh) {
     L3AC_REQUIRE(c % 4 == 0 && batch <= 65535, "head: bad shape");
     ProfScope prof(s, "head_kernel", 14.0 * c * batch * frames, 4.0 * (c + 1.0) * batch * frames);
     hipLaunchKernelGGL(head_kernel, dim3((unsigned)ceil_div64(frames, TILE), (unsigned)batch), dim3(TILE), 0, s, x, frames, c,
-                       w, b, audio, head_pretanh_enabled() ? 1 : 0);
+                       w, b, audio, pretanh ? 1 : 0);
     L3AC_LAUNCH_CHECK();
     return L3AC_OK;
 }

@@ -20,6 +20,17 @@
 
 namespace {
 
+// minimumNumber is the hardware's v_min / v_min3 as it stands; fminf first quiets every operand with a v_max.  Older clang
+// has no such builtin: fminf gives the same values (the operands are finite or +inf here), only slower.
+__device__ __forceinline__ float vq_min(float a, float b) {
+#if __has_builtin(__builtin_elementwise_minimumnum)
+    return __builtin_elementwise_minimumnum(a, b);
+#else
+    return fminf(a, b);
+#endif
+}
+
+
 constexpr int THREADS = 256;
 constexpr int MAXD = L3AC_MAX_LEVELS;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -602,13 +613,13 @@ __global__ __launch_bounds__(256) void vq_screen_kernel(const float* __restrict_
 #pragma unroll
             for (int s = 1; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bq[j][s], acc, 0, 0, 0);
             // (minimumNumber is the hardware's v_min / v_min3 as it stands: fminf would first quiet every operand with a v_max)
-            float m = __builtin_elementwise_minimumnum(__builtin_elementwise_minimumnum(acc[0], acc[1]), acc[2]);
+            float m = vq_min(vq_min(acc[0], acc[1]), acc[2]);
 #pragma unroll
-            for (int r = 3; r < 15; r += 2) m = __builtin_elementwise_minimumnum(__builtin_elementwise_minimumnum(m, acc[r]), acc[r + 1]);
-            m = __builtin_elementwise_minimumnum(m, acc[15]);
+            for (int r = 3; r < 15; r += 2) m = vq_min(vq_min(m, acc[r]), acc[r + 1]);
+            m = vq_min(m, acc[15]);
             sb[j] = __builtin_amdgcn_fmed3f(b[j], m, sb[j]);  // b <= sb always: the median is the new second smallest
             blk[j] = m < b[j] ? t : blk[j];
-            b[j] = __builtin_elementwise_minimumnum(b[j], m);
+            b[j] = vq_min(b[j], m);
         }
     }
     // the two half-waves hold the two halves of every tile for the same 32 queries
@@ -706,30 +717,21 @@ struct VqPlan {
     size_t off_norms, off_list, off_a, off_b, off_c, off_xd, off_xi, bytes;  // scratch layout (bytes)
 };
 
-std::atomic<int> g_vq_force_scan{0};  // test hook l3ac_set_vq_form
 constexpr int VQ_SCREEN_ROUNDS = 8;
 constexpr int VQ_SCREEN_WGS_PER_CU = 3;  // <= 168 registers per lane
 constexpr int VQ_SCREEN_LDS = (160 * 1024 / VQ_SCREEN_WGS_PER_CU) & ~255;  // requested, not used: pins that many workgroups per CU
 
-int device_cu_count() {
-    static const int cus = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        return v;
-    }();
-    return cus;
-}
 
-VqForm vq_form(int64_t n) {
+VqForm vq_form(int64_t n, int form) {  // form 1: the direct-form scan wherever the screened form would run
     if (n < VQ_WAVE_MAX_N) return VQ_WAVE;
-    return g_vq_force_scan.load(std::memory_order_relaxed) ? VQ_SCAN : VQ_SCREEN;
+    return form == 1 ? VQ_SCAN : VQ_SCREEN;
 }
 
 // How the codebook is cut: enough (query group, slice) work items for ~8 waves per SIMD at the scan form, ~4 at the wave form,
 // ~16 rounds of waves at the screened form
-VqPlan vq_plan(int64_t n, int k) {
+VqPlan vq_plan(int64_t n, int k, int form) {
     VqPlan pl{};
-    pl.form = vq_form(n);
+    pl.form = vq_form(n, form);
     auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
     if (pl.form == VQ_SCREEN) {
         // Work items (4 waves = 4 * 32 NQ queries, one index range) are equal in cost, so their number is made to FILL a whole
@@ -737,7 +739,7 @@ VqPlan vq_plan(int64_t n, int k) {
         // request): 4 200 items on 1 024 places take five rounds, 4 032 take four.
         const int n_tiles = (k + 31) / 32;
         const int64_t groups_q = ceil_div64(n, 4 * 32 * VQ_SCREEN_NQ);
-        const int64_t places = (int64_t)device_cu_count() * VQ_SCREEN_WGS_PER_CU;
+        const int64_t places = (int64_t)l3ac_device_cu_count() * VQ_SCREEN_WGS_PER_CU;
         int64_t parts = (VQ_SCREEN_ROUNDS * places) / groups_q;  // rounded down: at most ROUNDS full rounds
         const int64_t max_parts = ceil_div64(n_tiles, 16);
         if (parts > max_parts) parts = max_parts;
@@ -891,16 +893,15 @@ int launch_fsq(hipStream_t s, const FsqArgs& a) {
     }
 }
 
-void vq_set_form(int form) { g_vq_force_scan.store(form == 1, std::memory_order_relaxed); }
-size_t vq_argmin_scratch_bytes(int64_t n, int k) { return vq_plan(n, k).bytes; }
+size_t vq_argmin_scratch_bytes(int64_t n, int k, int form) { return vq_plan(n, k, form).bytes; }
 
 // scratch = vq_argmin_scratch_bytes(n, k) bytes
 int launch_vq_argmin(hipStream_t s, const float* queries, int64_t n, const float* codebook, int k, int dim, void* scratch,
-                     int32_t* out_idx) {
+                     int32_t* out_idx, int form) {
     L3AC_REQUIRE(dim >= 1 && dim <= 8 && k > 0 && n >= 0, "vq_argmin: bad shape (dim=%d k=%d)", dim, k);
     L3AC_REQUIRE(n < ((int64_t)1 << 31), "vq_argmin: %lld queries exceed the 32-bit query numbers of one call", (long long)n);
     if (n == 0) return L3AC_OK;
-    const VqPlan pl = vq_plan(n, k);
+    const VqPlan pl = vq_plan(n, k, form);
     char* sc = reinterpret_cast<char*>(scratch);
     switch (dim) {
         case 1: return launch_vq_t<1>(s, queries, n, codebook, k, pl, sc, out_idx);

@@ -399,7 +399,7 @@ int launch_gemm(hipStream_t s, const GemmArgs& g) {
         L3AC_REQUIRE(!conv && g.gate_stats && g.gate_in_w && g.gate_in_b && g.gate_w && g.gate_b && g.gate_frames > 0 &&
                          g.m % g.gate_frames == 0,
                      "gemm: incomplete gate arguments");
-    } else if (g.w_img && gemm_split_eligible(g.n, g.k) && (!conv || gemm_split_conv_ok(g)) && gemm_split_enabled()) {
+    } else if (g.w_img && gemm_split_eligible(g.n, g.k) && (!conv || gemm_split_conv_ok(g))) {
         return launch_gemm_split(s, g);
     }
     if (conv) {

@@ -544,8 +544,6 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_split_kernel_few_blocks(const
     gemm_split_body16<KTAIL, 1, true>(p, gp);  // 64-row blocks: twice the blocks, half the MFMAs per k tile and block
 }
 
-std::atomic<int> g_split_enabled{-1};
-
 }  // namespace
 
 #ifdef L3AC_SPLIT_STAMPS
@@ -553,16 +551,11 @@ extern "C" int l3ac_debug_split_stamps(long long* out, int n) {  // diagnostic b
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_split_stamps), (size_t)n * sizeof(long long));
 }
 #endif
-bool gemm_split_enabled() {
-    int v = g_split_enabled.load(std::memory_order_relaxed);
-    if (v < 0) {
-        const char* e = std::getenv("L3AC_GEMM_SPLIT");
-        v = e ? (std::atoi(e) != 0) : 1;
-        g_split_enabled.store(v, std::memory_order_relaxed);
-    }
-    return v != 0;
+// the route a new context starts on (l3ac_ctx::gemm_split; l3ac_ctx_set_gemm_split changes it per context)
+bool gemm_split_default() {
+    const char* e = std::getenv("L3AC_GEMM_SPLIT");
+    return e ? (std::atoi(e) != 0) : true;
 }
-void gemm_split_set_enabled(bool on) { g_split_enabled.store(on ? 1 : 0, std::memory_order_relaxed); }
 
 // n < 192 would be a single 128-column block per row panel: too few workgroups at the transformer's row counts, where
 // the exact kernel's narrower tiles win (measured: 128 x 344 and 128 x 192 weights, 26 vs 45 TFLOP/s at 15360 rows)
@@ -630,11 +623,7 @@ int launch_gemm_split(hipStream_t s, const GemmArgs& g) {
         return e && std::atoi(e) == 32;
     }();
     const bool tail = g.k % BK != 0;
-    static const int cus = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        return v;
-    }();
+    const int cus = l3ac_device_cu_count();
     if (conv) {  // (whole k tiles: no tail; the 16x16x32 form only)
         if (blocks <= cus)
             hipLaunchKernelGGL(gemm_split_conv_kernel_few_blocks, dim3((unsigned)(ceil_div64(g.m, BM / 2) * ceil_div64(g.n, BN))), dim3(THREADS),

@@ -487,19 +487,19 @@ __global__ __launch_bounds__(FRAMES) void head_fused_kernel(const HeadW w, const
 }
 
 template <int C>
-int launch_legacy_t(hipStream_t s, const LegacyW& w, const float* x, float* y, int batch, int frames) {
+int launch_legacy_t(hipStream_t s, const LegacyW& w, const float* x, float* y, int batch, int frames, bool split_route) {
     L3AC_REQUIRE(w.dil >= 1 && w.dil <= 9, "legacy unit: dilation %d outside the LDS tile budget", w.dil);
-    const bool split = w.w1_img && w.w2_img && gemm_split_enabled();
+    const bool split = split_route && w.w1_img && w.w2_img;
     using G = LGeo<C>;
     using GS = LSGeo<C>;
     const size_t lds = split ? (size_t)GS::lds_bytes(w.dil) : (size_t)G::lds_floats(w.dil) * sizeof(float);
-    static bool configured = false;
-    if (!configured) {
+    static PerDeviceOnce configured;
+    if (configured.first()) {
         L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(legacy_unit_kernel<C>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(G::lds_floats(9) * sizeof(float))));
         L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(legacy_unit_split_kernel<C>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, GS::lds_bytes(9)));
-        configured = true;
+        configured.done();
     }
     const double rows = (double)batch * frames;
     const int tiles_per_clip = (int)ceil_div64(frames, FRAMES);
@@ -518,11 +518,11 @@ int launch_legacy_t(hipStream_t s, const LegacyW& w, const float* x, float* y, i
 }
 
 template <int C>
-int launch_head_t(hipStream_t s, const HeadW& w, const float* x, int batch, int frames, float* audio) {
+int launch_head_t(hipStream_t s, const HeadW& w, const float* x, int batch, int frames, float* audio, bool pretanh) {
     const double rows = (double)batch * frames;
     ProfScope prof(s, "head_fused_kernel", rows * (14.0 * C + 20.0 * C), rows * (4.0 * C + 4.0));
     hipLaunchKernelGGL((head_fused_kernel<C>), dim3((unsigned)ceil_div64(frames, FRAMES), (unsigned)batch), dim3(FRAMES), 0, s, w,
-                       x, frames, audio, head_pretanh_enabled() ? 1 : 0);
+                       x, frames, audio, pretanh ? 1 : 0);
     L3AC_LAUNCH_CHECK();
     return L3AC_OK;
 }
@@ -532,24 +532,24 @@ int launch_head_t(hipStream_t s, const HeadW& w, const float* x, int batch, int 
 bool last_block_fused_supported(int c, int max_dil) { return (c == 8 || c == 16 || c == 24 || c == 32) && max_dil <= 9; }
 
 // x must not alias y (neighbouring blocks read each other's halo frames)
-int launch_legacy_unit_fused(hipStream_t s, const LegacyW& w, const float* x, float* y, int batch, int frames) {
+int launch_legacy_unit_fused(hipStream_t s, const LegacyW& w, const float* x, float* y, int batch, int frames, bool split) {
     L3AC_REQUIRE(x != y && batch <= 65535, "legacy unit: bad arguments");
     switch (w.c) {
-        case 8: return launch_legacy_t<8>(s, w, x, y, batch, frames);
-        case 16: return launch_legacy_t<16>(s, w, x, y, batch, frames);
-        case 24: return launch_legacy_t<24>(s, w, x, y, batch, frames);
-        case 32: return launch_legacy_t<32>(s, w, x, y, batch, frames);
+        case 8: return launch_legacy_t<8>(s, w, x, y, batch, frames, split);
+        case 16: return launch_legacy_t<16>(s, w, x, y, batch, frames, split);
+        case 24: return launch_legacy_t<24>(s, w, x, y, batch, frames, split);
+        case 32: return launch_legacy_t<32>(s, w, x, y, batch, frames, split);
         default: l3ac_set_error("legacy unit: C=%d not supported by the fused kernel", w.c); return L3AC_EINVAL;
     }
 }
 
-int launch_head_fused(hipStream_t s, const HeadW& w, const float* x, int batch, int frames, float* audio) {
+int launch_head_fused(hipStream_t s, const HeadW& w, const float* x, int batch, int frames, float* audio, bool pretanh) {
     L3AC_REQUIRE(batch <= 65535, "head: bad arguments");
     switch (w.c) {
-        case 8: return launch_head_t<8>(s, w, x, batch, frames, audio);
-        case 16: return launch_head_t<16>(s, w, x, batch, frames, audio);
-        case 24: return launch_head_t<24>(s, w, x, batch, frames, audio);
-        case 32: return launch_head_t<32>(s, w, x, batch, frames, audio);
+        case 8: return launch_head_t<8>(s, w, x, batch, frames, audio, pretanh);
+        case 16: return launch_head_t<16>(s, w, x, batch, frames, audio, pretanh);
+        case 24: return launch_head_t<24>(s, w, x, batch, frames, audio, pretanh);
+        case 32: return launch_head_t<32>(s, w, x, batch, frames, audio, pretanh);
         default: l3ac_set_error("head: C=%d not supported by the fused kernel", w.c); return L3AC_EINVAL;
     }
 }

@@ -534,9 +534,16 @@ int workspace_ensure_clip(l3ac_ctx* ctx, int batch, int samples, hipStream_t s) 
     size_t x = 0, a = 0, h = 0, yi = 0;
     auto upd = [](size_t& m, int64_t v) { if ((size_t)v > m) m = (size_t)v; };
     int64_t f = frames0;
+    // (h is also the scratch of the wide ConvUnit's front end: bf16x3 planes of whole 32-frame tiles of ALL the batch's
+    // rows, conv_unit_wide_scratch_bytes — larger than 4C floats per row when batch * frames is small)
+    size_t wide_bytes = 0;
+    auto wide = [&](int cdim, int64_t fr) {
+        if (conv_unit_wide_supported(cdim)) wide_bytes = std::max(wide_bytes, conv_unit_wide_scratch_bytes(cdim, (int64_t)batch * fr));
+    };
     for (int i = 0; i < c.n_enc; ++i) {
         upd(x, f * c.enc_dims[i]);
         upd(h, f * 4 * c.enc_dims[i]);
+        wide(c.enc_dims[i], f);
         if (i + 1 < c.n_enc) f /= c.compress_rates[i];
     }
     const int64_t feat_frames = f;
@@ -547,6 +554,7 @@ int workspace_ensure_clip(l3ac_ctx* ctx, int batch, int samples, hipStream_t s) 
     for (int i = 0; i < c.n_dec; ++i) {
         upd(x, f * c.dec_dims[i]);
         upd(h, f * 4 * c.dec_dims[i]);
+        wide(c.dec_dims[i], f);
         upd(yi, f * 4);
         if (i + 1 < c.n_dec) {
             upd(x, f * c.dec_dims[i + 1]);
@@ -555,7 +563,7 @@ int workspace_ensure_clip(l3ac_ctx* ctx, int batch, int samples, hipStream_t s) 
     }
     (void)feat_frames;
     upd(a, (int64_t)x);
-    return workspace_ensure(ctx, x * batch, a * batch, h * batch, yi * batch, (size_t)batch, s);
+    return workspace_ensure(ctx, x * batch, a * batch, std::max(h * batch, (wide_bytes + 3) / 4), yi * batch, (size_t)batch, s);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -567,19 +575,19 @@ static bool use_wide(const l3ac_ctx* ctx, const ConvUnitW& w) {
         const char* e = std::getenv("L3AC_WIDE_FUSED");
         return e && std::atoi(e) == 0;
     }();
-    return !off && !ctx->cfg.grn_exact && w.wide_img && gemm_split_enabled() && conv_unit_wide_supported(w.c);
+    return !off && !ctx->cfg.grn_exact && w.wide_img && ctx->gemm_split && conv_unit_wide_supported(w.c);
 }
 
 int conv_unit_step(l3ac_ctx* ctx, hipStream_t s, const ConvUnitW& w, float** cur, float** alt, int batch, int frames) {
     if (use_wide(ctx, w)) {
-        L3AC_TRY(launch_conv_unit_wide(s, w, *cur, *alt, reinterpret_cast<unsigned char*>(ctx->ws.h), batch, frames));
+        L3AC_TRY(launch_conv_unit_wide(s, w, *cur, *alt, reinterpret_cast<unsigned char*>(ctx->ws.h), ctx->ws.h_cap * sizeof(float), batch, frames));
         float* t = *cur;
         *cur = *alt;
         *alt = t;
         return L3AC_OK;
     }
     if (!ctx->cfg.grn_exact && conv_unit_fused_supported(w.c)) {
-        L3AC_TRY(launch_conv_unit_fused(s, w, *cur, *alt, batch, frames));
+        L3AC_TRY(launch_conv_unit_fused(s, w, *cur, *alt, batch, frames, ctx->gemm_split));
         float* t = *cur;
         *cur = *alt;
         *alt = t;
@@ -632,8 +640,9 @@ int run_conv_units(l3ac_ctx* ctx, hipStream_t s, const std::vector<ConvUnitW>& u
 }
 
 int run_conv_unit(l3ac_ctx* ctx, hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames) {
-    if (x != y && use_wide(ctx, w)) return launch_conv_unit_wide(s, w, x, y, reinterpret_cast<unsigned char*>(ctx->ws.h), batch, frames);
-    if (!ctx->cfg.grn_exact && x != y && conv_unit_fused_supported(w.c)) return launch_conv_unit_fused(s, w, x, y, batch, frames);
+    if (x != y && use_wide(ctx, w))
+        return launch_conv_unit_wide(s, w, x, y, reinterpret_cast<unsigned char*>(ctx->ws.h), ctx->ws.h_cap * sizeof(float), batch, frames);
+    if (!ctx->cfg.grn_exact && x != y && conv_unit_fused_supported(w.c)) return launch_conv_unit_fused(s, w, x, y, batch, frames, ctx->gemm_split);
     const int group = conv_unit_group(ctx, w, batch, frames);
     for (int b0 = 0; b0 < batch; b0 += group) {
         const int nb = std::min(group, batch - b0);
@@ -738,12 +747,12 @@ int run_last_block(l3ac_ctx* ctx, hipStream_t s, float* x, float* audio, int bat
         float* cur = x;
         float* alt = ws.a;
         for (const LegacyW& l : ctx->legacy) {
-            L3AC_TRY(launch_legacy_unit_fused(s, l, cur, alt, batch, frames));
+            L3AC_TRY(launch_legacy_unit_fused(s, l, cur, alt, batch, frames, ctx->gemm_split));
             float* t = cur;
             cur = alt;
             alt = t;
         }
-        return launch_head_fused(s, ctx->head, cur, batch, frames, audio);
+        return launch_head_fused(s, ctx->head, cur, batch, frames, audio, ctx->head_pretanh);
     }
     for (const LegacyW& l : ctx->legacy) {  // modules.py:47-64
         L3AC_TRY(launch_snake(s, x, ws.a, rows, l.c, l.a0, l.ia0));
@@ -759,7 +768,7 @@ int run_last_block(l3ac_ctx* ctx, hipStream_t s, float* x, float* audio, int bat
     }
     const HeadW& hd = ctx->head;  // Snake1d -> Conv1d(c -> 1, k7) -> Tanh (modules.py:192-194)
     L3AC_TRY(launch_snake(s, x, ws.a, rows, hd.c, hd.alpha, hd.inv_alpha));
-    return launch_head(s, ws.a, batch, frames, hd.c, hd.w, hd.b, audio);
+    return launch_head(s, ws.a, batch, frames, hd.c, hd.w, hd.b, audio, ctx->head_pretanh);
 }
 
 int run_local_trans(l3ac_ctx* ctx, hipStream_t s, const LocalTransW& w, float* x, int batch, int frames) {

@@ -69,7 +69,12 @@ struct l3ac_ctx {
     unsigned char* img_arena = nullptr;
     size_t img_bytes = 0;
     std::unordered_map<const float*, const unsigned char*> split_img;
-    const unsigned char* img(const float* w) const {
+    // Route switches are PER CONTEXT (a flip never reaches another context's calls or captured graphs).  gemm_split: the large
+    // channel contractions on the bf16 matrix cores through exact bf16x3 operand splits (default) or everything on the fp32 MFMA
+    // instruction; head_pretanh (validation): the output head stores its value before the final tanh.
+    bool gemm_split = true, head_pretanh = false;
+    const unsigned char* img(const float* w) const {  // null on the exact route: launch_gemm then takes the fp32 kernel
+        if (!gemm_split) return nullptr;
         auto it = split_img.find(w);
         return it == split_img.end() ? nullptr : it->second;
     }
@@ -115,7 +120,7 @@ int workspace_ensure_clip(l3ac_ctx* ctx, int batch, int samples, hipStream_t s);
 
 // fused ConvUnit for the narrow stages (kernels/conv_unit_fused.hip); x must not alias y
 bool conv_unit_fused_supported(int c);
-int launch_conv_unit_fused(hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames);
+int launch_conv_unit_fused(hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames, bool split);
 // bf16x3 variant (kernels/conv_unit_split.hip), chosen by launch_conv_unit_fused when the images exist and the split route is on
 int launch_conv_unit_split(hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames);
 std::vector<unsigned char> conv_unit_w1_image(const float* w1, int c);  // w1 [4c][c]
@@ -123,15 +128,16 @@ std::vector<unsigned char> conv_unit_w2_image(const float* w2, int c);  // w2 [c
 // fused ConvUnit of the wide stages (kernels/conv_unit_wide.hip): hidden tensor in registers, weights streamed through an LDS ring
 bool conv_unit_wide_supported(int c);
 size_t conv_unit_wide_scratch_bytes(int c, int64_t rows);
-int launch_conv_unit_wide(hipStream_t s, const ConvUnitW& w, const float* x, float* y, unsigned char* planes, int batch, int frames);
+int launch_conv_unit_wide(hipStream_t s, const ConvUnitW& w, const float* x, float* y, unsigned char* planes, size_t planes_bytes, int batch,
+                          int frames);
 std::vector<unsigned char> conv_unit_wide_image(const float* w1, const float* w2, int c);  // w1 [4c][c], w2 [c][4c]
 // fused LegacyUnit / head (kernels/last_block.hip); x must not alias y
 bool last_block_fused_supported(int c, int max_dil);
 // host builders of the LegacyUnit weight images: w1 [c][7][c] (tap-major rows), w2 [c][c]
 std::vector<unsigned char> legacy_w1_image(const float* w1, int c);
 std::vector<unsigned char> legacy_w2_image(const float* w2, int c);
-int launch_legacy_unit_fused(hipStream_t s, const LegacyW& w, const float* x, float* y, int batch, int frames);
-int launch_head_fused(hipStream_t s, const HeadW& w, const float* x, int batch, int frames, float* audio);
+int launch_legacy_unit_fused(hipStream_t s, const LegacyW& w, const float* x, float* y, int batch, int frames, bool split);
+int launch_head_fused(hipStream_t s, const HeadW& w, const float* x, int batch, int frames, float* audio, bool pretanh);
 // one ConvUnit of a stage on the ping-pong buffers: fused kernel (result in *alt, buffers swapped) or in place
 int conv_unit_step(l3ac_ctx* ctx, hipStream_t s, const ConvUnitW& w, float** cur, float** alt, int batch, int frames);
 // all ConvUnits of one stage (wide units: clip groups outside the units, see network.hip)

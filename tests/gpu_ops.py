@@ -101,20 +101,16 @@ def fsq_decode(indices, levels, w_out, b_out):
 
 
 def vq_argmin(queries, codebook, form=0, info=None):
-    """form 1: the direct-form scan where the screened form would run (l3ac_set_vq_form).  info: dict that receives
+    """form 1: the direct-form scan where the screened form would run (an argument of l3ac_vq_argmin).  info: dict that receives
     'listed' = how many queries the screened form sent to the full direct-form search (first int32 of its scratch)."""
     lib = _capi.load_library()
     n, dim = queries.shape
     out = torch.empty((n,), dtype=torch.int32, device=queries.device)
-    lib.l3ac_set_vq_form(form)
-    try:
-        nbytes = lib.l3ac_vq_argmin_scratch_bytes(n, codebook.shape[0])
-        scratch = torch.zeros((max(nbytes, 4),), dtype=torch.uint8, device=queries.device)
-        _capi.check(lib.l3ac_vq_argmin(queries.data_ptr(), n, codebook.data_ptr(), codebook.shape[0], dim, out.data_ptr(),
-                                       scratch.data_ptr(), nbytes, _stream(queries.device)))
-        torch.cuda.synchronize()
-    finally:
-        lib.l3ac_set_vq_form(0)
+    nbytes = lib.l3ac_vq_argmin_scratch_bytes(n, codebook.shape[0], form)
+    scratch = torch.zeros((max(nbytes, 4),), dtype=torch.uint8, device=queries.device)
+    _capi.check(lib.l3ac_vq_argmin(queries.data_ptr(), n, codebook.data_ptr(), codebook.shape[0], dim, out.data_ptr(),
+                                   scratch.data_ptr(), nbytes, form, _stream(queries.device)))
+    torch.cuda.synchronize()
     if info is not None:
         info["listed"] = int(scratch[:4].view(torch.int32).item()) if (form == 0 and n >= 5120) else None
     return out

@@ -233,6 +233,35 @@ def test_conv_units_wide_fused(full):
     assert float(e_f.max()) <= 2.0 * float(e_u.max()) + 1e-7
 
 
+def test_conv_units_wide_scratch_on_a_fresh_context():
+    """The wide ConvUnit's front end writes bf16x3 planes of WHOLE 32-frame tiles (conv_unit_wide_scratch_bytes) into the
+    hidden scratch: more than the 4C floats per row that scratch is otherwise sized by when batch * frames < 12.  On a
+    context that has never run anything larger (round-2 advisor finding: the write ran past the buffer) a few-row unit and a
+    one-token clip of the reference-default geometry (C = 128 / 256 stages, hop 45) must work and match the oracle."""
+    for cfg, seed, block, c in (("1kbps", 0, "decoder.blocks.4.0.module", 256), ("1kbps", 0, "encoder.blocks.7.0.module", 192),
+                                (GOLDEN / "refdefault.toml", 5, "decoder.blocks.4.0.module", 128)):
+        for b, t in ((1, 3), (2, 4), (1, 11)):
+            codec = l3ac_amd.get_model(cfg, synthetic_seed=seed)  # fresh context every time: its workspace starts empty
+            codec.network.to(device="cuda").eval()
+            w = W.folded_weights(codec.network.state_dicts())
+            x = _rand((b, c, t), 700 + c + t)
+            ref = O.conv_unit(w, block, x)
+            got = G.op_block(codec.network.context(), "l3ac_op_conv_unit", block, G.to_frames(x), (b, t, c))
+            _close(f"fresh ctx {block} B={b} T={t}", G.from_frames(got), ref, atol=5e-5, rtol=5e-5)
+    codec = l3ac_amd.get_model(GOLDEN / "refdefault.toml", synthetic_seed=5)
+    codec.network.to(device="cuda").eval()
+    mc = codec.network.mc
+    w = W.folded_weights(codec.network.state_dicts())
+    audio = seeded_audio(1, mc.hop_length)  # one token
+    q, ind = codec.encode_audio(audio.cuda())
+    wave = codec.decode_audio(q)
+    torch.cuda.synchronize()
+    _, ind_ref = O.encode_audio(w, mc, audio)
+    assert torch.equal(ind["indices"].cpu(), ind_ref["indices"])
+    wave_ref = O.decode_audio(w, mc, indices=ind_ref["indices"])
+    assert float((wave.cpu() - wave_ref).abs().max()) < 2e-3
+
+
 def test_down_and_k3_layers(tiny, full):
     import torch.nn.functional as F
     for (codec, mc, w), cases in ((tiny, [("encoder.blocks.2", 8, 16, 2, 66), ("encoder.blocks.4", 16, 24, 3, 66)]),
@@ -473,10 +502,10 @@ def test_vq_argmin_graph_capture():
         eager = [G.vq_argmin(q, cb) for q in sets]
         q_static = sets[0].clone()
         out = torch.empty(n, dtype=torch.int32, device="cuda")
-        nbytes = lib.l3ac_vq_argmin_scratch_bytes(n, k)
+        nbytes = lib.l3ac_vq_argmin_scratch_bytes(n, k, 0)
         scratch = torch.zeros(max(nbytes, 4), dtype=torch.uint8, device="cuda")
         call = lambda: _capi.check(lib.l3ac_vq_argmin(q_static.data_ptr(), n, cb.data_ptr(), k, 6, out.data_ptr(), scratch.data_ptr(),
-                                                      nbytes, torch.cuda.current_stream().cuda_stream))
+                                                      nbytes, 0, torch.cuda.current_stream().cuda_stream))
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):

@@ -261,7 +261,7 @@ def test_batch_invariance_3kbps_256():
 
 def test_decoder_before_tanh_full_size():
     """The tanh output saturates with the synthetic weights (|wave| reaches 1.0), which hides pre-tanh error.  With the
-    l3ac_set_head_pretanh test hook the head stores the Conv1d(24 -> 1, k7) result itself: compared here at full clip size
+    l3ac_ctx_set_head_pretanh validation switch the head stores the Conv1d(24 -> 1, k7) result itself: compared here at full clip size
     against the oracle's pre-tanh value, relative to the size of the signal."""
     from l3ac_amd import _capi
     codec = _codec("1kbps", 0)
@@ -272,12 +272,15 @@ def test_decoder_before_tanh_full_size():
     wave_ref = O.decode_audio(w, mc, indices=ind_ref["indices"]).double()
     clipped = wave_ref.abs() > 0.999
     pre_ref = torch.atanh(wave_ref.clamp(-0.999, 0.999))  # where the oracle's tanh has not saturated, atanh recovers its input
-    lib = _capi.load_library()
-    lib.l3ac_set_head_pretanh(1)
+    other = _codec("1kbps", 0)  # a second context: the switch is per context and must not reach it
+    ctx = codec.network.context()
+    ctx.set_head_pretanh(True)
     try:
         pre = codec.decode_audio(indices=ind_ref["indices"].cuda()).cpu().double()
+        if other is not codec:
+            assert float(other.decode_audio(indices=ind_ref["indices"].cuda()).abs().max()) <= 1.0
     finally:
-        lib.l3ac_set_head_pretanh(0)
+        ctx.set_head_pretanh(False)
     wave = codec.decode_audio(indices=ind_ref["indices"].cuda()).cpu().double()
     assert torch.equal(torch.tanh(pre.float()).double(), wave) or (torch.tanh(pre) - wave).abs().max() < 1e-6
     ok = ~clipped

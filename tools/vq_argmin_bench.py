@@ -23,10 +23,9 @@ for levels, n in (CASES[:1] if QUICK else CASES):
     for form in ((0,) if QUICK else (0, 1)):  # 0: automatic (screened form from 5 120 queries on), 1: the direct-form scan
         if form != 0 and n < 5120:
             continue
-        lib.l3ac_set_vq_form(form)
-        nb = lib.l3ac_vq_argmin_scratch_bytes(n, k)
+        nb = lib.l3ac_vq_argmin_scratch_bytes(n, k, form)
         sc = torch.zeros(max(nb, 4), dtype=torch.uint8, device="cuda")
-        f = lambda: _capi.check(lib.l3ac_vq_argmin(q.data_ptr(), n, cb.data_ptr(), k, 6, idx.data_ptr(), sc.data_ptr(), nb, s))
+        f = lambda: _capi.check(lib.l3ac_vq_argmin(q.data_ptr(), n, cb.data_ptr(), k, 6, idx.data_ptr(), sc.data_ptr(), nb, form, s))
         for _ in range(3):
             f()
         torch.cuda.synchronize()
@@ -46,4 +45,3 @@ for levels, n in (CASES[:1] if QUICK else CASES):
             first = idx.clone()
         else:
             print(f"    forms agree on every query: {bool(torch.equal(first, idx))}")
-    lib.l3ac_set_vq_form(0)
