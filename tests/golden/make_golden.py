@@ -12,6 +12,8 @@ What is pinned (see oracle/l3ac_oracle.py docstring):
                        absent PyPI dependency ``local_attention`` replaced by a stand-in built on the oracle's
                        own restatement.  Pins the WIRING only; the attention arithmetic stays unpinned.
   * ``fsq_kat.npz``  — known-answer vectors from the reference ``SuperFSQ`` (half-even ties, saturation, decode).
+  * ``chunk_kat.npz`` — the reference's ``ChunkData`` cut / merge results and ``Codec.extract_unit`` / ``decode_unit`` run on the
+                       tiny model (pins oracle/chunk_oracle.py).
 """
 import sys
 import types
@@ -266,12 +268,91 @@ def make_fsq_boundary_kat():
     print("[fsq_boundary_kat] written")
 
 
+@torch.inference_mode()
+def make_chunk_kat():
+    """Long-audio bookkeeping, produced by the reference's own code: ``l3ac.codec.ChunkData`` (codec.py:159-188) cutting and
+    merging integer sequences (ragged tails, chunk_len dividing / not dividing the length, a single chunk), and
+    ``Codec.extract_unit`` / ``decode_unit`` (codec.py:124-156) run as written on the tiny model.
+
+    Harness note: as written the method cannot run — ``Codec.compress`` (codec.py:113-116) returns the quantiser's ``indices``
+    DICT, which ``extract_unit`` indexes with ``[0]`` (:141: KeyError with ``SuperFSQ``), and :144 reads ``self.hop_length``, which
+    only the config has (AttributeError); both are recorded in the fixture as ``extract_unit_errors_as_written``.  To run the rest
+    of the method as written, ``compress`` is wrapped so that it returns the dict's ``"indices"`` tensor and the instance is given
+    its config's ``hop_length``; nothing else is touched."""
+    from l3ac.codec import ChunkData  # reference
+    out = {}
+    cases = [(37, 10, 3), (40, 10, 3), (9, 10, 3), (10, 10, 1), (101, 25, 24), (64, 16, 1), (1, 5, 2), (23, 7, 6)]
+    out["cd_cases"] = np.array(cases, dtype=np.int64)
+    for i, (n, cl, pl) in enumerate(cases):
+        data = torch.arange(n, dtype=torch.int64) * 3 + 1
+        chunks = ChunkData(chunk_len=cl, prefix_len=pl, original_data=data).chunk_data
+        out[f"cd{i}_lens"] = np.array([len(c) for c in chunks], dtype=np.int64)
+        out[f"cd{i}_cat"] = torch.cat(chunks).numpy()
+        merged = ChunkData(chunk_len=cl, prefix_len=pl, chunk_data=chunks).data
+        assert torch.equal(merged, data)
+        out[f"cd{i}_merged"] = merged.numpy()
+        # merge of chunks whose contents are NOT slices of one sequence (what decode_unit does with decoded chunks)
+        g = torch.Generator().manual_seed(100 + i)
+        other = [torch.randint(0, 1000, (len(c), 2), generator=g) for c in chunks]
+        out[f"cd{i}_other_cat"] = torch.cat(other).numpy()
+        out[f"cd{i}_other_merged"] = ChunkData(chunk_len=cl, prefix_len=pl, chunk_data=other).data.numpy()
+    # ---- extract_unit / decode_unit on the tiny model's conv codec (the base ``Codec``: the methods skip en_encoder / en_decoder,
+    #      and on an ``EnCodec`` their token bookkeeping — process_window // hop with the EnCodec hop — does not match the tokens
+    #      ``compress`` returns) -----------------------------------------------------------------------------------------
+    mc, en_ref, sds = build_reference(HERE / "tiny.toml", 3)
+    base_mc = l3ac.codec.ModelConfig(**mc.model_dump(exclude={"hop_length", "en_coder_depth", "en_coder_window_size", "en_coder_dynamic_pos",
+                                                             "en_coder_compress_rate", "en_coder_cache_size"}))
+    ref = l3ac.codec.Codec(base_mc).eval()
+    for name, module in ref.trainable_modules.items():
+        module.load_state_dict(sds[name], strict=True)
+    audio = seeded_audio(1, 1000, seed=77)
+    as_written = []
+    try:
+        ref.extract_unit(audio, process_window=300)
+    except Exception as e:  # noqa: BLE001
+        as_written.append(type(e).__name__)
+    orig_compress = ref.compress
+
+    def compress(x):
+        ind, q = orig_compress(x)
+        return (ind["indices"] if isinstance(ind, dict) else ind), q
+    ref.compress = compress
+    try:
+        ref.extract_unit(audio, process_window=300)
+    except Exception as e:  # noqa: BLE001
+        as_written.append(type(e).__name__)
+    ref.hop_length = base_mc.hop_length  # codec.py:144 reads self.hop_length, which only the config has
+    out["extract_unit_errors_as_written"] = np.array(as_written)  # KeyError (dict indexed with [0], :141), AttributeError (:144)
+    eu = []
+    for j, (samples, window) in enumerate(((1000, 300), (1201, 500), (250, 5 * 16000), (960, 96), (2000, 333))):
+        audio = seeded_audio(1, samples, seed=77 + j)
+        ci, cq = ref.extract_unit(audio, process_window=window)
+        wave = ref.decode_unit(chunk_indices=ci)
+        wave_q = ref.decode_unit(chunk_q_feature=cq)
+        assert torch.equal(wave, wave_q)
+        eu.append((samples, window))
+        out[f"eu{j}_chunk_len"] = np.int64(ci.chunk_len)
+        out[f"eu{j}_prefix_len"] = np.int64(ci.prefix_len)
+        out[f"eu{j}_chunk_tokens"] = np.array([len(c) for c in ci.chunk_data], dtype=np.int64)
+        out[f"eu{j}_indices"] = ci.data.numpy()
+        out[f"eu{j}_q_feature"] = cq.data.numpy()
+        out[f"eu{j}_wave"] = wave.numpy()
+    out["eu_cases"] = np.array(eu, dtype=np.int64)
+    out["eu_seed"] = np.int64(3)
+    np.savez_compressed(HERE / "chunk_kat.npz", **out)
+    print(f"[chunk_kat] written ({len(cases)} ChunkData cases, {len(eu)} extract_unit cases; extract_unit as written raises: {as_written})")
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     if "--boundary-only" in sys.argv:
         make_fsq_boundary_kat()
         sys.exit(0)
+    if "--chunk-only" in sys.argv:
+        make_chunk_kat()
+        sys.exit(0)
+    make_chunk_kat()
     make_fsq_kat()
     make_fsq_boundary_kat()
     make_model_fixtures("tiny", HERE / "tiny.toml", seed=3, batch=2, samples=250, full_tensors=True)

@@ -129,3 +129,45 @@ def test_fsq_rounding_boundaries():
         # the fixture really sits on the boundaries: some products are exactly k + 0.5, and both roundings occur
         prod = kat[f"{tag}_act"] * (np.asarray(levels, dtype=np.float32) - 1)
         assert ((prod - np.floor(prod)) == 0.5).any()
+
+
+def test_chunk_oracle_chunkdata_matches_reference():
+    """oracle/chunk_oracle.py::ChunkData and the product's l3ac_amd.chunking.ChunkData against the reference's own class
+    (tests/golden/chunk_kat.npz, written by make_golden.py running l3ac.codec.ChunkData): cut lengths and contents, merge of the
+    cut, merge of unrelated chunks (ragged tails, a single chunk, prefix = chunk_len - 1)."""
+    from l3ac_amd.chunking import ChunkData as ProductChunkData
+    from oracle.chunk_oracle import ChunkData
+    kat = np.load(GOLDEN / "chunk_kat.npz")
+    for i, (n, cl, pl) in enumerate(kat["cd_cases"]):
+        data = torch.arange(int(n), dtype=torch.int64) * 3 + 1
+        for cls in (ChunkData, ProductChunkData):
+            chunks = cls(chunk_len=int(cl), prefix_len=int(pl), original_data=data).chunk_data
+            assert [len(c) for c in chunks] == kat[f"cd{i}_lens"].tolist()
+            np.testing.assert_array_equal(torch.cat(chunks).numpy(), kat[f"cd{i}_cat"])
+            np.testing.assert_array_equal(cls(chunk_len=int(cl), prefix_len=int(pl), chunk_data=chunks).data.numpy(), kat[f"cd{i}_merged"])
+            other = torch.from_numpy(kat[f"cd{i}_other_cat"]).split(kat[f"cd{i}_lens"].tolist())
+            np.testing.assert_array_equal(cls(chunk_len=int(cl), prefix_len=int(pl), chunk_data=list(other)).data.numpy(),
+                                          kat[f"cd{i}_other_merged"])
+
+
+def test_chunk_oracle_extract_unit_matches_reference():
+    """The oracle's restatement of the reference's chunk plan (window rounded to whole hops, one-hop overlap, token-domain
+    ChunkData, merge) against Codec.extract_unit / decode_unit run by make_golden.py on the tiny conv codec: chunk geometry
+    exactly, tokens exactly, features and waveform to fp32 tolerance."""
+    from oracle import chunk_oracle as CO
+    kat = np.load(GOLDEN / "chunk_kat.npz")
+    assert kat["extract_unit_errors_as_written"].tolist() == ["KeyError", "AttributeError"]  # the method as shipped cannot run
+    mc, w, _, _ = load_case("tiny")
+    assert int(kat["eu_seed"]) == 3
+    for j, (samples, window) in enumerate(kat["eu_cases"]):
+        audio = seeded_audio(1, int(samples), seed=77 + j)
+        ci, cq = CO.conv_extract_unit(w, mc, audio, process_window=int(window))
+        assert ci.chunk_len == int(kat[f"eu{j}_chunk_len"]) and ci.prefix_len == int(kat[f"eu{j}_prefix_len"])
+        assert [len(c) for c in ci.chunk_data] == kat[f"eu{j}_chunk_tokens"].tolist()
+        np.testing.assert_array_equal(ci.data.numpy(), kat[f"eu{j}_indices"])
+        np.testing.assert_allclose(cq.data.numpy(), kat[f"eu{j}_q_feature"], atol=ATOL, rtol=RTOL)
+        wave = CO.conv_decode_unit(w, mc, ci)
+        np.testing.assert_allclose(wave.numpy(), kat[f"eu{j}_wave"], atol=ATOL, rtol=RTOL)
+    # prefix_tokens = 1 on the full-path variant gives the same split points as the reference's plan (one hop of overlap)
+    from l3ac_amd.chunking import plan
+    assert plan(12, 500, 1) == (492, 12)
