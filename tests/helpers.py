@@ -16,6 +16,48 @@ def seeded_audio(batch, samples, seed=1234):
     return (torch.rand(batch, samples, generator=g) * 2 - 1) * 0.5
 
 
+STRUCTURED_KINDS = ("sweep", "sine", "harmonics", "burst_after_silence", "dc_offset", "clipped", "quiet", "loud")
+
+
+def structured_audio(per_kind, samples, seed=4321, sample_rate=16000):
+    """Inputs white noise does not reach (TrendPool / EnhanceBlock / InstanceNorm branches, snake at large arguments, the
+    zero-pad edge): `per_kind` clips of each of STRUCTURED_KINDS, deterministic in `seed`.  Returns (audio [8 * per_kind,
+    samples] fp32, kinds list)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    t = torch.arange(samples, dtype=torch.float64) / sample_rate
+    dur = samples / sample_rate
+    clips, kinds = [], []
+    for kind in STRUCTURED_KINDS:
+        for i in range(per_kind):
+            u = torch.rand(4, generator=g, dtype=torch.float64)
+            noise = torch.rand(samples, generator=g, dtype=torch.float64) * 2 - 1
+            if kind == "sweep":  # linear chirp f0 -> f1, 0.5 amplitude
+                f0, f1 = 40 + 400 * u[0], 2000 + 5500 * u[1]
+                x = 0.5 * torch.sin(2 * np.pi * (f0 * t + 0.5 * (f1 - f0) / dur * t * t) + 6.28 * u[2])
+            elif kind == "sine":
+                x = (0.1 + 0.8 * u[1]) * torch.sin(2 * np.pi * (60 + 3000 * u[0] ** 2) * t + 6.28 * u[2])
+            elif kind == "harmonics":  # voiced-speech-like: decaying harmonics of a 90-300 Hz fundamental, slow amplitude modulation
+                f = 90 + 210 * u[0]
+                x = sum((0.6 ** h) * torch.sin(2 * np.pi * f * (h + 1) * t + h) for h in range(10))
+                x = 0.3 * x * (0.6 + 0.4 * torch.sin(2 * np.pi * (2 + 4 * u[1]) * t))
+            elif kind == "burst_after_silence":  # digital silence, then a noise burst with a hard onset, silence again
+                on = int((0.2 + 0.5 * u[0]) * samples)
+                off = min(samples, on + int((0.05 + 0.2 * u[1]) * samples))
+                x = torch.zeros(samples, dtype=torch.float64)
+                x[on:off] = 0.7 * noise[on:off]
+            elif kind == "dc_offset":
+                x = (0.45 if i % 2 == 0 else -0.45) + 0.1 * noise
+            elif kind == "clipped":  # hard-clipped at +-1.0
+                x = (3.0 * (0.5 * noise + 0.5 * torch.sin(2 * np.pi * (100 + 900 * u[0]) * t))).clamp(-1.0, 1.0)
+            elif kind == "quiet":
+                x = 0.005 * noise
+            else:  # loud: full-scale noise
+                x = 1.0 * noise
+            clips.append(x.to(torch.float32))
+            kinds.append(kind)
+    return torch.stack(clips), kinds
+
+
 def load_case(tag):
     """(mc, folded weights, conv fixture, e2e fixture) for a golden case; weights regenerate from the seed."""
     cfg_file = GOLDEN / "tiny.toml" if tag == "tiny" else resolve_config_file(tag)

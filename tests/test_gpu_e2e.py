@@ -240,6 +240,47 @@ def test_index_agreement_full_batch(tag):
         l3ac_amd.set_gemm_split(before)
 
 
+# mismatches observed on the MI355X per (config, input set), both GEMM routes (round 3; every one a +-1 flip within TAU)
+OBSERVED_WIDE_MISMATCHES = {}
+OBSERVED_WIDE_WAVE_ERR = 2e-3
+
+
+@pytest.mark.parametrize("tag", ["1kbps", "3kbps"])
+def test_index_agreement_other_seeds_and_structured_inputs(tag):
+    """Round-2 verdict: one draw of white noise says little.  Three further noise seeds (64 clips each) and a structured set
+    (chirps, sines, harmonic stacks, bursts after digital silence, DC offsets, hard-clipped +-1.0, 0.005 and 1.0 amplitudes; 8
+    clips each) are encoded on both GEMM routes and compared token for token with the oracle; the decoder is compared on the
+    structured set given the oracle's tokens.  Reported per set: flips, their margins, how close the set's latents come to a
+    boundary."""
+    from tests.helpers import structured_audio
+    codec = _codec(tag, 0)
+    mc = codec.network.mc
+    w = W.folded_weights(codec.network.state_dicts())
+    sets = {f"noise seed {sd}": seeded_audio(64, 16000, seed=sd) for sd in (1, 2, 3)}
+    sets["structured"], kinds = structured_audio(8, 16000)
+    before = l3ac_amd.get_gemm_split()
+    try:
+        for name, audio in sets.items():
+            idx_ref, lat_ref = _oracle_indices(w, mc, audio)
+            for route in (True, False):
+                l3ac_amd.set_gemm_split(route)
+                _, ind = codec.encode_audio(audio.cuda())
+                rep = index_agreement(ind["indices"].cpu().numpy(), idx_ref.numpy(), lat_ref.numpy(), mc.levels)
+                print(f"[index agreement {tag} {name} {'split' if route else 'exact'}] {rep}")
+                assert rep["single_step"] and rep["max_margin_of_mismatches"] < TAU
+                assert rep["mismatches"] <= OBSERVED_WIDE_MISMATCHES.get((tag, name), 0) + 1
+                if name == "structured":
+                    wave = codec.decode_audio(indices=idx_ref.cuda()).cpu()
+                    wave_ref = torch.cat([O.decode_audio(w, mc, indices=idx_ref[b0:b0 + ORACLE_CHUNK]) for b0 in range(0, len(idx_ref), ORACLE_CHUNK)])
+                    err = (wave - wave_ref).abs()
+                    per_kind = {k: float(err[[i for i, kk in enumerate(kinds) if kk == k]].max()) for k in dict.fromkeys(kinds)}
+                    print(f"[structured wave {tag} {'split' if route else 'exact'}] max err per kind: "
+                          + ", ".join(f"{k} {v:.2e}" for k, v in per_kind.items()))
+                    assert float(err.max()) < OBSERVED_WIDE_WAVE_ERR
+    finally:
+        l3ac_amd.set_gemm_split(before)
+
+
 def test_batch_invariance_3kbps_256():
     """3kbps at the BASELINE batch: the clip-group scheduling of the wide stages depends on the geometry (T = 167 / 668 /
     2672 frames), so batch invariance is asserted here as well as for 1kbps."""
@@ -257,6 +298,35 @@ def test_batch_invariance_3kbps_256():
         assert torch.equal(codec.decode_audio(q1), wave[b:b + 1])
     q64, ind64 = codec.encode_audio(audio[64:128])
     assert torch.equal(ind64["indices"], idx[64:128]) and torch.equal(codec.decode_audio(q64), wave[64:128])
+
+
+@pytest.mark.parametrize("tag", ["0k75bps", "1k5bps"])
+def test_batch_invariance_and_agreement_other_configs_256(tag):
+    """SURVEY §8 f2 at the headline batch: the other two shipped configs (hop 360: 135 frames / 45 tokens per second; hop 180:
+    178 frames / 89 tokens) cut their clip groups and attention windows differently from 1kbps / 3kbps.  A clip of the 256-batch
+    must be bit-identical alone, and the first 32 clips' tokens are compared with the oracle."""
+    codec = _codec(tag, 0)
+    mc = codec.network.mc
+    w = W.folded_weights(codec.network.state_dicts())
+    audio = seeded_audio(256, 16000)
+    q, ind = codec.encode_audio(audio.cuda())
+    idx = ind["indices"]
+    n_tok = -(-16000 // mc.hop_length)
+    assert idx.shape == (256, n_tok) and int(idx.min()) >= 0 and int(idx.max()) < mc.codebook_size
+    wave = codec.decode_audio(q)
+    assert wave.shape == (256, n_tok * mc.hop_length) and torch.isfinite(wave).all() and float(wave.abs().max()) <= 1.0
+    for b in (0, 77, 130, 255):
+        q1, ind1 = codec.encode_audio(audio[b:b + 1].cuda())
+        assert torch.equal(ind1["indices"], idx[b:b + 1]) and torch.equal(q1, q[b:b + 1])
+        assert torch.equal(codec.decode_audio(q1), wave[b:b + 1])
+    idx_ref, lat_ref = _oracle_indices(w, mc, audio[:32])
+    rep = index_agreement(idx[:32].cpu().numpy(), idx_ref.numpy(), lat_ref.numpy(), mc.levels)
+    print(f"[index agreement {tag} b256, first 32 clips] {rep}")
+    assert rep["single_step"] and rep["max_margin_of_mismatches"] < TAU and rep["mismatches"] <= 1  # observed: 0
+    wave_ref = O.decode_audio(w, mc, indices=idx_ref[:8])
+    err = float((codec.decode_audio(indices=idx_ref[:8].cuda()).cpu() - wave_ref).abs().max())
+    print(f"[{tag} wave given the oracle's tokens, 8 clips] max err {err:.3e}")
+    assert err < WAVE_ATOL
 
 
 def test_decoder_before_tanh_full_size():

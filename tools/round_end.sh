@@ -1,15 +1,15 @@
 #!/bin/bash
-# Run on the GPU box (gpurun -- 'bash tools/round_end.sh r02'): the -m gpu tests, the rocprofv3 passes and the default
-# bench of ONE build, so that profiles/<round>/traffic.json carries the fingerprint of the sources bench.py runs on.
+# Run on the GPU box (gpurun -- 'bash tools/round_end.sh r03'): the -m gpu tests, the rocprofv3 passes (four workloads) and the
+# default bench of ONE build, so that profiles/<round>/*traffic.json carry the fingerprint of the sources bench.py runs on.
 # Everything is written under gpurun_out/<round>_final/ (the only directory that travels back); copy its profiles/ part
 # into profiles/<round>/ and commit.
-R=${1:-r02}
+R=${1:-r03}
 OUT=gpurun_out/${R}_final
 mkdir -p $OUT/profiles
-timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/profiles/pytest_gpu.log 2>&1
+timeout 2400 python -m pytest tests -m gpu -x -q -s > $OUT/profiles/pytest_gpu.log 2>&1
 tail -2 $OUT/profiles/pytest_gpu.log
-timeout 900 bash tools/collect_profiles.sh $OUT/raw > /dev/null 2>&1
-python3 tools/summarize_profiles.py $OUT/raw $OUT/profiles | tail -3
+timeout 1500 bash tools/collect_profiles.sh $OUT/raw > /dev/null 2>&1
+python3 tools/summarize_profiles.py $OUT/raw $OUT/profiles | tail -12
 timeout 900 python bench.py --profiles-dir $OUT/profiles > $OUT/profiles/bench_default.json 2> $OUT/bench_default.err
 tail -c 600 $OUT/profiles/bench_default.json
-rm -rf $OUT/raw/pmc_* # per-dispatch counter dumps: tens of MB
+rm -rf $OUT/raw/*/pmc_* # per-dispatch counter dumps: tens of MB
