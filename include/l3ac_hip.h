@@ -140,6 +140,11 @@ int l3ac_fsq_quantize_act(const float* act, int64_t n, int32_t feat, const int32
 int l3ac_fsq_decode(const int32_t* indices, int64_t n, int32_t feat, const int32_t* levels, int32_t n_levels,
                     const float* w_out, const float* b_out, float* q_feature, void* stream);
 
+/* Measurement aid (no reference counterpart): the quantiser kernel's grid and per-lane access pattern at feat = 128, 6 levels
+ * — 512 B read, 512 + 4 + 24 B written per token — with no arithmetic: the HBM rate this access pattern can reach on the
+ * box, printed beside the quantiser's own rate by bench.py (`fsq_kernel.copy_ceiling`). */
+int l3ac_fsq_copy_ceiling(const float* x, int64_t n, float* q_feature, int32_t* indices, float* level_indices, void* stream);
+
 /* Explicit-codebook nearest neighbour (the search FSQ is the closed form of):
  * queries [n][dim] (= tanh(latents)), codebook [k][dim] (= indices_to_codes(arange(k)), vq/fsq.py:80-81);
  * out_idx[i] = argmin_k ||q_i - c_k||^2, lowest k on exact ties.  dim <= 8.

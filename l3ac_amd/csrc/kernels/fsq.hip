@@ -65,8 +65,15 @@ __device__ __forceinline__ void nt_store4(float* p, const float4& v) {
     __builtin_nontemporal_store(f32x4_nt{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4_nt*>(p));
 }
 
-template <int D, int NV>  // NV 16-byte chunks (4 channels each) per lane: lanes per token = feat / (4 NV)
-__global__ __launch_bounds__(THREADS) void fsq_kernel(const FsqDev p, const int lpt) {
+// NV 16-byte chunks (4 channels each) per lane: lanes per token = feat / (4 NV).  FEAT > 0 fixes the feature width at compile
+// time: every LDS weight address is then the lane's base + an immediate.  With a run-time width the 2 D NV addresses took a
+// register each and the kernel ran at 158 registers = 3 waves per SIMD (49 KB in flight per CU, and 2 048 blocks on 768 places:
+// a last round a third full); now 64-96 registers, OCC waves per SIMD.  FEAT = 0 is the generic form.
+template <int D, int NV, int FEAT, int OCC>
+__global__ __launch_bounds__(THREADS, OCC) void fsq_kernel(const FsqDev p_, const int lpt_) {
+    FsqDev p = p_;
+    if (FEAT) p.feat = FEAT;
+    const int lpt = FEAT ? FEAT / (4 * NV) : lpt_;
     // HBM-bound by construction (1 052 B per token); what limits it in practice is bytes in flight and issue slots,
     // so: projection weights in LDS (not registers), the next token group's rows prefetched into registers, each
     // block walking a contiguous token range, and ONE tanh per lane (lane d of a token's group quantises latent d
@@ -120,6 +127,7 @@ __global__ __launch_bounds__(THREADS) void fsq_kernel(const FsqDev p, const int 
         for (int v = 0; v < NV; ++v) xv[v] = x_next[v];
         fetch(g + 1);
         float li[D];
+        float li_mine = 0.f;  // spread mode: level index `sub` of this token (lanes sub < D)
         if (p.idx_in) {  // decode: indices -> level indices (vq/fsq.py:70-71)
             int idx = p.idx_in[tk];
             if ((unsigned)idx >= (unsigned)p.k_total) {  // corrupted / truncated stream: counted, clamped (never a wrapped level)
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(THREADS) void fsq_kernel(const FsqDev p, const int 
                 float mine = 0.f;  // latent `sub` of this token (all lanes of the group hold identical latents)
 #pragma unroll
                 for (int d = 0; d < D; ++d) mine = sub == d ? lat[d] : mine;
-                const float li_mine = quantise(mine, sub < D ? sub : 0);
+                li_mine = quantise(mine, sub < D ? sub : 0);
                 const int group_base = lane - sub;
 #pragma unroll
                 for (int d = 0; d < D; ++d) li[d] = __shfl(li_mine, group_base + d, 64);
@@ -184,13 +192,54 @@ __global__ __launch_bounds__(THREADS) void fsq_kernel(const FsqDev p, const int 
             float* dst = p.q_feature + tok * p.feat + cq;
 #pragma unroll
             for (int v = 0; v < NV; ++v) *reinterpret_cast<float4*>(dst + cstep * v) = o[v];
-            if (sub == 0) {
-                if (p.indices) p.indices[tok] = (int32_t)idx_f;
-                if (p.level_indices) {
+            if (sub == 0 && p.indices) p.indices[tok] = (int32_t)idx_f;
+            if (p.level_indices) {
+                if (spread && !p.idx_in) {
+                    // lane d of the token's group holds level index d: ONE store instruction per wave, the tokens' D values
+                    // contiguous (a wave's tokens are consecutive: 8 x 24 B in a row) instead of D scattered 4-byte stores
+                    if (sub < D) p.level_indices[tok * D + sub] = li_mine;
+                } else if (sub == 0) {
 #pragma unroll
                     for (int d = 0; d < D; ++d) p.level_indices[tok * D + d] = li[d];
                 }
             }
+        }
+    }
+}
+
+// The ceiling fsq_kernel is measured against: the same grid, the same per-lane access pattern (4 x 16 B loads per lane one
+// token group ahead, 4 x 16 B stores, 4 B per token of indices, 24 B per token of level indices) and NO arithmetic.
+__global__ __launch_bounds__(THREADS, 8) void fsq_copy_ceiling_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ q,
+                                                                    int32_t* __restrict__ idx, float* __restrict__ li) {
+    constexpr int FEAT = 128, NV = 4, LPT = 8, D = 6, TPB = THREADS / LPT;
+    const int tid = threadIdx.x, sub = tid % LPT;
+    const int cq = 4 * sub, cstep = 4 * LPT;
+    const int64_t n_groups = (n + TPB - 1) / TPB;
+    const int64_t per_block = (n_groups + gridDim.x - 1) / gridDim.x;
+    const int64_t g_begin = (int64_t)blockIdx.x * per_block;
+    const int64_t g_end = g_begin + per_block < n_groups ? g_begin + per_block : n_groups;
+    float4 nxt[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) nxt[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto fetch = [&](int64_t g) {
+        const int64_t t = g * TPB + tid / LPT;
+        if (g < g_end && t < n) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) nxt[v] = *reinterpret_cast<const float4*>(x + t * FEAT + cq + cstep * v);
+        }
+    };
+    fetch(g_begin);
+    for (int64_t g = g_begin; g < g_end; ++g) {
+        const int64_t tok = g * TPB + tid / LPT;
+        float4 cur[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) cur[v] = nxt[v];
+        fetch(g + 1);
+        if (tok < n) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) *reinterpret_cast<float4*>(q + tok * FEAT + cq + cstep * v) = cur[v];
+            if (sub == 0) idx[tok] = __float_as_int(cur[0].x);
+            if (sub < D) li[tok * D + sub] = cur[0].y;
         }
     }
 }
@@ -202,15 +251,39 @@ int launch_fsq_t(hipStream_t s, const FsqDev& p) {
     const int tok_per_block = THREADS / lpt;
     int64_t blocks = ceil_div64(p.n, tok_per_block);
     if (blocks <= 0) return L3AC_OK;
-    if (blocks > 256 * 8) blocks = 256 * 8;  // one weight staging per block, contiguous token range each
     const size_t lds = (size_t)(2 * D + 1) * p.feat * sizeof(float);
+    // One weight staging per block, a contiguous token range each, and ONE resident round: with more blocks than the chip
+    // holds at once the last, partly filled round streams at a fraction of the HBM rate for a whole block lifetime
+    // (2 048 blocks on 6 x 256 places: the last quarter of the work at a third of the bytes in flight).
+    // form: 0 generic nv 2, 1 generic nv 4, 2.. the feat = 128 specialisations at 5 / 6 / 8 waves per SIMD
+    static const int occ_env = [] {
+        const char* e = std::getenv("L3AC_FSQ_OCC");
+        return e ? std::atoi(e) : 0;
+    }();
+    const int occ = occ_env == 5 || occ_env == 6 || occ_env == 8 ? occ_env : 8;
+    const int form = (p.feat == 128 && nv == 4) ? (occ == 5 ? 2 : occ == 6 ? 3 : 4) : (nv == 4 ? 1 : 0);
+    const void* fns[5] = {reinterpret_cast<const void*>(fsq_kernel<D, 2, 0, 1>), reinterpret_cast<const void*>(fsq_kernel<D, 4, 0, 1>),
+                          reinterpret_cast<const void*>(fsq_kernel<D, 4, 128, 5>), reinterpret_cast<const void*>(fsq_kernel<D, 4, 128, 6>),
+                          reinterpret_cast<const void*>(fsq_kernel<D, 4, 128, 8>)};
+    static int per_cu[L3AC_MAX_DEVICES][5] = {};
+    int& resident = per_cu[l3ac_device_slot()][form];
+    if (resident <= 0) {
+        int v = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, fns[form], THREADS, lds) != hipSuccess || v <= 0) v = 3;
+        resident = v > 8 ? 8 : v;
+    }
+    const int64_t places = (int64_t)l3ac_device_cu_count() * resident;
+    if (blocks > places) blocks = places;
     const double in_b = p.x ? 4.0 * p.feat : (p.idx_in ? 4.0 : 4.0 * D);
     ProfScope prof(s, "fsq_kernel", 4.0 * D * p.feat * (double)p.n,
                    (double)p.n * (in_b + 4.0 * p.feat + (p.indices ? 4.0 : 0.0) + (p.level_indices ? 4.0 * D : 0.0)));
-    if (nv == 4)
-        hipLaunchKernelGGL((fsq_kernel<D, 4>), dim3((unsigned)blocks), dim3(THREADS), lds, s, p, lpt);
-    else
-        hipLaunchKernelGGL((fsq_kernel<D, 2>), dim3((unsigned)blocks), dim3(THREADS), lds, s, p, lpt);
+    switch (form) {
+        case 0: hipLaunchKernelGGL((fsq_kernel<D, 2, 0, 1>), dim3((unsigned)blocks), dim3(THREADS), lds, s, p, lpt); break;
+        case 1: hipLaunchKernelGGL((fsq_kernel<D, 4, 0, 1>), dim3((unsigned)blocks), dim3(THREADS), lds, s, p, lpt); break;
+        case 2: hipLaunchKernelGGL((fsq_kernel<D, 4, 128, 5>), dim3((unsigned)blocks), dim3(THREADS), lds, s, p, lpt); break;
+        case 3: hipLaunchKernelGGL((fsq_kernel<D, 4, 128, 6>), dim3((unsigned)blocks), dim3(THREADS), lds, s, p, lpt); break;
+        default: hipLaunchKernelGGL((fsq_kernel<D, 4, 128, 8>), dim3((unsigned)blocks), dim3(THREADS), lds, s, p, lpt); break;
+    }
     L3AC_LAUNCH_CHECK();
     return L3AC_OK;
 }
@@ -891,6 +964,17 @@ int launch_fsq(hipStream_t s, const FsqArgs& a) {
         case 7: return launch_fsq_t<7>(s, p);
         default: return launch_fsq_t<8>(s, p);
     }
+}
+
+int launch_fsq_copy_ceiling(hipStream_t s, const float* x, int64_t n, float* q, int32_t* idx, float* li) {
+    L3AC_REQUIRE(x && q && idx && li && n > 0, "fsq_copy_ceiling: bad arguments");
+    int64_t blocks = ceil_div64(n, THREADS / 8);
+    const int64_t places = (int64_t)l3ac_device_cu_count() * 8;
+    if (blocks > places) blocks = places;
+    ProfScope prof(s, "fsq_copy_ceiling_kernel", 0.0, (double)n * 1052.0);
+    hipLaunchKernelGGL(fsq_copy_ceiling_kernel, dim3((unsigned)blocks), dim3(THREADS), 0, s, x, n, q, idx, li);
+    L3AC_LAUNCH_CHECK();
+    return L3AC_OK;
 }
 
 size_t vq_argmin_scratch_bytes(int64_t n, int k, int form) { return vq_plan(n, k, form).bytes; }
