@@ -232,6 +232,9 @@ class L3AC:
             idx = indices.to(torch.int32).contiguous()
             b, n_tok = idx.shape
             f_ptr, i_ptr, keep = None, idx.data_ptr(), idx
+        if n_tok * mc.en_coder_compress_rate < 2:
+            # reference behaviour: the first EnhanceBlock's InstanceNorm1d (tconv/__init__.py:36) raises on a single frame
+            raise ValueError(f"Expected more than 1 spatial element when training, got input size torch.Size([{b}, 4, 1])")
         audio = torch.empty((b, n_tok * mc.hop_length), dtype=torch.float32, device=src.device)
         with torch.cuda.device(src.device):
             stream = torch.cuda.current_stream(src.device).cuda_stream

@@ -28,6 +28,7 @@ SOURCES = [
     "kernels/first_block.hip",
     "kernels/enhance.hip",
     "kernels/attention.hip",
+    "kernels/trans_stack.hip",
     "kernels/fsq.hip",
     "kernels/conv_unit_fused.hip",
     "kernels/conv_unit_split.hip",

@@ -1,0 +1,452 @@
+// One LocalTrans STACK (all layers of one reference `LocalTrans`, l3ac/local_trans.py:7-53) per launch, one workgroup per clip.
+// Arithmetic of PyPI local-attention==1.11.2 as configured by local_trans.py:23-53 (see attention.hip / DESIGN.md §4): per layer
+//
+//     x = x + to_out( causal_attention( to_qkv( LayerNorm(x) ) ) + distance bias )          (LocalMHA, prenorm, heads 6 x 32)
+//     x = x + W2( GEGLU( W1( LayerNorm(x) ) ) )                                                (FeedForward, inner 341)
+//
+// What it replaces: 7 launches per layer (LayerNorm, qkv GEMM, attention, out GEMM, LayerNorm, FF-in GEMM, FF-out GEMM — 56
+// launches and ~1.75 ms of the 256-clip step for 6 % of its FLOPs, ~45 % of a streaming chunk), each a round trip of the
+// [rows][128..704] tensors through L2 / HBM with a prologue and an epilogue around a K = 128..344 product.
+//
+// Here a clip's rows never leave the CU.  Clips are independent and, for the clip lengths this kernel takes (frames <= the
+// attention window and <= 192), every layer is a single window: ONE workgroup owns a clip for the whole stack.
+//   * wave w owns frames 16 w .. 16 w + 15 (the columns of every MFMA tile) from the first LayerNorm to the last residual; the
+//     residual stream x lives in its registers in accumulator layout (channel 16 t + 4 g + i in register i of tile t, lane
+//     (frame f, group g)), which is at once the LayerNorm's input (channel sums = 32 registers + two cross-lane steps) and,
+//     split into bf16 planes, the B operand of the next product in the k order sigma(g, j) = (j < 4 ? 4 g + j : 16 + 4 g + j - 4)
+//     (guide: 'An accumulator tile as the next MFMA's operand'; conv_unit_wide.hip uses the same order);
+//   * every product is weights (A) x activations (B) on v_mfma_f32_16x16x32_bf16 with both operands as exact bf16x3 splits
+//     (split_bf16.hpp: 6 plane products per fp32 MAC, error <= the fp32 instruction's), so each result tile is again in
+//     accumulator layout: q^T and k^T as computed; V with the operands SWAPPED (activations as A, weights as B: the same weight
+//     bytes) so that its tile is V[frame][d] — what P.V needs as its A operand; S^T = K.Q^T has keys on its rows, so the
+//     probabilities are directly the B operand of O^T = V^T.P^T; O^T that of the out projection; GEGLU's tile that of W2;
+//   * K and V^T of the current head are the only activations that cross waves: written to LDS as operand fragments by the
+//     producing lane itself (the lane that computed element (d, frame) is the lane that will read it as (key, d));
+//   * the weights of the stack are ONE stream of fragment-ordered bf16x3 "pieces" (16 rows x 32 k, 3 planes x 1 KB) in
+//     consumption order (trans_stack_image), L2-resident (1.37 MB per layer, every CU walks it in step), staged by LDS-DMA into a
+//     ring of 4 slots of 4 pieces behind a counted s_waitcnt vmcnt and one raw s_barrier per slot.
+// Online softmax over key steps of 32 (as attention_mfma_kernel); expf / erff are the OCML ones the unfused route uses.
+// Results differ from the unfused route's in rounding only (other summation orders); clip i of a batch is bit-identical to
+// clip i alone (one workgroup per clip, nothing depends on the batch).
+#include "../kernels.hpp"
+#include "../network.hpp"
+#include "device_math.hpp"
+#include "split_bf16.hpp"
+
+#include <cmath>
+#include <vector>
+
+namespace {
+
+constexpr int TS_DIM = 128, TS_HEADS = 6, TS_DH = 32, TS_INNER = TS_HEADS * TS_DH;
+constexpr int TS_FFI = 341;                    // int(128 * 4 * 2 / 3)
+constexpr int TS_FF_CHUNKS = (TS_FFI + 31) / 32;  // hidden units in chunks of 32 (zero padded)
+constexpr int TS_PIECE = 3072, TS_SLOT_PIECES = 4, TS_SLOT = TS_SLOT_PIECES * TS_PIECE, TS_RING_SLOTS = 4;
+constexpr int TS_PIECES_PER_HEAD = 32, TS_PIECES_PER_CHUNK = 24;
+constexpr int TS_PIECES_PER_LAYER = TS_HEADS * TS_PIECES_PER_HEAD + TS_FF_CHUNKS * TS_PIECES_PER_CHUNK;  // 456
+constexpr int TS_SLOTS_PER_LAYER = TS_PIECES_PER_LAYER / TS_SLOT_PIECES;                                // 114
+static_assert(TS_PIECES_PER_LAYER % TS_SLOT_PIECES == 0, "a layer is a whole number of ring slots");
+constexpr int TS_MAX_FRAMES = 192, TS_MAX_WAVES = TS_MAX_FRAMES / 16, TS_MAX_LAYERS = 8;
+// LDS (bytes)
+constexpr int TS_OFF_RING = 0;
+constexpr int TS_OFF_K = TS_OFF_RING + TS_RING_SLOTS * TS_SLOT;          // K fragments: [key tile 12][plane][lane] 16 B
+constexpr int TS_OFF_V = TS_OFF_K + TS_MAX_WAVES * TS_PIECE;             // V^T fragments: [key step 6][d tile 2][plane][lane] 16 B
+constexpr int TS_OFF_BIAS = TS_OFF_V + TS_MAX_WAVES * TS_PIECE;          // distance bias [heads][192]
+constexpr int TS_OFF_LN = TS_OFF_BIAS + TS_HEADS * TS_MAX_FRAMES * 4;    // LayerNorm parameters [layers][4][128]
+constexpr int ts_lds_bytes(int layers) { return TS_OFF_LN + layers * 4 * TS_DIM * 4; }
+static_assert(ts_lds_bytes(TS_MAX_LAYERS) <= 160 * 1024, "LDS budget exceeded");
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+struct TransStackArgs {
+    float* x;                  // [batch][frames][128], updated in place
+    int frames, n_layers;
+    const unsigned char* img;  // n_layers * TS_SLOTS_PER_LAYER slots
+    const float* ln;           // [n_layers][4][128]: norm.weight, norm.bias (LocalMHA), ff.0.weight, ff.0.bias
+    const float* bias_table;   // [heads][table_stride], entry = bias at distance i - j
+    int table_stride;
+    float scale;               // dim_head^-0.5 (applied to q before the scores, as the package does)
+};
+
+// the six plane products of one fragment pair, smallest first (split_bf16.hpp, mfma_split)
+__device__ __forceinline__ f32x4_t mfma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4_t acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
+    return acc;
+}
+
+// two accumulator tiles (rows 16 t + 4 g + i and 16 (t + 1) + 4 g + i of this lane's column) as the three bf16 planes of one
+// k step of 32 in the order sigma(g, j)
+__device__ __forceinline__ void planes_of(const f32x4_t& lo, const f32x4_t& hi, bf16x8 (&out)[3]) {
+    unsigned p[3][4];
+    split2(lo[0], lo[1], p[0][0], p[1][0], p[2][0]);
+    split2(lo[2], lo[3], p[0][1], p[1][1], p[2][1]);
+    split2(hi[0], hi[1], p[0][2], p[1][2], p[2][2]);
+    split2(hi[2], hi[3], p[0][3], p[1][3], p[2][3]);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) out[pl] = __builtin_bit_cast(bf16x8, u32x4{p[pl][0], p[pl][1], p[pl][2], p[pl][3]});
+}
+
+// this wave's quarter (3 KB) of one ring slot: three 1-KB LDS-DMA pieces, lane l copying 16 B (as conv_unit_wide.hip)
+__device__ __forceinline__ void ts_dma_quarter(const unsigned char* base, unsigned lane_off, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(lane_off), "s"(base), "s"(lds_dst)
+        : "memory");
+}
+
+__global__ __launch_bounds__(64 * TS_MAX_WAVES) void trans_stack_kernel(const TransStackArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_ts[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_waves = (int)(blockDim.x >> 6);
+    const int fl = lane & 15, lg = lane >> 4;
+    const int frames = p.frames;
+    const int frame = 16 * wave + fl;            // this lane's frame (column of every tile)
+    const bool frame_ok = frame < frames;
+    float* const xclip = p.x + (int64_t)blockIdx.x * frames * TS_DIM;
+    float* const bias_s = reinterpret_cast<float*>(smem_ts + TS_OFF_BIAS);
+    float* const ln_s = reinterpret_cast<float*>(smem_ts + TS_OFF_LN);
+
+    // ---- the residual stream of this wave's 16 frames: xr[t][i] = x[frame][16 t + 4 g + i] ------------------------------
+    f32x4_t xr[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        xr[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (frame_ok) xr[t] = *reinterpret_cast<const f32x4_t*>(xclip + (int64_t)frame * TS_DIM + 16 * t + 4 * lg);
+    }
+    // distance bias (distances 0 .. frames - 1 of every head) and the stack's LayerNorm parameters
+    for (int i = tid; i < TS_HEADS * TS_MAX_FRAMES; i += blockDim.x) {
+        const int h = i / TS_MAX_FRAMES, d = i % TS_MAX_FRAMES;
+        bias_s[i] = d < frames ? p.bias_table[(int64_t)h * p.table_stride + d] : 0.f;
+    }
+    for (int i = tid; i < p.n_layers * 4 * TS_DIM; i += blockDim.x) ln_s[i] = p.ln[i];
+    __syncthreads();  // (every plain load above is drained here, before the first hand-counted LDS-DMA is issued)
+
+    // ---- the weight stream -------------------------------------------------------------------------------------------
+    const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(smem_ts + TS_OFF_RING);
+    const unsigned lane_off = 16u * (unsigned)lane;
+    const int total_slots = p.n_layers * TS_SLOTS_PER_LAYER;
+    int dma_slot = 0;  // next slot of the stream to fetch (wave-uniform); past the end it wraps around (never consumed)
+    auto issue = [&]() __attribute__((always_inline)) {
+        if (wave < 4) {
+            const int src = dma_slot < total_slots ? dma_slot : dma_slot - total_slots;
+            ts_dma_quarter(p.img + (int64_t)src * TS_SLOT + TS_PIECE * wave, lane_off,
+                           ring_lds + (unsigned)((dma_slot & (TS_RING_SLOTS - 1)) * TS_SLOT + TS_PIECE * wave));
+        }
+        ++dma_slot;
+    };
+    // end of a slot step: this wave's copies of the NEXT slot have landed (all but the two youngest slots' 3 + 3 pieces), its
+    // own LDS reads and writes are done, then everybody's are; the slot just consumed is free for the next step's DMA
+    auto step_sync = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    issue();
+    issue();
+    issue();
+    step_sync();  // slot 0 has landed
+    int pc = 0;   // pieces consumed so far (wave-uniform)
+    const unsigned char* const ring_lane = smem_ts + TS_OFF_RING + 16 * lane;
+    // the next weight piece as an operand fragment (3 planes x 16 B of this lane)
+    auto next_piece = [&](bf16x8 (&f)[3]) __attribute__((always_inline)) {
+        if ((pc & (TS_SLOT_PIECES - 1)) == 0) issue();  // a new slot step begins: refill the slot consumed one step ago
+        const unsigned char* a = ring_lane + ((pc >> 2) & (TS_RING_SLOTS - 1)) * TS_SLOT + (pc & (TS_SLOT_PIECES - 1)) * TS_PIECE;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) f[pl] = *reinterpret_cast<const bf16x8*>(a + 1024 * pl);
+    };
+    auto piece_done = [&]() __attribute__((always_inline)) {
+        ++pc;
+        if ((pc & (TS_SLOT_PIECES - 1)) == 0) step_sync();
+    };
+
+    // LayerNorm over the 128 channels of this lane's frame (F.layer_norm, eps 1e-5: two-pass, rstd = 1 / sqrt(var + eps) as
+    // rows.hip), then the bf16x3 planes of the result: ap[s] = k step s (channels 32 s .. 32 s + 31)
+    bf16x8 ap[4][3];
+    auto layer_norm_planes = [&](const float* w, const float* b) __attribute__((always_inline)) {
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) s += (xr[t][0] + xr[t][1]) + (xr[t][2] + xr[t][3]);
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        const float mean = s / (float)TS_DIM;
+        float q = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float d = xr[t][i] - mean;
+                q = fmaf(d, d, q);
+            }
+        q += __shfl_xor(q, 16, 64);
+        q += __shfl_xor(q, 32, 64);
+        const float rstd = 1.0f / sqrtf(q / (float)TS_DIM + 1e-5f);
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            f32x4_t a[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int t = 2 * s2 + u;
+                const f32x4_t wv = *reinterpret_cast<const f32x4_t*>(w + 16 * t + 4 * lg);
+                const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(b + 16 * t + 4 * lg);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[u][i] = (xr[t][i] - mean) * rstd * wv[i] + bv[i];
+            }
+            planes_of(a[0], a[1], ap[s2]);
+        }
+    };
+
+    unsigned char* const k_mine = smem_ts + TS_OFF_K + wave * TS_PIECE + 16 * lane;                               // + 1024 plane
+    unsigned char* const v_mine = smem_ts + TS_OFF_V + (wave >> 1) * 2 * TS_PIECE + 16 * lane + 8 * (wave & 1);  // + 3072 dt + 1024 plane
+    const unsigned char* const k_lane = smem_ts + TS_OFF_K + 16 * lane;
+    const unsigned char* const v_lane = smem_ts + TS_OFF_V + 16 * lane;
+    const int key_steps = (wave >> 1) + 1;  // causal: keys 0 .. 16 wave + 15 in steps of 32
+
+#pragma unroll 1
+    for (int layer = 0; layer < p.n_layers; ++layer) {
+        const float* const lnp = ln_s + layer * 4 * TS_DIM;
+        // ================= LocalMHA ===================================================================================
+        layer_norm_planes(lnp, lnp + TS_DIM);
+#pragma unroll 1
+        for (int h = 0; h < TS_HEADS; ++h) {
+            bf16x8 f[3];
+            // ---- q^T, k^T (weights x activations) and V (activations x weights) of head h for this wave's frames ------
+            f32x4_t qa[2], ka[2], va[2];
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                qa[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    next_piece(f);
+                    qa[dt] = mfma6(f, ap[s], qa[dt]);
+                    piece_done();
+                }
+            }
+            bf16x8 qp[3];
+            {
+                f32x4_t q0 = qa[0] * p.scale, q1 = qa[1] * p.scale;  // q pre-scaled (local_attention: q = q * scale)
+                planes_of(q0, q1, qp);
+            }
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                ka[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    next_piece(f);
+                    ka[dt] = mfma6(f, ap[s], ka[dt]);
+                    if (dt == 1 && s == 3) {  // K of this wave's 16 keys as S^T's A-operand fragment, before the slot's barrier
+                        bf16x8 kp[3];
+                        planes_of(ka[0], ka[1], kp);
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bf16x8*>(k_mine + 1024 * pl) = kp[pl];
+                    }
+                    piece_done();
+                }
+            }
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                va[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    next_piece(f);
+                    va[dt] = mfma6(ap[s], f, va[dt]);  // operands swapped: va[dt][i] = V[frame 16 wave + 4 g + i][d = 16 dt + fl]
+                    if (s == 3) {  // half (keys of this wave) of the V^T fragment of key step wave / 2, d tile dt
+                        unsigned w0[3], w1[3];
+                        split2(va[dt][0], va[dt][1], w0[0], w0[1], w0[2]);
+                        split2(va[dt][2], va[dt][3], w1[0], w1[1], w1[2]);
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl)
+                            *reinterpret_cast<uint2*>(v_mine + TS_PIECE * dt + 1024 * pl) = make_uint2(w0[pl], w1[pl]);
+                    }
+                    piece_done();  // (the last one ends a slot step: its barrier publishes K and V of every wave)
+                }
+            }
+            // ---- causal attention of this wave's 16 queries over keys 0 .. 16 wave + 15 ------------------------------
+            float m_run = -INFINITY, l_run = 0.f;
+            f32x4_t oa[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+            const float* const bias_h = bias_s + h * TS_MAX_FRAMES;
+#pragma unroll 1
+            for (int ks = 0; ks < key_steps; ++ks) {
+                f32x4_t st[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    bf16x8 kf[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) kf[pl] = *reinterpret_cast<const bf16x8*>(k_lane + (2 * ks + u) * TS_PIECE + 1024 * pl);
+                    st[u] = mfma6(kf, qp, f32x4_t{0.f, 0.f, 0.f, 0.f});  // S^T[key 32 ks + 16 u + 4 g + i][query fl]
+                }
+                float mx = -INFINITY;
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int key = 32 * ks + 16 * u + 4 * lg + i;
+                        const bool vis = key <= frame;
+                        const float sv = vis ? st[u][i] + bias_h[vis ? frame - key : 0] : -INFINITY;
+                        st[u][i] = sv;
+                        mx = fmaxf(mx, sv);
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float m_new = fmaxf(m_run, mx);  // finite from the first step on: key 0 is visible to every query
+                const float alpha = expf(m_run - m_new);
+                float psum = 0.f;
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float pv = expf(st[u][i] - m_new);  // masked entries: exp(-inf) = 0
+                        st[u][i] = pv;
+                        psum += pv;
+                    }
+                l_run = l_run * alpha + psum;
+                m_run = m_new;
+                bf16x8 pp[3];
+                planes_of(st[0], st[1], pp);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    bf16x8 vf[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) vf[pl] = *reinterpret_cast<const bf16x8*>(v_lane + (2 * ks + dt) * TS_PIECE + 1024 * pl);
+                    oa[dt] = mfma6(vf, pp, oa[dt] * alpha);  // O^T[d = 16 dt + 4 g + i][query fl]
+                }
+            }
+            float l_tot = l_run + __shfl_xor(l_run, 16, 64);
+            l_tot += __shfl_xor(l_tot, 32, 64);
+            const float inv = 1.0f / l_tot;
+            bf16x8 op[3];
+            {
+                f32x4_t o0 = oa[0] * inv, o1 = oa[1] * inv;
+                planes_of(o0, o1, op);
+            }
+            // ---- out projection of this head's 32 columns, accumulated onto the residual stream ------------------------
+#pragma unroll
+            for (int rt = 0; rt < 8; ++rt) {
+                next_piece(f);
+                xr[rt] = mfma6(f, op, xr[rt]);
+                piece_done();
+            }
+        }
+        // ================= FeedForward (GEGLU) ========================================================================
+        layer_norm_planes(lnp + 2 * TS_DIM, lnp + 3 * TS_DIM);
+#pragma unroll 1
+        for (int c = 0; c < TS_FF_CHUNKS; ++c) {
+            bf16x8 f[3];
+            f32x4_t vg[4];  // value tiles 0, 1 then gate tiles 0, 1 of hidden units 32 c .. 32 c + 31
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                vg[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    next_piece(f);
+                    vg[u] = mfma6(f, ap[s], vg[u]);
+                    piece_done();
+                }
+            }
+            bf16x8 hp[3];
+            {
+                f32x4_t h0, h1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    h0[i] = vg[0][i] * gelu_erf(vg[2][i]);  // GEGLU: value * gelu(gate), the first half is the value
+                    h1[i] = vg[1][i] * gelu_erf(vg[3][i]);
+                }
+                planes_of(h0, h1, hp);
+            }
+#pragma unroll
+            for (int rt = 0; rt < 8; ++rt) {
+                next_piece(f);
+                xr[rt] = mfma6(f, hp, xr[rt]);
+                piece_done();
+            }
+        }
+    }
+    // leave no LDS-DMA in flight behind the workgroup, then write the residual stream back
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (frame_ok) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) *reinterpret_cast<f32x4_t*>(xclip + (int64_t)frame * TS_DIM + 16 * t + 4 * lg) = xr[t];
+    }
+}
+
+// one piece: 16 rows x 32 k of a row-major [n][ld] matrix (rows >= n_rows / columns >= n_cols: zeros) as the three bf16 planes of
+// the operand fragment — lane (m = lane & 15, g = lane >> 4) holds the 8 values W[row0 + m][k0 + sigma(g, j)], j = 0 .. 7
+void put_piece(std::vector<unsigned char>& img, const float* w, int64_t ld, int n_rows, int n_cols, int row0, int k0) {
+    const size_t base = img.size();
+    img.resize(base + TS_PIECE, 0);
+    for (int g = 0; g < 4; ++g)
+        for (int m = 0; m < 16; ++m)
+            for (int j = 0; j < 8; ++j) {
+                const int k = k0 + (j < 4 ? 4 * g + j : 16 + 4 * g + j - 4);
+                const int r = row0 + m;
+                const float v = (r < n_rows && k < n_cols) ? w[(int64_t)r * ld + k] : 0.f;
+                uint16_t pl[3];
+                split3_host(v, pl);
+                for (int p = 0; p < 3; ++p) std::memcpy(img.data() + base + (size_t)p * 1024 + (size_t)(16 * g + m) * 16 + 2 * j, &pl[p], 2);
+            }
+}
+
+}  // namespace
+
+bool trans_stack_supported(int dim, int dim_head, int heads, int ff_inner, int frames, int window, int n_layers) {
+    return dim == TS_DIM && dim_head == TS_DH && heads == TS_HEADS && ff_inner == TS_FFI && frames >= 1 && frames <= TS_MAX_FRAMES &&
+           frames <= window && n_layers >= 1 && n_layers <= TS_MAX_LAYERS;
+}
+
+// The weight stream of one layer in consumption order (host, at model-build time).  wqkv [576][128], wout [128][192] as the
+// reference stores them; wff1 / wff2 in the re-laid forms of network.hip (value / gate 32-row tiles interleaved, [ff_n][128];
+// [128][ff_pad] zero padded along k).
+void trans_stack_layer_image(std::vector<unsigned char>& img, const float* wqkv, const float* wout, const float* wff1, int ff_n,
+                             const float* wff2, int ff_pad) {
+    for (int h = 0; h < TS_HEADS; ++h) {
+        for (int part = 0; part < 3; ++part)
+            for (int dt = 0; dt < 2; ++dt)
+                for (int s = 0; s < 4; ++s) put_piece(img, wqkv, TS_DIM, 3 * TS_INNER, TS_DIM, part * TS_INNER + h * TS_DH + 16 * dt, 32 * s);
+        for (int rt = 0; rt < 8; ++rt) put_piece(img, wout, TS_INNER, TS_DIM, TS_INNER, 16 * rt, 32 * h);
+    }
+    for (int c = 0; c < TS_FF_CHUNKS; ++c) {
+        for (int half = 0; half < 2; ++half)  // value rows 64 c + r, gate rows 64 c + 32 + r of the interleaved image
+            for (int t = 0; t < 2; ++t)
+                for (int s = 0; s < 4; ++s) put_piece(img, wff1, TS_DIM, ff_n, TS_DIM, 64 * c + 32 * half + 16 * t, 32 * s);
+        for (int rt = 0; rt < 8; ++rt) put_piece(img, wff2, ff_pad, TS_DIM, ff_pad, 16 * rt, 32 * c);
+    }
+}
+int64_t trans_stack_layer_image_bytes() { return (int64_t)TS_SLOTS_PER_LAYER * TS_SLOT; }
+
+int launch_trans_stack(hipStream_t s, const LocalTransW& w, float* x, int batch, int frames, float scale) {
+    const int n_layers = (int)w.layers.size();
+    L3AC_REQUIRE(w.stack_img && w.stack_ln && batch > 0 && frames >= 1 && frames <= TS_MAX_FRAMES && frames <= w.window &&
+                     n_layers >= 1 && n_layers <= TS_MAX_LAYERS,
+                 "trans_stack: bad arguments (frames=%d window=%d layers=%d)", frames, w.window, n_layers);
+    const int lds = ts_lds_bytes(n_layers);
+    static PerDeviceOnce configured;
+    if (configured.first()) {
+        L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trans_stack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           ts_lds_bytes(TS_MAX_LAYERS)));
+        configured.done();
+    }
+    int waves = 2 * (int)ceil_div64(frames, 32);  // even: every key tile a wave reads in pairs has been written by some wave
+    if (waves < 4) waves = 4;                      // waves 0 .. 3 carry the weight stream
+    TransStackArgs a{};
+    a.x = x; a.frames = frames; a.n_layers = n_layers; a.img = w.stack_img; a.ln = w.stack_ln; a.bias_table = w.bias_table;
+    a.table_stride = 2 * w.window; a.scale = scale;
+    const double rows = (double)batch * frames;
+    const double lin = 2.0 * (3.0 * TS_INNER * TS_DIM + TS_DIM * TS_INNER + 3.0 * TS_FFI * TS_DIM);
+    const double att = 2.0 * 2.0 * TS_INNER * 0.5 * (frames + 1.0);
+    ProfScope prof(s, "trans_stack_kernel", n_layers * rows * (lin + att), 2.0 * rows * TS_DIM * 4.0);
+    hipLaunchKernelGGL(trans_stack_kernel, dim3((unsigned)batch), dim3(64 * waves), lds, s, a);
+    L3AC_LAUNCH_CHECK();
+    return L3AC_OK;
+}

@@ -303,6 +303,28 @@ int network_build(l3ac_ctx* ctx, const l3ac_tensor* tensors, int n_tensors) {
         ctx->en_dec.push_back(build_local_trans(b, ctx, "en_decoder.local_trans", win, c.en_coder_depth));
     }
 
+    // the stacks as trans_stack_kernel takes them (the stack vectors no longer reallocate: the image targets stay valid)
+    if (b.err.empty()) {
+        const int dim = c.feature_dim;
+        for (auto* stacks : {&ctx->en_enc, &ctx->en_dec})
+            for (LocalTransW& t : *stacks) {
+                if (!trans_stack_supported(dim, ctx->dim_head, HEADS, ctx->ff_inner, 1, t.window, (int)t.layers.size())) continue;
+                const float* d = nullptr;
+                float* ln = b.alloc(t.layers.size() * 4 * (size_t)dim, &d);
+                if (!d) continue;
+                t.stack_ln = d;
+                std::vector<unsigned char> img;
+                img.reserve(t.layers.size() * (size_t)trans_stack_layer_image_bytes());
+                for (size_t l = 0; l < t.layers.size(); ++l) {
+                    const TransLayerW& w = t.layers[l];
+                    const float* srcs[4] = {w.ln1w, w.ln1b, w.ln2w, w.ln2b};
+                    for (int q = 0; q < 4; ++q) std::memcpy(ln + (l * 4 + q) * dim, b.host_of(srcs[q]), dim * sizeof(float));
+                    trans_stack_layer_image(img, b.host_of(w.wqkv), b.host_of(w.wout), b.host_of(w.wff1), ctx->ff_n, b.host_of(w.wff2), ctx->ff_pad);
+                }
+                b.extra_imgs.push_back({std::move(img), &t.stack_img});
+            }
+    }
+
     // ---- quantiser (vq/__init__.py:13-14) -------------------------------------------------------------
     ctx->q_win = b.copy("quantizer.project_in.weight", (int64_t)c.n_levels * c.feature_dim);
     ctx->q_bin = b.copy("quantizer.project_in.bias", c.n_levels);
@@ -771,7 +793,19 @@ int run_last_block(l3ac_ctx* ctx, hipStream_t s, float* x, float* audio, int bat
     return launch_head(s, ws.a, batch, frames, hd.c, hd.w, hd.b, audio, ctx->head_pretanh);
 }
 
+// the fused stack kernel computes on the bf16 matrix cores only (bf16x3): it belongs to the split route
+static bool use_trans_stack(const l3ac_ctx* ctx, const LocalTransW& w, int frames) {
+    static const bool off = [] {
+        const char* e = std::getenv("L3AC_TRANS_FUSED");
+        return e && std::atoi(e) == 0;
+    }();
+    return !off && ctx->gemm_split && w.stack_img && w.stack_ln &&
+           trans_stack_supported(ctx->cfg.feature_dim, ctx->dim_head, HEADS, ctx->ff_inner, frames, w.window, (int)w.layers.size());
+}
+
 int run_local_trans(l3ac_ctx* ctx, hipStream_t s, const LocalTransW& w, float* x, int batch, int frames) {
+    if (use_trans_stack(ctx, w, frames))  // one launch for the whole stack, one workgroup per clip
+        return launch_trans_stack(s, w, x, batch, frames, (float)std::pow((double)ctx->dim_head, -0.5));
     Workspace& ws = ctx->ws;
     const int dim = ctx->cfg.feature_dim;
     const int64_t rows = (int64_t)batch * frames;

@@ -51,6 +51,10 @@ struct LocalTransW {  // local_trans.py:7-53
     int window = 0;
     std::vector<TransLayerW> layers;
     const float* bias_table = nullptr;  // [heads][2 * window]
+    // the whole stack for trans_stack_kernel (kernels/trans_stack.hip): the layers' weights as one fragment-ordered bf16x3 stream
+    // in consumption order, and their LayerNorm parameters [layers][4][dim]; null when the geometry is not the kernel's
+    const unsigned char* stack_img = nullptr;
+    const float* stack_ln = nullptr;
 };
 
 struct Workspace {
@@ -131,6 +135,12 @@ size_t conv_unit_wide_scratch_bytes(int c, int64_t rows);
 int launch_conv_unit_wide(hipStream_t s, const ConvUnitW& w, const float* x, float* y, unsigned char* planes, size_t planes_bytes, int batch,
                           int frames);
 std::vector<unsigned char> conv_unit_wide_image(const float* w1, const float* w2, int c);  // w1 [4c][c], w2 [c][4c]
+// one LocalTrans stack per launch, one workgroup per clip (kernels/trans_stack.hip); x [batch][frames][128] in place
+bool trans_stack_supported(int dim, int dim_head, int heads, int ff_inner, int frames, int window, int n_layers);
+void trans_stack_layer_image(std::vector<unsigned char>& img, const float* wqkv, const float* wout, const float* wff1, int ff_n,
+                             const float* wff2, int ff_pad);
+int64_t trans_stack_layer_image_bytes();
+int launch_trans_stack(hipStream_t s, const LocalTransW& w, float* x, int batch, int frames, float scale);
 // fused LegacyUnit / head (kernels/last_block.hip); x must not alias y
 bool last_block_fused_supported(int c, int max_dil);
 // host builders of the LegacyUnit weight images: w1 [c][7][c] (tap-major rows), w2 [c][c]

@@ -187,7 +187,7 @@ def _tap(taps, name, x):
 def dynamic_position_bias(w, prefix, i, j):
     """local_attention.transformer.DynamicPositionBias(dim, heads).forward(i, j): an MLP over the integer
     distance, gathered at |(j - i + a) - b|.  Returns (heads, i, j).  Call site: local_trans.py:43."""
-    rel = torch.arange(j, dtype=torch.float32).unsqueeze(-1)
+    rel = torch.arange(j, dtype=w[f"{prefix}.mlp.0.weight"].dtype).unsqueeze(-1)  # (fp32; fp64 when the test evaluates the stack in double)
     h = F.silu(F.linear(rel, w[f"{prefix}.mlp.0.weight"], w[f"{prefix}.mlp.0.bias"]))
     h = F.silu(F.linear(h, w[f"{prefix}.mlp.2.weight"], w[f"{prefix}.mlp.2.bias"]))
     table = F.linear(h, w[f"{prefix}.mlp.4.weight"], w[f"{prefix}.mlp.4.bias"])  # (j, heads)
@@ -197,7 +197,7 @@ def dynamic_position_bias(w, prefix, i, j):
 
 def position_bias_table(w, prefix, window):
     """The (2W, heads) distance table the bias is gathered from (input independent)."""
-    rel = torch.arange(2 * window, dtype=torch.float32).unsqueeze(-1)
+    rel = torch.arange(2 * window, dtype=w[f"{prefix}.mlp.0.weight"].dtype).unsqueeze(-1)
     h = F.silu(F.linear(rel, w[f"{prefix}.mlp.0.weight"], w[f"{prefix}.mlp.0.bias"]))
     h = F.silu(F.linear(h, w[f"{prefix}.mlp.2.weight"], w[f"{prefix}.mlp.2.bias"]))
     return F.linear(h, w[f"{prefix}.mlp.4.weight"], w[f"{prefix}.mlp.4.bias"])

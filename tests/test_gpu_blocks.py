@@ -252,7 +252,7 @@ def test_conv_units_wide_scratch_on_a_fresh_context():
     codec.network.to(device="cuda").eval()
     mc = codec.network.mc
     w = W.folded_weights(codec.network.state_dicts())
-    audio = seeded_audio(1, mc.hop_length)  # one token
+    audio = seeded_audio(1, 2 * mc.hop_length)  # two tokens (with ONE the reference itself raises: InstanceNorm over a single frame)
     q, ind = codec.encode_audio(audio.cuda())
     wave = codec.decode_audio(q)
     torch.cuda.synchronize()
@@ -332,6 +332,51 @@ def test_local_trans_single_and_multi_window(tiny, full):
         ref = O.local_trans(w, block, x, window, depth)
         got = G.op_block(codec.network.context(), "l3ac_op_local_trans", block, x.cuda(), (2, t, 128))
         _close(f"{block} T={t} W={window}", got.cpu(), ref, atol=1e-4, rtol=1e-4)
+
+
+def test_local_trans_stack_kernel(full):
+    """trans_stack_kernel (one launch per LocalTrans stack, one workgroup per clip: LayerNorm, qkv, causal attention + distance
+    bias, out projection, GEGLU FeedForward, all on bf16x3 MFMAs with the clip resident on the CU) against the oracle for every
+    stack of the 1kbps and 3kbps models: full-length clips, lengths that are not multiples of 16 / 32 (padding frames inside the
+    last wave's tile, an odd number of key tiles), a single frame, and a batch larger than the chip holds workgroups at once.  The
+    fp64 evaluation of the same stack bounds the error: the fused kernel may not be less accurate than the unfused route."""
+    codec, mc, w = full
+    ctx = codec.network.context()
+    cases = [("en_encoder.down_trans.trans", 750, 1, 180, 3), ("en_encoder.local_trans", 250, 2, 60, 3),
+             ("en_decoder.local_trans", 250, 3, 60, 2), ("en_decoder.up_trans.trans", 750, 2, 180, 2),
+             ("en_decoder.up_trans.trans", 750, 2, 177, 2), ("en_decoder.local_trans", 250, 3, 45, 2),
+             ("en_decoder.local_trans", 250, 3, 1, 2), ("en_decoder.up_trans.trans", 750, 2, 33, 1),
+             ("en_decoder.up_trans.trans", 750, 2, 192, 1), ("en_encoder.local_trans", 250, 2, 17, 300)]
+    for block, window, depth, t, bsz in cases:
+        x = _rand((bsz, t, 128), 500 + t + bsz)
+        ref = O.local_trans(w, block, x[:4], window, depth)
+        got = G.op_block(ctx, "l3ac_op_local_trans", block, x.cuda(), (bsz, t, 128)).cpu()
+        _close(f"stack {block} T={t} B={bsz}", got[:4], ref, atol=1e-4, rtol=1e-4)
+        if bsz > 4:  # clips are independent: every clip of the big batch equals the same clip run alone
+            alone = G.op_block(ctx, "l3ac_op_local_trans", block, x[[0, 255, 299]].cuda(), (3, t, 128)).cpu()
+            assert torch.equal(alone, got[[0, 255, 299]])
+    codec3 = l3ac_amd.get_model("3kbps", synthetic_seed=0)
+    codec3.network.to(device="cuda").eval()
+    w3 = W.folded_weights(codec3.network.state_dicts())
+    for block, depth, t in (("en_encoder.local_trans", 1, 167), ("en_decoder.local_trans", 3, 167), ("en_decoder.local_trans", 3, 100)):
+        x = _rand((2, t, 128), 600 + t)
+        ref = O.local_trans(w3, block, x, 400, depth)
+        got = G.op_block(codec3.network.context(), "l3ac_op_local_trans", block, x.cuda(), (2, t, 128)).cpu()
+        _close(f"3kbps stack {block} T={t}", got, ref, atol=1e-4, rtol=1e-4)
+    # accuracy against fp64, fused vs unfused (the exact-fp32 route of the same context runs the unfused kernels)
+    block, window, depth, t = "en_decoder.up_trans.trans", 750, 2, 180
+    x = _rand((4, t, 128), 777)
+    ref64 = O.local_trans({k: v.double() for k, v in w.items() if k.startswith(block)}, block, x.double(), window, depth)
+    fused = G.op_block(ctx, "l3ac_op_local_trans", block, x.cuda(), (4, t, 128)).cpu().double()
+    ctx.set_gemm_split(False)
+    try:
+        unfused = G.op_block(ctx, "l3ac_op_local_trans", block, x.cuda(), (4, t, 128)).cpu().double()
+    finally:
+        ctx.set_gemm_split(True)
+    e_f, e_u = (fused - ref64).abs(), (unfused - ref64).abs()
+    print(f"[trans stack vs fp64] fused max {float(e_f.max()):.3e} rms {float(e_f.pow(2).mean().sqrt()):.3e} | "
+          f"exact-fp32 unfused max {float(e_u.max()):.3e} rms {float(e_u.pow(2).mean().sqrt()):.3e}")
+    assert float(e_f.pow(2).mean().sqrt()) <= 1.5 * float(e_u.pow(2).mean().sqrt()) + 1e-9
 
 
 # ---------------------------------------------------------------------------------------------------
