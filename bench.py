@@ -183,7 +183,7 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--cpu-threads", type=int, default=32,
                     help="host threads for the CPU baseline (32 measured fastest on the 256-thread GPU box; "
-                         "torch's default of 128 is 3x slower: tools/experiments/cpu_threads.py)")
+                         "torch's default of 128 is 3x slower: tools/cpu_threads.py)")
     ap.add_argument("--agreement-clips", type=int, default=-1,
                     help="clips of the batch whose tokens are compared with the oracle (default: all of them)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph")

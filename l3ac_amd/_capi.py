@@ -7,7 +7,7 @@ from pathlib import Path
 
 import os
 
-# L3AC_LIB_PATH: load another build of the same library (experiment builds under tools/experiments/_build); default in-tree
+# L3AC_LIB_PATH: load another build of the same library (experiment builds); default in-tree
 LIB_PATH = Path(os.environ.get("L3AC_LIB_PATH") or Path(__file__).resolve().parent / "libl3ac_hip.so")
 ABI_VERSION = 3
 MAX_STAGES = 8

@@ -26,7 +26,7 @@
 //                            stays L2-resident: every CU walks it in step.  The first product of hidden tile nt+1 (MFMA) is
 //                            interleaved in program order with the activation + split of tile nt (VALU).
 // Why the front end is a kernel of its own: with one wave per SIMD nothing covers a load phase, and measured inside the main
-// kernel (tools/wide_stamps.py on tools/experiments/conv_unit_wide_v1.hip, conv_unit_wide_v2.hip) the depth-wise conv's 38
+// kernel (tools/wide_stamps.py on tools/experiments/conv_unit_wide_v1.hip (retired: git show 1a7dadb:tools/experiments/conv_unit_wide_v1.hip), conv_unit_wide_v2.hip) the depth-wise conv's 38
 // rows per tile cost 17-32 % of a pass however they were fetched; as a full-occupancy streaming kernel the same work is
 // HBM-bound and the main kernel's prologue becomes 48 coalesced 16-B loads per lane.
 // Tiles are 32 consecutive GLOBAL rows (clip boundaries only matter to the front end's taps).

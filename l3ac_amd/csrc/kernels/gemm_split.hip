@@ -8,7 +8,7 @@
 // three 8-bit significands = the whole 24-bit fp32 significand, so the split loses nothing.  a.w is evaluated as the
 // six plane products with i + j <= 2 (a2w0, a1w1, a0w2, a1w0, a0w1, a0w0 — smallest first), each product exact in
 // fp32 (8 x 8 bits), accumulated in the MFMA's fp32 accumulator; the three dropped products are <= 2^-26 |a.w|, below
-// fp32's own product rounding (2^-24).  Measured against fp64 on the L3AC shapes (tools/experiments/split_gemm.hip,
+// fp32's own product rounding (2^-24).  Measured against fp64 on the L3AC shapes (tools/experiments/split_gemm.hip (retired: git show 1a7dadb:tools/experiments/split_gemm.hip),
 // tests/test_gpu_blocks.py::test_gemm_split_accuracy) the error is <= that of the k-ordered fp32 fmaf chain which
 // v_mfma_f32_32x32x2_f32 (gemm_f32.hip) computes: rms 2.0e-8 vs 2.4e-8 of sum|a.w|.  This is NOT a reduced-precision
 // path: every bit of both fp32 operands takes part.

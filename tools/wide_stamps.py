@@ -7,7 +7,7 @@
 The kernel stamps s_memtime (shader cycles) at the phase boundaries of every pass of wave 0 of every workgroup into a
 __device__ array that only this tool reads.  Phases: 0 pass start | 1 after the plane loads | 2 after the entry barrier |
 3 after the first product of hidden tile 0 | 4 after the hidden-tile loop | 5 after the last tile | 6 after the residual store
-(written by the NEXT stamp 0 / the final stamp).  (tools/experiments/conv_unit_wide_v1.hip / _v2.hip carry the same stamps.)
+(written by the NEXT stamp 0 / the final stamp).  (tools/experiments/conv_unit_wide_v1.hip (retired: git show 1a7dadb:tools/experiments/conv_unit_wide_v1.hip) / _v2.hip carry the same stamps.)
 """
 import ctypes as C
 import sys
