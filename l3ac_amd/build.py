@@ -15,8 +15,11 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 REPO = PKG.parent
 CSRC = PKG / "csrc"
-OBJ_DIR = CSRC / "build"
-LIB_PATH = PKG / "libl3ac_hip.so"
+# L3AC_BUILD_TAG=<tag> builds a second, independent library (libl3ac_hip_<tag>.so, objects under csrc/build_<tag>): diagnostic
+# and timing-only builds (L3AC_EXTRA_HIPCC_FLAGS=-D...) next to the product library; load it with L3AC_LIB_PATH.
+_TAG = os.environ.get("L3AC_BUILD_TAG", "")
+OBJ_DIR = CSRC / (f"build_{_TAG}" if _TAG else "build")
+LIB_PATH = PKG / (f"libl3ac_hip_{_TAG}.so" if _TAG else "libl3ac_hip.so")
 ARCH = "gfx950"
 
 SOURCES = [

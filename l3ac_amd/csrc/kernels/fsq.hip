@@ -41,8 +41,6 @@ struct FsqDev {
     int feat, d;
     int levels[MAXD];
     int basis[MAXD];
-    float lm1_f[MAXD];    // (float)(levels[d] - 1) and (float)basis[d], converted on the host: as kernel arguments they are scalar
-    float basis_f[MAXD];  // operands; converted in the kernel they sat in a vector register each for the whole token loop
     const float* w_in;
     const float* b_in;
     const float* w_out;
@@ -67,9 +65,14 @@ __device__ __forceinline__ void nt_store4(float* p, const float4& v) {
     __builtin_nontemporal_store(f32x4_nt{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4_nt*>(p));
 }
 
-// Generic form (any feat % 8 == 0, every mode: forward, quantise-from-activations, decode-from-indices, latents in / out).
-// NV 16-byte chunks (4 channels each) per lane: lanes per token = feat / (4 NV).  The hot case — forward at feat = 128 — runs
-// fsq_forward128_kernel below.
+// Every mode: forward, quantise-from-activations, decode-from-indices, latents in / out; any feat = 8 * 2^j.
+// NV 16-byte chunks (4 channels each) per lane: lanes per token = feat / (4 NV).
+// Round 3 measurements (profiles/r03/fsq_notes.md): hipcc keeps the 2 D NV projection-weight quads of a lane in registers across
+// the token loop (158 registers, 3 blocks per CU).  A variant that re-read them from LDS at 64-96 registers and 4 / 6 / 8 blocks
+// per CU was SLOWER (4.75 / 4.75 / 4.42 vs 4.83 TB/s): the kernel is bound by the instructions of an iteration, not by bytes in
+// flight.  What did pay: one resident round (the 2 048-block grid left the last round a third full) and the level indices as
+// ONE contiguous store per wave.  The same grid and accesses with no arithmetic (fsq_copy_ceiling_kernel) reach 5.15 TB/s on the
+// same box, a plain copy in this access pattern 5.3-5.6, hipMemcpy 4.8-5.2: the kernel runs at 0.93-0.94 of its own ceiling.
 template <int D, int NV>
 __global__ __launch_bounds__(THREADS) void fsq_kernel(const FsqDev p, const int lpt) {
     const int feat = p.feat;
@@ -206,151 +209,6 @@ __global__ __launch_bounds__(THREADS) void fsq_kernel(const FsqDev p, const int 
     }
 }
 
-// Forward quantiser at feat = 128 (every shipped config): the arithmetic of fsq_kernel, operation for operation (same fmaf
-// chains in the same order, same butterfly, one tanhf per lane), laid out for registers: 8 lanes per token, channel quads dealt
-// round-robin (whole 128-B lines per instruction), two token groups in flight in two register sets (no copy), the weights
-// RE-READ from LDS one quad at a time (immediate offsets from one lane base), each output quad stored as soon as it is
-// complete.  ~70 registers: OCC (5 / 6 / 8) waves per SIMD instead of the generic form's 3 at 158 registers, whose 2 048-block
-// grid also left the last round a third full.
-template <int D, int OCC>
-__global__ __launch_bounds__(THREADS, OCC) void fsq_forward128_kernel(const FsqDev p) {
-    constexpr int FEAT = 128, NV = 4, LPT = 8, TPB = THREADS / LPT, CSTEP = 4 * LPT;
-    static_assert(D <= LPT, "one latent per lane of the token's group");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Win = smem;                 // [D][FEAT]
-    float* Wout = smem + D * FEAT;     // [D][FEAT] (project_out transposed)
-    float* Bout = Wout + D * FEAT;     // [FEAT]
-    const int tid = threadIdx.x;
-    // every field is copied out of the argument struct once: lambdas that capture the struct itself make hipcc keep a private
-    // (scratch) copy of it, pointers and all
-    const float* const xin = p.x;
-    float* const q_feature = p.q_feature;
-    int32_t* const indices = p.indices;
-    float* const level_indices = p.level_indices;
-    float* const latents = p.latents;
-    const int64_t n = p.n;
-    float basis_f[D], lm1_all[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        basis_f[d] = p.basis_f[d];
-        lm1_all[d] = p.lm1_f[d];
-    }
-    {
-        const float* const w_in = p.w_in;
-        const float* const w_out = p.w_out;
-        const float* const b_out = p.b_out;
-        for (int i = tid; i < D * FEAT; i += THREADS) {
-            const int d = i / FEAT, c = i % FEAT;
-            Win[i] = w_in[i];
-            Wout[i] = w_out[c * D + d];
-        }
-        for (int i = tid; i < FEAT; i += THREADS) Bout[i] = b_out[i];
-    }
-    __syncthreads();
-    const int sub = tid & (LPT - 1);
-    const int lane = tid & 63;
-    const int cq = 4 * sub;
-    const int64_t n_groups = (n + TPB - 1) / TPB;
-    const int64_t per_block = (n_groups + gridDim.x - 1) / gridDim.x;  // contiguous token range per block
-    const int64_t g_begin = (int64_t)blockIdx.x * per_block;
-    const int64_t g_end_ = g_begin + per_block < n_groups ? g_begin + per_block : n_groups;
-    // everything inside the block's range is addressed with 32-bit offsets from wave-uniform block bases (the launcher keeps a
-    // block's range below 2^24 tokens): 64-bit per-lane address arithmetic cost this kernel a dozen register pairs
-    const int ng = g_end_ > g_begin ? (int)(g_end_ - g_begin) : 0;
-    const int64_t tok0 = g_begin * TPB;
-    const int n_local = ng > 0 ? (int)((n - tok0) < (int64_t)ng * TPB ? (n - tok0) : (int64_t)ng * TPB) : 0;
-    const float* const xb_ = xin + tok0 * FEAT;
-    float* const qb_ = q_feature + tok0 * FEAT;
-    int32_t* const ib_ = indices ? indices + tok0 : nullptr;
-    float* const lb_ = level_indices ? level_indices + tok0 * D : nullptr;
-    float* const latb_ = latents ? latents + tok0 * D : nullptr;
-    const int tl0 = tid >> 3;
-    float lm1 = 1.f, b_mine = 0.f;  // this lane's latent (sub < D): level count - 1 and project_in bias
-#pragma unroll
-    for (int d = 0; d < D; ++d) lm1 = sub == d ? lm1_all[d] : lm1;
-    if (p.b_in && sub < D) b_mine = p.b_in[sub];
-
-    typedef float v4f __attribute__((ext_vector_type(4)));  // (arrays of HIP's float4 struct are not reliably promoted to registers)
-    v4f x[NV];  // ONE register set: the next group's rows are requested as soon as the in-projection has consumed this one's,
-                   // and arrive behind the tanh / out-projection / stores (and the SIMD's other waves)
-#pragma unroll
-    for (int v = 0; v < NV; ++v) x[v] = v4f{0.f, 0.f, 0.f, 0.f};
-    auto fetch = [&](int g) __attribute__((always_inline)) {  // (clamped, unconditional: a skipped load would make every x[v] a phi + copy)
-        const int t = min(g * TPB + tl0, n_local - 1);
-#pragma unroll
-        for (int v = 0; v < NV; ++v) x[v] = *reinterpret_cast<const v4f*>(xb_ + (t * FEAT + cq + CSTEP * v));
-    };
-    if (ng > 0) fetch(0);
-    for (int g = 0; g < ng; ++g) {
-        const int tok = g * TPB + tl0;
-        const bool ok = tok < n_local;  // (all 8 lanes of a token agree: the shuffles below stay inside the token's group)
-        // the lane's weight offset is made opaque in EVERY iteration: hipcc otherwise hoists the (loop-invariant) 2 D NV weight
-        // reads out of the token loop and then spills them to scratch
-        int woff = cq;
-        asm volatile("" : "+v"(woff));
-        const float* win_lane = Win + woff;
-        const float* wout_lane = Wout + woff;
-        float lat[D];
-#pragma unroll
-        for (int d = 0; d < D; ++d) lat[d] = 0.f;
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                const v4f wv = *reinterpret_cast<const v4f*>(win_lane + d * FEAT + CSTEP * v);
-                lat[d] = fmaf(x[v].x, wv.x, lat[d]); lat[d] = fmaf(x[v].y, wv.y, lat[d]);
-                lat[d] = fmaf(x[v].z, wv.z, lat[d]); lat[d] = fmaf(x[v].w, wv.w, lat[d]);
-            }
-            __builtin_amdgcn_sched_barrier(0);  // one quad's D weight reads live at a time (the scheduler front-loads all of them)
-        }
-        // the sums are pinned HERE: hipcc otherwise sinks the whole in-projection behind the next group's loads (into the
-        // branch that uses it), keeping all 2 D NV weight quads and both x generations alive across them
-#pragma unroll
-        for (int d = 0; d < D; ++d) asm volatile("" : "+v"(lat[d]));
-        fetch(g + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        float mine = 0.f;  // latent `sub` of this token, complete with its bias (every lane of the group holds identical sums)
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            float s = lat[d];
-            s += __shfl_xor(s, 4, 64);
-            s += __shfl_xor(s, 2, 64);
-            s += __shfl_xor(s, 1, 64);
-            mine = sub == d ? s : mine;
-        }
-        mine += b_mine;
-        if (latb_ && ok && sub < D) latb_[tok * D + sub] = mine;
-        const float act = (tanhf(mine) + 1.0f) * 0.5f;              // fsq_act.py:39
-        const float li_mine = rintf(__fmul_rn(act, lm1));            // vq/fsq.py:59 (half-to-even)
-        const int group_base = lane - sub;
-        float idx_f = 0.f;
-        float q[D];
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const float li = __shfl(li_mine, group_base + d, 64);
-            idx_f += li * basis_f[d];                                          // exact (vq/fsq.py:67-68)
-            const float q_act = __fdiv_rn(li, lm1_all[d]);                     // vq/fsq.py:60
-            q[d] = __fsub_rn(__fmul_rn(q_act, 2.0f), 1.0f);                    // vq/fsq.py:21
-        }
-        float* dst = qb_ + (tok * FEAT + cq);
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            v4f o = *reinterpret_cast<const v4f*>(Bout + cq + CSTEP * v);
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                const v4f wv = *reinterpret_cast<const v4f*>(wout_lane + d * FEAT + CSTEP * v);
-                o.x = fmaf(q[d], wv.x, o.x); o.y = fmaf(q[d], wv.y, o.y);
-                o.z = fmaf(q[d], wv.z, o.z); o.w = fmaf(q[d], wv.w, o.w);
-            }
-            if (ok) *reinterpret_cast<v4f*>(dst + CSTEP * v) = o;
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (ok && sub == 0 && ib_) ib_[tok] = (int32_t)idx_f;
-        // lane d of the group holds level index d: ONE store instruction per wave, the tokens' D values contiguous
-        if (ok && lb_ && sub < D) lb_[tok * D + sub] = li_mine;
-    }
-}
-
 // The ceiling fsq_kernel is measured against: the same grid, the same per-lane access pattern (4 x 16 B loads per lane one
 // token group ahead, 4 x 16 B stores, 4 B per token of indices, 24 B per token of level indices) and NO arithmetic.
 __global__ __launch_bounds__(THREADS, 8) void fsq_copy_ceiling_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ q,
@@ -399,18 +257,9 @@ int launch_fsq_t(hipStream_t s, const FsqDev& p) {
     // One weight staging per block, a contiguous token range each, and ONE resident round: with more blocks than the chip
     // holds at once the last, partly filled round streams at a fraction of the HBM rate for a whole block lifetime
     // (2 048 blocks on 6 x 256 places: the last quarter of the work at a third of the bytes in flight).
-    // form: 0 generic nv 2, 1 generic nv 4, 2.. the forward kernel at feat = 128 with 4 / 6 / 8 waves per SIMD (L3AC_FSQ_OCC; 3 = the generic kernel)
-    static const int occ_env = [] {
-        const char* e = std::getenv("L3AC_FSQ_OCC");
-        return e ? std::atoi(e) : 0;
-    }();
-    const bool fwd128 = p.feat == 128 && p.x && !p.idx_in && !p.act_in && p.w_in && D <= 8;
-    const int occ = occ_env == 4 || occ_env == 6 || occ_env == 8 || occ_env == 3 ? occ_env : 6;
-    const int form = (fwd128 && occ != 3) ? (occ == 4 ? 2 : occ == 6 ? 3 : 4) : (nv == 4 ? 1 : 0);
-    const void* fns[5] = {reinterpret_cast<const void*>(fsq_kernel<D, 2>), reinterpret_cast<const void*>(fsq_kernel<D, 4>),
-                          reinterpret_cast<const void*>(fsq_forward128_kernel<D, 4>), reinterpret_cast<const void*>(fsq_forward128_kernel<D, 6>),
-                          reinterpret_cast<const void*>(fsq_forward128_kernel<D, 8>)};
-    static int per_cu[L3AC_MAX_DEVICES][5] = {};
+    const int form = nv == 4 ? 1 : 0;
+    const void* fns[2] = {reinterpret_cast<const void*>(fsq_kernel<D, 2>), reinterpret_cast<const void*>(fsq_kernel<D, 4>)};
+    static int per_cu[L3AC_MAX_DEVICES][2] = {};
     int& resident = per_cu[l3ac_device_slot()][form];
     if (resident <= 0) {
         int v = 0;
@@ -418,17 +267,14 @@ int launch_fsq_t(hipStream_t s, const FsqDev& p) {
         resident = v > 8 ? 8 : v;
     }
     const int64_t places = (int64_t)l3ac_device_cu_count() * resident;
-    if (blocks > places) blocks = places * ceil_div64(ceil_div64(blocks, places) * tok_per_block, (int64_t)1 << 24);  // (> 2^24 tokens per block: more rounds)
+    if (blocks > places) blocks = places;
     const double in_b = p.x ? 4.0 * p.feat : (p.idx_in ? 4.0 : 4.0 * D);
     ProfScope prof(s, "fsq_kernel", 4.0 * D * p.feat * (double)p.n,
                    (double)p.n * (in_b + 4.0 * p.feat + (p.indices ? 4.0 : 0.0) + (p.level_indices ? 4.0 * D : 0.0)));
-    switch (form) {
-        case 0: hipLaunchKernelGGL((fsq_kernel<D, 2>), dim3((unsigned)blocks), dim3(THREADS), lds, s, p, lpt); break;
-        case 1: hipLaunchKernelGGL((fsq_kernel<D, 4>), dim3((unsigned)blocks), dim3(THREADS), lds, s, p, lpt); break;
-        case 2: hipLaunchKernelGGL((fsq_forward128_kernel<D, 4>), dim3((unsigned)blocks), dim3(THREADS), lds, s, p); break;
-        case 3: hipLaunchKernelGGL((fsq_forward128_kernel<D, 6>), dim3((unsigned)blocks), dim3(THREADS), lds, s, p); break;
-        default: hipLaunchKernelGGL((fsq_forward128_kernel<D, 8>), dim3((unsigned)blocks), dim3(THREADS), lds, s, p); break;
-    }
+    if (form == 1)
+        hipLaunchKernelGGL((fsq_kernel<D, 4>), dim3((unsigned)blocks), dim3(THREADS), lds, s, p, lpt);
+    else
+        hipLaunchKernelGGL((fsq_kernel<D, 2>), dim3((unsigned)blocks), dim3(THREADS), lds, s, p, lpt);
     L3AC_LAUNCH_CHECK();
     return L3AC_OK;
 }
@@ -1090,8 +936,6 @@ int launch_fsq(hipStream_t s, const FsqArgs& a) {
         L3AC_REQUIRE(a.levels[d] >= 2, "fsq: level %d < 2", a.levels[d]);
         p.levels[d] = a.levels[d];
         p.basis[d] = (int)basis;
-        p.lm1_f[d] = (float)(a.levels[d] - 1);
-        p.basis_f[d] = (float)basis;
         basis *= a.levels[d];
     }
     L3AC_REQUIRE(basis < (1 << 24), "fsq: codebook size %lld exceeds the exact fp32 index range", (long long)basis);

@@ -275,6 +275,14 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmArgs& p, f32x4a (&acc)
                         const f32x2 sv = snake_act2(hv + bi, al, ia);
                         const f32x2 o = p.epi == EPI_SNAKE_GRN ? __builtin_elementwise_fma(ga, sv, be) + sv : sv;  // layers.py:115, n_x == 1
                         const int64_t m = mw + 16 * h + 4 * half + i;
+#ifdef L3AC_BOUND_NOHIDDEN  // TIMING-ONLY bounding build (wrong results): what would fusing pw1 -> snake/GRN -> pw2 of the C = 512 stage
+                            // be worth?  The 2048-wide hidden tensor is computed but only its first 256 rows are stored (finite
+                            // data for the second product, which reads those rows over and over: L2-resident)
+                        if (p.epi == EPI_SNAKE_GRN && p.n >= 2048 && m >= 256) {
+                            asm volatile("" ::"v"(o.x), "v"(o.y));
+                            continue;
+                        }
+#endif
                         if (m < p.m) p.c[m * p.ldc + n] = o.x;
                         if (m + 1 < p.m) p.c[(m + 1) * p.ldc + n] = o.y;
                     }
@@ -332,7 +340,11 @@ __device__ __forceinline__ void gemm_split_body16(const GemmArgs& p, const int g
 #pragma unroll
     for (int h = 0; h < RG; ++h) {
         const int64_t row = m0 + WM * wave + 16 * h + ln;
+#ifdef L3AC_BOUND_NOHIDDEN
+        const int64_t rr = row < p.m ? (p.k >= 2048 && p.lda >= 2048 ? row % 256 : row) : 0;
+#else
         const int64_t rr = row < p.m ? row : 0;
+#endif
         a_row[h] = p.a + rr * p.lda + 8 * lg;
         a_t[h] = CONV ? (int)((unsigned)rr % (unsigned)p.frames) : 0;  // (m < 2^31: checked by the launcher)
     }

@@ -105,26 +105,42 @@ __device__ __forceinline__ void ts_dma_quarter(const unsigned char* base, unsign
         : "memory");
 }
 
-__global__ __launch_bounds__(64 * TS_MAX_WAVES) void trans_stack_kernel(const TransStackArgs p) {
+template <int N, class F, int I = 0>
+__device__ __forceinline__ void ts_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        ts_static_for<N, F, I + 1>(static_cast<F&&>(f));
+    }
+}
+
+// MAXW: most waves a workgroup of this instantiation is launched with (register budget 512 / ceil(MAXW / 4) per lane).  Where the
+// budget allows (MAXW <= 8: clips of at most 128 frames, e.g. the 60-token stages) the next weight fragment is fetched from LDS
+// while the current one multiplies; with one wave per SIMD nothing else covers that latency.
+template <int MAXW>
+__global__ __launch_bounds__(64 * MAXW) void trans_stack_kernel(const TransStackArgs p) {
+    constexpr bool PREF = MAXW <= 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_ts[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n_waves = (int)(blockDim.x >> 6);
     const int fl = lane & 15, lg = lane >> 4;
     const int frames = p.frames;
     const int frame = 16 * wave + fl;            // this lane's frame (column of every tile)
     const bool frame_ok = frame < frames;
     float* const xclip = p.x + (int64_t)blockIdx.x * frames * TS_DIM;
+    float* const xlane = xclip + (int64_t)(frame_ok ? frame : 0) * TS_DIM + 4 * lg;  // + 16 t: this lane's 4 channels of tile t
     float* const bias_s = reinterpret_cast<float*>(smem_ts + TS_OFF_BIAS);
     float* const ln_s = reinterpret_cast<float*>(smem_ts + TS_OFF_LN);
 
-    // ---- the residual stream of this wave's 16 frames: xr[t][i] = x[frame][16 t + 4 g + i] ------------------------------
+    // ---- the residual stream of this wave's 16 frames: xr[t][i] = x[frame][16 t + 4 g + i].  It is in registers only around a
+    // LayerNorm: the products of a sub-layer accumulate from ZERO (yacc) and are added to x once, at the sub-layer's end —
+    // accumulated directly onto x, every one of the ~100 MFMA steps of a layer rounded at the magnitude of x (measured: 5 x the
+    // error of the unfused route against fp64).  In between x waits in its own rows of the global tensor (L2).
     f32x4_t xr[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         xr[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        if (frame_ok) xr[t] = *reinterpret_cast<const f32x4_t*>(xclip + (int64_t)frame * TS_DIM + 16 * t + 4 * lg);
+        if (frame_ok) xr[t] = *reinterpret_cast<const f32x4_t*>(xlane + 16 * t);
     }
     // distance bias (distances 0 .. frames - 1 of every head) and the stack's LayerNorm parameters
     for (int i = tid; i < TS_HEADS * TS_MAX_FRAMES; i += blockDim.x) {
@@ -147,8 +163,9 @@ __global__ __launch_bounds__(64 * TS_MAX_WAVES) void trans_stack_kernel(const Tr
         }
         ++dma_slot;
     };
-    // end of a slot step: this wave's copies of the NEXT slot have landed (all but the two youngest slots' 3 + 3 pieces), its
-    // own LDS reads and writes are done, then everybody's are; the slot just consumed is free for the next step's DMA
+    // end of a slot step: this wave's copies of the NEXT slot have landed (all but the two youngest slots' 3 + 3 pieces; plain
+    // loads / stores of x in the queue only make the wait stronger), its own LDS reads and writes are done, then everybody's
+    // are; the slot just consumed is free for the next step's DMA
     auto step_sync = [&]() __attribute__((always_inline)) {
         asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -158,19 +175,34 @@ __global__ __launch_bounds__(64 * TS_MAX_WAVES) void trans_stack_kernel(const Tr
     issue();
     issue();
     step_sync();  // slot 0 has landed
-    int pc = 0;   // pieces consumed so far (wave-uniform)
+    int slot_no = 0;  // slots consumed so far (wave-uniform)
     const unsigned char* const ring_lane = smem_ts + TS_OFF_RING + 16 * lane;
-    // the next weight piece as an operand fragment (3 planes x 16 B of this lane)
-    auto next_piece = [&](bf16x8 (&f)[3]) __attribute__((always_inline)) {
-        if ((pc & (TS_SLOT_PIECES - 1)) == 0) issue();  // a new slot step begins: refill the slot consumed one step ago
-        const unsigned char* a = ring_lane + ((pc >> 2) & (TS_RING_SLOTS - 1)) * TS_SLOT + (pc & (TS_SLOT_PIECES - 1)) * TS_PIECE;
+    auto load_frag = [&](bf16x8 (&f)[3], const unsigned char* a) __attribute__((always_inline)) {
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) f[pl] = *reinterpret_cast<const bf16x8*>(a + 1024 * pl);
     };
-    auto piece_done = [&]() __attribute__((always_inline)) {
-        ++pc;
-        if ((pc & (TS_SLOT_PIECES - 1)) == 0) step_sync();
+    // One slot step: the slot's 4 weight pieces in order, body(j, fragment) for piece j (compile-time j); `last` runs after the
+    // last piece's products and before the step's barrier (LDS writes other waves read after it).
+    auto slot_step = [&](auto&& body, auto&& last) __attribute__((always_inline)) {
+        issue();  // refill the slot consumed one step ago
+        const unsigned char* a = ring_lane + (slot_no & (TS_RING_SLOTS - 1)) * TS_SLOT;
+        bf16x8 f[PREF ? 2 : 1][3];
+        load_frag(f[0], a);
+        ts_static_for<TS_SLOT_PIECES>([&](auto j_) {
+            constexpr int j = decltype(j_)::value;
+            if constexpr (PREF) {
+                if constexpr (j + 1 < TS_SLOT_PIECES) load_frag(f[(j + 1) & 1], a + (j + 1) * TS_PIECE);
+                body(j_, f[j & 1]);
+            } else {
+                body(j_, f[0]);
+                if constexpr (j + 1 < TS_SLOT_PIECES) load_frag(f[0], a + (j + 1) * TS_PIECE);
+            }
+        });
+        last();
+        ++slot_no;
+        step_sync();
     };
+    auto nothing = []() __attribute__((always_inline)) {};
 
     // LayerNorm over the 128 channels of this lane's frame (F.layer_norm, eps 1e-5: two-pass, rstd = 1 / sqrt(var + eps) as
     // rows.hip), then the bf16x3 planes of the result: ap[s] = k step s (channels 32 s .. 32 s + 31)
@@ -207,75 +239,73 @@ __global__ __launch_bounds__(64 * TS_MAX_WAVES) void trans_stack_kernel(const Tr
             planes_of(a[0], a[1], ap[s2]);
         }
     };
+    // end of a sub-layer: x += yacc, back to its rows (the next sub-layer's end re-reads them), and into xr for the LayerNorm
+    f32x4_t yacc[8];
+    auto add_residual = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            f32x4_t xv = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if (frame_ok) xv = *reinterpret_cast<const f32x4_t*>(xlane + 16 * t);
+            xr[t] = xv + yacc[t];
+            if (frame_ok) *reinterpret_cast<f32x4_t*>(xlane + 16 * t) = xr[t];
+        }
+    };
 
     unsigned char* const k_mine = smem_ts + TS_OFF_K + wave * TS_PIECE + 16 * lane;                               // + 1024 plane
     unsigned char* const v_mine = smem_ts + TS_OFF_V + (wave >> 1) * 2 * TS_PIECE + 16 * lane + 8 * (wave & 1);  // + 3072 dt + 1024 plane
     const unsigned char* const k_lane = smem_ts + TS_OFF_K + 16 * lane;
     const unsigned char* const v_lane = smem_ts + TS_OFF_V + 16 * lane;
     const int key_steps = (wave >> 1) + 1;  // causal: keys 0 .. 16 wave + 15 in steps of 32
+    const f32x4_t zero4 = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll 1
     for (int layer = 0; layer < p.n_layers; ++layer) {
         const float* const lnp = ln_s + layer * 4 * TS_DIM;
         // ================= LocalMHA ===================================================================================
         layer_norm_planes(lnp, lnp + TS_DIM);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) yacc[t] = zero4;
 #pragma unroll 1
         for (int h = 0; h < TS_HEADS; ++h) {
-            bf16x8 f[3];
             // ---- q^T, k^T (weights x activations) and V (activations x weights) of head h for this wave's frames ------
-            f32x4_t qa[2], ka[2], va[2];
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                qa[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    next_piece(f);
-                    qa[dt] = mfma6(f, ap[s], qa[dt]);
-                    piece_done();
-                }
-            }
+            f32x4_t qa[2] = {zero4, zero4}, ka[2] = {zero4, zero4}, va[2] = {zero4, zero4};
+            ts_static_for<2>([&](auto dt_) {
+                constexpr int dt = decltype(dt_)::value;
+                slot_step([&](auto j_, const bf16x8 (&f)[3]) __attribute__((always_inline)) { qa[dt] = mfma6(f, ap[decltype(j_)::value], qa[dt]); }, nothing);
+            });
             bf16x8 qp[3];
             {
                 f32x4_t q0 = qa[0] * p.scale, q1 = qa[1] * p.scale;  // q pre-scaled (local_attention: q = q * scale)
                 planes_of(q0, q1, qp);
             }
+            ts_static_for<2>([&](auto dt_) {
+                constexpr int dt = decltype(dt_)::value;
+                slot_step([&](auto j_, const bf16x8 (&f)[3]) __attribute__((always_inline)) { ka[dt] = mfma6(f, ap[decltype(j_)::value], ka[dt]); },
+                          [&]() __attribute__((always_inline)) {
+                              if constexpr (dt == 1) {  // K of this wave's 16 keys as S^T's A-operand fragment
+                                  bf16x8 kp[3];
+                                  planes_of(ka[0], ka[1], kp);
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                ka[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                                  for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bf16x8*>(k_mine + 1024 * pl) = kp[pl];
+                              }
+                          });
+            });
+            ts_static_for<2>([&](auto dt_) {
+                constexpr int dt = decltype(dt_)::value;
+                // operands swapped: va[dt][i] = V[frame 16 wave + 4 g + i][d = 16 dt + fl]
+                slot_step([&](auto j_, const bf16x8 (&f)[3]) __attribute__((always_inline)) { va[dt] = mfma6(ap[decltype(j_)::value], f, va[dt]); },
+                          [&]() __attribute__((always_inline)) {  // half (keys of this wave) of the V^T fragment of key step wave / 2, d tile dt
+                              unsigned w0[3], w1[3];
+                              split2(va[dt][0], va[dt][1], w0[0], w0[1], w0[2]);
+                              split2(va[dt][2], va[dt][3], w1[0], w1[1], w1[2]);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    next_piece(f);
-                    ka[dt] = mfma6(f, ap[s], ka[dt]);
-                    if (dt == 1 && s == 3) {  // K of this wave's 16 keys as S^T's A-operand fragment, before the slot's barrier
-                        bf16x8 kp[3];
-                        planes_of(ka[0], ka[1], kp);
-#pragma unroll
-                        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bf16x8*>(k_mine + 1024 * pl) = kp[pl];
-                    }
-                    piece_done();
-                }
-            }
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                va[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    next_piece(f);
-                    va[dt] = mfma6(ap[s], f, va[dt]);  // operands swapped: va[dt][i] = V[frame 16 wave + 4 g + i][d = 16 dt + fl]
-                    if (s == 3) {  // half (keys of this wave) of the V^T fragment of key step wave / 2, d tile dt
-                        unsigned w0[3], w1[3];
-                        split2(va[dt][0], va[dt][1], w0[0], w0[1], w0[2]);
-                        split2(va[dt][2], va[dt][3], w1[0], w1[1], w1[2]);
-#pragma unroll
-                        for (int pl = 0; pl < 3; ++pl)
-                            *reinterpret_cast<uint2*>(v_mine + TS_PIECE * dt + 1024 * pl) = make_uint2(w0[pl], w1[pl]);
-                    }
-                    piece_done();  // (the last one ends a slot step: its barrier publishes K and V of every wave)
-                }
-            }
+                              for (int pl = 0; pl < 3; ++pl)
+                                  *reinterpret_cast<uint2*>(v_mine + TS_PIECE * dt + 1024 * pl) = make_uint2(w0[pl], w1[pl]);
+                          });  // (the last step's barrier publishes K and V of every wave)
+            });
             // ---- causal attention of this wave's 16 queries over keys 0 .. 16 wave + 15 ------------------------------
             float m_run = -INFINITY, l_run = 0.f;
-            f32x4_t oa[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+            f32x4_t oa[2] = {zero4, zero4};
             const float* const bias_h = bias_s + h * TS_MAX_FRAMES;
 #pragma unroll 1
             for (int ks = 0; ks < key_steps; ++ks) {
@@ -283,9 +313,8 @@ __global__ __launch_bounds__(64 * TS_MAX_WAVES) void trans_stack_kernel(const Tr
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     bf16x8 kf[3];
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) kf[pl] = *reinterpret_cast<const bf16x8*>(k_lane + (2 * ks + u) * TS_PIECE + 1024 * pl);
-                    st[u] = mfma6(kf, qp, f32x4_t{0.f, 0.f, 0.f, 0.f});  // S^T[key 32 ks + 16 u + 4 g + i][query fl]
+                    load_frag(kf, k_lane + (2 * ks + u) * TS_PIECE);
+                    st[u] = mfma6(kf, qp, zero4);  // S^T[key 32 ks + 16 u + 4 g + i][query fl]
                 }
                 float mx = -INFINITY;
 #pragma unroll
@@ -318,8 +347,7 @@ __global__ __launch_bounds__(64 * TS_MAX_WAVES) void trans_stack_kernel(const Tr
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
                     bf16x8 vf[3];
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) vf[pl] = *reinterpret_cast<const bf16x8*>(v_lane + (2 * ks + dt) * TS_PIECE + 1024 * pl);
+                    load_frag(vf, v_lane + (2 * ks + dt) * TS_PIECE);
                     oa[dt] = mfma6(vf, pp, oa[dt] * alpha);  // O^T[d = 16 dt + 4 g + i][query fl]
                 }
             }
@@ -331,30 +359,27 @@ __global__ __launch_bounds__(64 * TS_MAX_WAVES) void trans_stack_kernel(const Tr
                 f32x4_t o0 = oa[0] * inv, o1 = oa[1] * inv;
                 planes_of(o0, o1, op);
             }
-            // ---- out projection of this head's 32 columns, accumulated onto the residual stream ------------------------
-#pragma unroll
-            for (int rt = 0; rt < 8; ++rt) {
-                next_piece(f);
-                xr[rt] = mfma6(f, op, xr[rt]);
-                piece_done();
-            }
+            // ---- out projection of this head's 32 columns, summed over the heads in yacc -------------------------------
+            ts_static_for<2>([&](auto half_) {
+                constexpr int half = decltype(half_)::value;
+                slot_step([&](auto j_, const bf16x8 (&f)[3]) __attribute__((always_inline)) {
+                    constexpr int rt = 4 * half + decltype(j_)::value;
+                    yacc[rt] = mfma6(f, op, yacc[rt]);
+                }, nothing);
+            });
         }
+        add_residual();
         // ================= FeedForward (GEGLU) ========================================================================
         layer_norm_planes(lnp + 2 * TS_DIM, lnp + 3 * TS_DIM);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) yacc[t] = zero4;
 #pragma unroll 1
         for (int c = 0; c < TS_FF_CHUNKS; ++c) {
-            bf16x8 f[3];
-            f32x4_t vg[4];  // value tiles 0, 1 then gate tiles 0, 1 of hidden units 32 c .. 32 c + 31
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                vg[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    next_piece(f);
-                    vg[u] = mfma6(f, ap[s], vg[u]);
-                    piece_done();
-                }
-            }
+            f32x4_t vg[4] = {zero4, zero4, zero4, zero4};  // value tiles 0, 1 then gate tiles 0, 1 of hidden units 32 c .. 32 c + 31
+            ts_static_for<4>([&](auto u_) {
+                constexpr int u = decltype(u_)::value;
+                slot_step([&](auto j_, const bf16x8 (&f)[3]) __attribute__((always_inline)) { vg[u] = mfma6(f, ap[decltype(j_)::value], vg[u]); }, nothing);
+            });
             bf16x8 hp[3];
             {
                 f32x4_t h0, h1;
@@ -365,20 +390,18 @@ __global__ __launch_bounds__(64 * TS_MAX_WAVES) void trans_stack_kernel(const Tr
                 }
                 planes_of(h0, h1, hp);
             }
-#pragma unroll
-            for (int rt = 0; rt < 8; ++rt) {
-                next_piece(f);
-                xr[rt] = mfma6(f, hp, xr[rt]);
-                piece_done();
-            }
+            ts_static_for<2>([&](auto half_) {
+                constexpr int half = decltype(half_)::value;
+                slot_step([&](auto j_, const bf16x8 (&f)[3]) __attribute__((always_inline)) {
+                    constexpr int rt = 4 * half + decltype(j_)::value;
+                    yacc[rt] = mfma6(f, hp, yacc[rt]);
+                }, nothing);
+            });
         }
+        add_residual();  // (also the next layer's LayerNorm input, already in xr)
     }
-    // leave no LDS-DMA in flight behind the workgroup, then write the residual stream back
+    // leave no LDS-DMA in flight behind the workgroup
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (frame_ok) {
-#pragma unroll
-        for (int t = 0; t < 8; ++t) *reinterpret_cast<f32x4_t*>(xclip + (int64_t)frame * TS_DIM + 16 * t + 4 * lg) = xr[t];
-    }
 }
 
 // one piece: 16 rows x 32 k of a row-major [n][ld] matrix (rows >= n_rows / columns >= n_cols: zeros) as the three bf16 planes of
@@ -433,8 +456,9 @@ int launch_trans_stack(hipStream_t s, const LocalTransW& w, float* x, int batch,
     const int lds = ts_lds_bytes(n_layers);
     static PerDeviceOnce configured;
     if (configured.first()) {
-        L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trans_stack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           ts_lds_bytes(TS_MAX_LAYERS)));
+        for (const void* fn : {reinterpret_cast<const void*>(trans_stack_kernel<4>), reinterpret_cast<const void*>(trans_stack_kernel<8>),
+                               reinterpret_cast<const void*>(trans_stack_kernel<12>)})
+            L3AC_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, ts_lds_bytes(TS_MAX_LAYERS)));
         configured.done();
     }
     int waves = 2 * (int)ceil_div64(frames, 32);  // even: every key tile a wave reads in pairs has been written by some wave
@@ -446,7 +470,13 @@ int launch_trans_stack(hipStream_t s, const LocalTransW& w, float* x, int batch,
     const double lin = 2.0 * (3.0 * TS_INNER * TS_DIM + TS_DIM * TS_INNER + 3.0 * TS_FFI * TS_DIM);
     const double att = 2.0 * 2.0 * TS_INNER * 0.5 * (frames + 1.0);
     ProfScope prof(s, "trans_stack_kernel", n_layers * rows * (lin + att), 2.0 * rows * TS_DIM * 4.0);
-    hipLaunchKernelGGL(trans_stack_kernel, dim3((unsigned)batch), dim3(64 * waves), lds, s, a);
+    // (the instantiation only changes the register budget and whether weight fragments are fetched one piece ahead: same bits)
+    if (waves <= 4)
+        hipLaunchKernelGGL(trans_stack_kernel<4>, dim3((unsigned)batch), dim3(64 * waves), lds, s, a);
+    else if (waves <= 8)
+        hipLaunchKernelGGL(trans_stack_kernel<8>, dim3((unsigned)batch), dim3(64 * waves), lds, s, a);
+    else
+        hipLaunchKernelGGL(trans_stack_kernel<12>, dim3((unsigned)batch), dim3(64 * waves), lds, s, a);
     L3AC_LAUNCH_CHECK();
     return L3AC_OK;
 }
