@@ -241,6 +241,12 @@ int l3ac_gemm_f32(const float* a, int64_t lda, const float* w, const float* bias
  * (tests/test_host.py::test_bf16x3_split_is_exact). */
 void l3ac_split3_host(const float* x, int64_t n, uint16_t* planes);
 int l3ac_ctx_set_gemm_split(l3ac_ctx* ctx, int32_t enable);
+/* Route options of ONE context by name (same rules as the setters above): "gemm_split", "head_pretanh", and "narrow_ring" — which
+ * fused kernel takes the ConvUnits with C <= 96 on the split route: 0 = conv_unit_split_kernel (32 frames per wave) everywhere,
+ * 1 (default) = conv_unit_ring_kernel (16 frames per wave, weights through an LDS-DMA ring) at the widths where it is the faster
+ * one (C = 48, 96), 2 = wherever it exists (C = 24 too).  Both evaluate the same operations; their results agree to rounding.
+ * Unknown names return L3AC_EINVAL. */
+int l3ac_ctx_set_option(l3ac_ctx* ctx, const char* name, int32_t value);
 int32_t l3ac_ctx_get_gemm_split(const l3ac_ctx* ctx);
 /* Weight image for l3ac_gemm_split_f32: w [n][k] fp32 -> `image` (device, l3ac_gemm_split_image_bytes(n, k) bytes;
  * 0 = shape not eligible: needs n >= 192, k >= 32, k % 8 == 0). */

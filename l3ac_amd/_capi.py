@@ -81,6 +81,7 @@ SIGNATURES = {
     "l3ac_gemm_f32": (C.c_int, [_P, _I64, _P, _P, _P, _I64, _I64, _I32, _I32, _P]),
     "l3ac_split3_host": (None, [_P, _I64, _P]),
     "l3ac_ctx_set_gemm_split": (C.c_int, [_P, _I32]),
+    "l3ac_ctx_set_option": (C.c_int, [_P, C.c_char_p, _I32]),
     "l3ac_ctx_get_gemm_split": (_I32, [_P]),
     "l3ac_gemm_split_image_bytes": (_I64, [_I32, _I32]),
     "l3ac_gemm_split_image": (C.c_int, [_P, _I32, _I32, _P, _P]),
@@ -234,6 +235,9 @@ class Context:
 
     def get_gemm_split(self) -> bool:
         return bool(self.lib.l3ac_ctx_get_gemm_split(self.handle))
+
+    def set_option(self, name: str, value: int) -> None:
+        check(self.lib.l3ac_ctx_set_option(self.handle, name.encode(), int(value)))
 
     def set_head_pretanh(self, enable: bool) -> None:
         check(self.lib.l3ac_ctx_set_head_pretanh(self.handle, int(bool(enable))))

@@ -36,6 +36,7 @@ SOURCES = [
     "kernels/conv_unit_fused.hip",
     "kernels/conv_unit_split.hip",
     "kernels/conv_unit_wide.hip",
+    "kernels/conv_unit_ring.hip",
     "kernels/last_block.hip",
     "kernels/bitpack.hip",
 ]

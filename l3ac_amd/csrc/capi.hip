@@ -122,6 +122,10 @@ int l3ac_create(const l3ac_config* cfg, const l3ac_tensor* tensors, int32_t n_te
     ctx->cfg = *cfg;
     ctx->device = device;
     ctx->gemm_split = gemm_split_default();
+    {
+        const char* e = std::getenv("L3AC_NARROW_RING");
+        if (e) ctx->narrow_ring = std::atoi(e);
+    }
     DeviceGuard guard(device);
     int rc = guard.ok ? network_build(ctx, tensors, n_tensors) : L3AC_EHIP;
     if (rc == L3AC_OK && hipEventCreateWithFlags(&ctx->ws_done, hipEventDisableTiming) != hipSuccess) {
@@ -520,6 +524,19 @@ int l3ac_op_snake(const float* x, float* y, int64_t rows, int32_t c, const float
     (void)hipStreamSynchronize(s);
     (void)hipFree(inv);
     return rc;
+}
+
+int l3ac_ctx_set_option(l3ac_ctx* ctx, const char* name, int32_t value) {
+    L3AC_REQUIRE(ctx != nullptr && name != nullptr, "set_option: null argument");
+    const std::string n(name);
+    if (n == "gemm_split") ctx->gemm_split = value != 0;
+    else if (n == "head_pretanh") ctx->head_pretanh = value != 0;
+    else if (n == "narrow_ring") ctx->narrow_ring = value < 0 ? 0 : (value > 2 ? 2 : value);
+    else {
+        l3ac_set_error("set_option: unknown option '%s' (gemm_split, head_pretanh, narrow_ring)", name);
+        return L3AC_EINVAL;
+    }
+    return L3AC_OK;
 }
 
 int l3ac_ctx_set_gemm_split(l3ac_ctx* ctx, int32_t enable) {

@@ -25,13 +25,14 @@
 //   * the weights of the stack are ONE stream of fragment-ordered bf16x3 "pieces" (16 rows x 32 k, 3 planes x 1 KB) in
 //     consumption order (trans_stack_image), L2-resident (1.37 MB per layer, every CU walks it in step), staged by LDS-DMA into a
 //     ring of 4 slots of 4 pieces behind a counted s_waitcnt vmcnt and one raw s_barrier per slot.
-// Online softmax over key steps of 32 (as attention_mfma_kernel); expf / erff are the OCML ones the unfused route uses.
+// Online softmax over key steps of 32 (as attention_mfma_kernel) with ts_exp_neg (1-2 ulp); erff is the OCML one.
 // Results differ from the unfused route's in rounding only (other summation orders); clip i of a batch is bit-identical to
 // clip i alone (one workgroup per clip, nothing depends on the batch).
 #include "../kernels.hpp"
 #include "../network.hpp"
 #include "device_math.hpp"
 #include "split_bf16.hpp"
+#include "ring_common.hpp"
 
 #include <cmath>
 #include <vector>
@@ -56,8 +57,6 @@ constexpr int TS_OFF_LN = TS_OFF_BIAS + TS_HEADS * TS_MAX_FRAMES * 4;    // Laye
 constexpr int ts_lds_bytes(int layers) { return TS_OFF_LN + layers * 4 * TS_DIM * 4; }
 static_assert(ts_lds_bytes(TS_MAX_LAYERS) <= 160 * 1024, "LDS budget exceeded");
 
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
-
 struct TransStackArgs {
     float* x;                  // [batch][frames][128], updated in place
     int frames, n_layers;
@@ -68,49 +67,16 @@ struct TransStackArgs {
     float scale;               // dim_head^-0.5 (applied to q before the scores, as the package does)
 };
 
-// the six plane products of one fragment pair, smallest first (split_bf16.hpp, mfma_split)
-__device__ __forceinline__ f32x4_t mfma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4_t acc) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
-    return acc;
-}
-
-// two accumulator tiles (rows 16 t + 4 g + i and 16 (t + 1) + 4 g + i of this lane's column) as the three bf16 planes of one
-// k step of 32 in the order sigma(g, j)
-__device__ __forceinline__ void planes_of(const f32x4_t& lo, const f32x4_t& hi, bf16x8 (&out)[3]) {
-    unsigned p[3][4];
-    split2(lo[0], lo[1], p[0][0], p[1][0], p[2][0]);
-    split2(lo[2], lo[3], p[0][1], p[1][1], p[2][1]);
-    split2(hi[0], hi[1], p[0][2], p[1][2], p[2][2]);
-    split2(hi[2], hi[3], p[0][3], p[1][3], p[2][3]);
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) out[pl] = __builtin_bit_cast(bf16x8, u32x4{p[pl][0], p[pl][1], p[pl][2], p[pl][3]});
-}
-
-// this wave's quarter (3 KB) of one ring slot: three 1-KB LDS-DMA pieces, lane l copying 16 B (as conv_unit_wide.hip)
-__device__ __forceinline__ void ts_dma_quarter(const unsigned char* base, unsigned lane_off, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
-        "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-        "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(lane_off), "s"(base), "s"(lds_dst)
-        : "memory");
-}
-
-template <int N, class F, int I = 0>
-__device__ __forceinline__ void ts_static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        ts_static_for<N, F, I + 1>(static_cast<F&&>(f));
-    }
+// exp(x) for x <= 0 (softmax terms; x = -inf for masked entries): the hardware's 2^t on t = x log2(e) carried in two parts — the
+// rounded product and its residual (exact by fma) plus the constant's low part — with the residual applied to first order:
+// 2^(t + r) = 2^t (1 + r ln 2), |r| < 2^-22.  6 instructions and 1-2 ulp, against ~20 for the OCML expf of the same accuracy;
+// the exponentials were a quarter of the vector work of an attention step.
+__device__ __forceinline__ float ts_exp_neg(float x) {
+    x = fmaxf(x, -1.0e4f);  // (-inf -> a value whose exponential underflows to 0 as well; keeps the residual finite)
+    const float t = x * 1.44269502162933349609375f;
+    const float r = fmaf(x, 1.44269502162933349609375f, -t) + x * 1.92596299112661746e-8f;
+    const float e = __builtin_amdgcn_exp2f(t);
+    return fmaf(e, r * 0.693147182464599609375f, e);
 }
 
 // MAXW: most waves a workgroup of this instantiation is launched with (register budget 512 / ceil(MAXW / 4) per lane).  Where the
@@ -158,7 +124,7 @@ __global__ __launch_bounds__(64 * MAXW) void trans_stack_kernel(const TransStack
     auto issue = [&]() __attribute__((always_inline)) {
         if (wave < 4) {
             const int src = dma_slot < total_slots ? dma_slot : dma_slot - total_slots;
-            ts_dma_quarter(p.img + (int64_t)src * TS_SLOT + TS_PIECE * wave, lane_off,
+            ring_dma_quarter(p.img + (int64_t)src * TS_SLOT + TS_PIECE * wave, lane_off,
                            ring_lds + (unsigned)((dma_slot & (TS_RING_SLOTS - 1)) * TS_SLOT + TS_PIECE * wave));
         }
         ++dma_slot;
@@ -188,7 +154,7 @@ __global__ __launch_bounds__(64 * MAXW) void trans_stack_kernel(const TransStack
         const unsigned char* a = ring_lane + (slot_no & (TS_RING_SLOTS - 1)) * TS_SLOT;
         bf16x8 f[PREF ? 2 : 1][3];
         load_frag(f[0], a);
-        ts_static_for<TS_SLOT_PIECES>([&](auto j_) {
+        ring_static_for<TS_SLOT_PIECES>([&](auto j_) {
             constexpr int j = decltype(j_)::value;
             if constexpr (PREF) {
                 if constexpr (j + 1 < TS_SLOT_PIECES) load_frag(f[(j + 1) & 1], a + (j + 1) * TS_PIECE);
@@ -269,7 +235,7 @@ __global__ __launch_bounds__(64 * MAXW) void trans_stack_kernel(const TransStack
         for (int h = 0; h < TS_HEADS; ++h) {
             // ---- q^T, k^T (weights x activations) and V (activations x weights) of head h for this wave's frames ------
             f32x4_t qa[2] = {zero4, zero4}, ka[2] = {zero4, zero4}, va[2] = {zero4, zero4};
-            ts_static_for<2>([&](auto dt_) {
+            ring_static_for<2>([&](auto dt_) {
                 constexpr int dt = decltype(dt_)::value;
                 slot_step([&](auto j_, const bf16x8 (&f)[3]) __attribute__((always_inline)) { qa[dt] = mfma6(f, ap[decltype(j_)::value], qa[dt]); }, nothing);
             });
@@ -278,7 +244,7 @@ __global__ __launch_bounds__(64 * MAXW) void trans_stack_kernel(const TransStack
                 f32x4_t q0 = qa[0] * p.scale, q1 = qa[1] * p.scale;  // q pre-scaled (local_attention: q = q * scale)
                 planes_of(q0, q1, qp);
             }
-            ts_static_for<2>([&](auto dt_) {
+            ring_static_for<2>([&](auto dt_) {
                 constexpr int dt = decltype(dt_)::value;
                 slot_step([&](auto j_, const bf16x8 (&f)[3]) __attribute__((always_inline)) { ka[dt] = mfma6(f, ap[decltype(j_)::value], ka[dt]); },
                           [&]() __attribute__((always_inline)) {
@@ -290,7 +256,7 @@ __global__ __launch_bounds__(64 * MAXW) void trans_stack_kernel(const TransStack
                               }
                           });
             });
-            ts_static_for<2>([&](auto dt_) {
+            ring_static_for<2>([&](auto dt_) {
                 constexpr int dt = decltype(dt_)::value;
                 // operands swapped: va[dt][i] = V[frame 16 wave + 4 g + i][d = 16 dt + fl]
                 slot_step([&](auto j_, const bf16x8 (&f)[3]) __attribute__((always_inline)) { va[dt] = mfma6(ap[decltype(j_)::value], f, va[dt]); },
@@ -330,13 +296,13 @@ __global__ __launch_bounds__(64 * MAXW) void trans_stack_kernel(const TransStack
                 mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
                 const float m_new = fmaxf(m_run, mx);  // finite from the first step on: key 0 is visible to every query
-                const float alpha = expf(m_run - m_new);
+                const float alpha = ts_exp_neg(m_run - m_new);
                 float psum = 0.f;
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const float pv = expf(st[u][i] - m_new);  // masked entries: exp(-inf) = 0
+                        const float pv = ts_exp_neg(st[u][i] - m_new);  // masked entries: exp(-inf) = 0
                         st[u][i] = pv;
                         psum += pv;
                     }
@@ -360,7 +326,7 @@ __global__ __launch_bounds__(64 * MAXW) void trans_stack_kernel(const TransStack
                 planes_of(o0, o1, op);
             }
             // ---- out projection of this head's 32 columns, summed over the heads in yacc -------------------------------
-            ts_static_for<2>([&](auto half_) {
+            ring_static_for<2>([&](auto half_) {
                 constexpr int half = decltype(half_)::value;
                 slot_step([&](auto j_, const bf16x8 (&f)[3]) __attribute__((always_inline)) {
                     constexpr int rt = 4 * half + decltype(j_)::value;
@@ -376,7 +342,7 @@ __global__ __launch_bounds__(64 * MAXW) void trans_stack_kernel(const TransStack
 #pragma unroll 1
         for (int c = 0; c < TS_FF_CHUNKS; ++c) {
             f32x4_t vg[4] = {zero4, zero4, zero4, zero4};  // value tiles 0, 1 then gate tiles 0, 1 of hidden units 32 c .. 32 c + 31
-            ts_static_for<4>([&](auto u_) {
+            ring_static_for<4>([&](auto u_) {
                 constexpr int u = decltype(u_)::value;
                 slot_step([&](auto j_, const bf16x8 (&f)[3]) __attribute__((always_inline)) { vg[u] = mfma6(f, ap[decltype(j_)::value], vg[u]); }, nothing);
             });
@@ -390,7 +356,7 @@ __global__ __launch_bounds__(64 * MAXW) void trans_stack_kernel(const TransStack
                 }
                 planes_of(h0, h1, hp);
             }
-            ts_static_for<2>([&](auto half_) {
+            ring_static_for<2>([&](auto half_) {
                 constexpr int half = decltype(half_)::value;
                 slot_step([&](auto j_, const bf16x8 (&f)[3]) __attribute__((always_inline)) {
                     constexpr int rt = 4 * half + decltype(j_)::value;
@@ -402,23 +368,6 @@ __global__ __launch_bounds__(64 * MAXW) void trans_stack_kernel(const TransStack
     }
     // leave no LDS-DMA in flight behind the workgroup
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-// one piece: 16 rows x 32 k of a row-major [n][ld] matrix (rows >= n_rows / columns >= n_cols: zeros) as the three bf16 planes of
-// the operand fragment — lane (m = lane & 15, g = lane >> 4) holds the 8 values W[row0 + m][k0 + sigma(g, j)], j = 0 .. 7
-void put_piece(std::vector<unsigned char>& img, const float* w, int64_t ld, int n_rows, int n_cols, int row0, int k0) {
-    const size_t base = img.size();
-    img.resize(base + TS_PIECE, 0);
-    for (int g = 0; g < 4; ++g)
-        for (int m = 0; m < 16; ++m)
-            for (int j = 0; j < 8; ++j) {
-                const int k = k0 + (j < 4 ? 4 * g + j : 16 + 4 * g + j - 4);
-                const int r = row0 + m;
-                const float v = (r < n_rows && k < n_cols) ? w[(int64_t)r * ld + k] : 0.f;
-                uint16_t pl[3];
-                split3_host(v, pl);
-                for (int p = 0; p < 3; ++p) std::memcpy(img.data() + base + (size_t)p * 1024 + (size_t)(16 * g + m) * 16 + 2 * j, &pl[p], 2);
-            }
 }
 
 }  // namespace
@@ -436,14 +385,14 @@ void trans_stack_layer_image(std::vector<unsigned char>& img, const float* wqkv,
     for (int h = 0; h < TS_HEADS; ++h) {
         for (int part = 0; part < 3; ++part)
             for (int dt = 0; dt < 2; ++dt)
-                for (int s = 0; s < 4; ++s) put_piece(img, wqkv, TS_DIM, 3 * TS_INNER, TS_DIM, part * TS_INNER + h * TS_DH + 16 * dt, 32 * s);
-        for (int rt = 0; rt < 8; ++rt) put_piece(img, wout, TS_INNER, TS_DIM, TS_INNER, 16 * rt, 32 * h);
+                for (int s = 0; s < 4; ++s) ring_put_piece(img, wqkv, TS_DIM, 3 * TS_INNER, TS_DIM, part * TS_INNER + h * TS_DH + 16 * dt, 32 * s);
+        for (int rt = 0; rt < 8; ++rt) ring_put_piece(img, wout, TS_INNER, TS_DIM, TS_INNER, 16 * rt, 32 * h);
     }
     for (int c = 0; c < TS_FF_CHUNKS; ++c) {
         for (int half = 0; half < 2; ++half)  // value rows 64 c + r, gate rows 64 c + 32 + r of the interleaved image
             for (int t = 0; t < 2; ++t)
-                for (int s = 0; s < 4; ++s) put_piece(img, wff1, TS_DIM, ff_n, TS_DIM, 64 * c + 32 * half + 16 * t, 32 * s);
-        for (int rt = 0; rt < 8; ++rt) put_piece(img, wff2, ff_pad, TS_DIM, ff_pad, 16 * rt, 32 * c);
+                for (int s = 0; s < 4; ++s) ring_put_piece(img, wff1, TS_DIM, ff_n, TS_DIM, 64 * c + 32 * half + 16 * t, 32 * s);
+        for (int rt = 0; rt < 8; ++rt) ring_put_piece(img, wff2, ff_pad, TS_DIM, ff_pad, 16 * rt, 32 * c);
     }
 }
 int64_t trans_stack_layer_image_bytes() { return (int64_t)TS_SLOTS_PER_LAYER * TS_SLOT; }

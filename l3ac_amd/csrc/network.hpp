@@ -16,6 +16,8 @@ struct ConvUnitW {  // modules.py:10-41
     const unsigned char *w1_img = nullptr, *w2_img = nullptr;
     // W1 / W2 as ONE fragment-ordered bf16x3 stream in consumption order for conv_unit_wide_kernel (wide stages)
     const unsigned char* wide_img = nullptr;
+    // the same for conv_unit_ring_kernel (narrow stages, 16 frames per wave): pieces of ring_common.hpp per hidden pair
+    const unsigned char* ring_img = nullptr;
 };
 struct DownW {  // modules.py:96-99 and local_trans.py:136: Conv1d(k = stride) [+ ChannelNorm]
     int cin = 0, cout = 0, stride = 1;
@@ -77,6 +79,9 @@ struct l3ac_ctx {
     // channel contractions on the bf16 matrix cores through exact bf16x3 operand splits (default) or everything on the fp32 MFMA
     // instruction; head_pretanh (validation): the output head stores its value before the final tanh.
     bool gemm_split = true, head_pretanh = false;
+    // which fused kernel takes the narrow ConvUnits (C <= 96) on the split route: conv_unit_ring_kernel (16 frames per wave, LDS-DMA
+    // weight ring) or conv_unit_split_kernel (32 frames per wave, chunk barriers); l3ac_ctx_set_option(ctx, "narrow_ring", 0 / 1)
+    int narrow_ring = 1;  // 0: conv_unit_split_kernel everywhere, 1: the ring kernel where it is faster (C = 48, 96), 2: wherever it exists
     const unsigned char* img(const float* w) const {  // null on the exact route: launch_gemm then takes the fp32 kernel
         if (!gemm_split) return nullptr;
         auto it = split_img.find(w);
@@ -124,7 +129,12 @@ int workspace_ensure_clip(l3ac_ctx* ctx, int batch, int samples, hipStream_t s);
 
 // fused ConvUnit for the narrow stages (kernels/conv_unit_fused.hip); x must not alias y
 bool conv_unit_fused_supported(int c);
-int launch_conv_unit_fused(hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames, bool split);
+int launch_conv_unit_fused(hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames, bool split, int ring = 0);
+// third form of the narrow ConvUnit (kernels/conv_unit_ring.hip): 16 frames per wave, weights through an LDS-DMA ring
+bool conv_unit_ring_supported(int c);
+bool conv_unit_ring_preferred(int c);  // the widths the pipeline routes there by default
+int launch_conv_unit_ring(hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames);
+std::vector<unsigned char> conv_unit_ring_image(const float* w1, const float* w2, int c);  // w1 [4c][c], w2 [c][4c]
 // bf16x3 variant (kernels/conv_unit_split.hip), chosen by launch_conv_unit_fused when the images exist and the split route is on
 int launch_conv_unit_split(hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames);
 std::vector<unsigned char> conv_unit_w1_image(const float* w1, int c);  // w1 [4c][c]

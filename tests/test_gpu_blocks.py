@@ -192,6 +192,47 @@ def test_conv_units(tiny, full):
         _close(block, G.from_frames(got), ref, atol=5e-5, rtol=5e-5)
 
 
+def test_conv_units_narrow_ring_and_split_forms(full):
+    """The two fused forms of the narrow ConvUnits (C = 24 / 48 / 96) — conv_unit_ring_kernel (16 frames per wave, LDS-DMA weight
+    ring; default) and conv_unit_split_kernel (32 frames per wave) — against the oracle on shapes that exercise tile and clip
+    boundaries (frames = 1, 15, 17, not a multiple of 16, enough tiles for several passes of the persistent grid with the ring
+    wrapping around), and against each other through an fp64 evaluation: neither may be the less accurate one by more than
+    rounding noise."""
+    codec, mc, w = full
+    ctx = codec.network.context()
+    cases = (("encoder.blocks.1.0.module", 24, 3, 1), ("encoder.blocks.1.0.module", 24, 2, 47), ("encoder.blocks.1.0.module", 24, 40, 16200),
+             ("encoder.blocks.3.0.module", 48, 5, 15), ("decoder.blocks.10.0.module", 48, 3, 8100), ("decoder.blocks.10.0.module", 48, 300, 97),
+             ("encoder.blocks.5.0.module", 96, 7, 17), ("decoder.blocks.7.0.module", 96, 2, 2700), ("decoder.blocks.7.1.module", 96, 130, 333))
+    for block, c, b, t in cases:
+        x = _rand((b, c, t), 900 + c + t)
+        ref = O.conv_unit(w, block, x[:2])
+        outs = {}
+        for name, ring in (("ring", 2), ("split", 0)):
+            ctx.set_option("narrow_ring", ring)
+            try:
+                outs[name] = G.from_frames(G.op_block(ctx, "l3ac_op_conv_unit", block, G.to_frames(x), (b, t, c)))
+            finally:
+                ctx.set_option("narrow_ring", 1)
+            _close(f"{name} {block} B={b} T={t}", outs[name][:2], ref, atol=5e-5, rtol=5e-5)
+        d = float((outs["ring"] - outs["split"]).abs().max())
+        print(f"[ring vs split {block} B={b} T={t}] max difference {d:.3e}")
+        assert d < 5e-5
+    block, c = "decoder.blocks.7.0.module", 96
+    x = _rand((2, c, 1000), 4242)
+    ref64 = O.conv_unit({k: v.double() for k, v in w.items() if k.startswith(block)}, block, x.double())
+    errs = {}
+    for name, ring in (("ring", 2), ("split", 0)):
+        ctx.set_option("narrow_ring", ring)
+        try:
+            got = G.from_frames(G.op_block(ctx, "l3ac_op_conv_unit", block, G.to_frames(x), (2, 1000, c))).double()
+        finally:
+            ctx.set_option("narrow_ring", 1)
+        e = (got - ref64).abs()
+        errs[name] = (float(e.max()), float(e.pow(2).mean().sqrt()))
+    print(f"[narrow forms vs fp64] ring max {errs['ring'][0]:.3e} rms {errs['ring'][1]:.3e} | split max {errs['split'][0]:.3e} rms {errs['split'][1]:.3e}")
+    assert errs["ring"][1] <= 1.25 * errs["split"][1] + 1e-9
+
+
 def test_conv_units_wide_fused(full):
     """conv_unit_wide_kernel (C = 192 / 256: hidden tensor in registers, weights streamed through the LDS ring) against the
     oracle on shapes that exercise what the small cases above do not: clip boundaries inside a 32-row tile (frames % 32 != 0),
