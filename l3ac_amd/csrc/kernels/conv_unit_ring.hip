@@ -176,8 +176,7 @@ __global__ __launch_bounds__(64 * G::WAVES, G::WAVES * G::PER_CU / 4) void conv_
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
         }
-        s1 += __shfl_xor(s1, 16, 64);
-        s1 += __shfl_xor(s1, 32, 64);
+        s1 = rows_sum(s1);
         const float mean = s1 / (float)C;
         float s2 = 0.f;
 #pragma unroll
@@ -187,8 +186,7 @@ __global__ __launch_bounds__(64 * G::WAVES, G::WAVES * G::PER_CU / 4) void conv_
                 const float d = (16 * t + 4 * lg + i < C) ? a[t][i] - mean : 0.f;
                 s2 = fmaf(d, d, s2);
             }
-        s2 += __shfl_xor(s2, 16, 64);
-        s2 += __shfl_xor(s2, 32, 64);
+        s2 = rows_sum(s2);
         const float rstd = 1.0f / sqrtf(s2 / (float)C + 1e-8f);
         bf16x8 ap[G::K1][3];
 #pragma unroll

@@ -42,20 +42,38 @@ namespace {
 constexpr int TS_DIM = 128, TS_HEADS = 6, TS_DH = 32, TS_INNER = TS_HEADS * TS_DH;
 constexpr int TS_FFI = 341;                    // int(128 * 4 * 2 / 3)
 constexpr int TS_FF_CHUNKS = (TS_FFI + 31) / 32;  // hidden units in chunks of 32 (zero padded)
-constexpr int TS_PIECE = 3072, TS_SLOT_PIECES = 4, TS_SLOT = TS_SLOT_PIECES * TS_PIECE, TS_RING_SLOTS = 4;
+constexpr int TS_PIECE = 3072, TS_SLOT_PIECES = 4, TS_SLOT = TS_SLOT_PIECES * TS_PIECE;
 constexpr int TS_PIECES_PER_HEAD = 32, TS_PIECES_PER_CHUNK = 24;
 constexpr int TS_PIECES_PER_LAYER = TS_HEADS * TS_PIECES_PER_HEAD + TS_FF_CHUNKS * TS_PIECES_PER_CHUNK;  // 456
 constexpr int TS_SLOTS_PER_LAYER = TS_PIECES_PER_LAYER / TS_SLOT_PIECES;                                // 114
 static_assert(TS_PIECES_PER_LAYER % TS_SLOT_PIECES == 0, "a layer is a whole number of ring slots");
-constexpr int TS_MAX_FRAMES = 192, TS_MAX_WAVES = TS_MAX_FRAMES / 16, TS_MAX_LAYERS = 8;
-// LDS (bytes)
-constexpr int TS_OFF_RING = 0;
-constexpr int TS_OFF_K = TS_OFF_RING + TS_RING_SLOTS * TS_SLOT;          // K fragments: [key tile 12][plane][lane] 16 B
-constexpr int TS_OFF_V = TS_OFF_K + TS_MAX_WAVES * TS_PIECE;             // V^T fragments: [key step 6][d tile 2][plane][lane] 16 B
-constexpr int TS_OFF_BIAS = TS_OFF_V + TS_MAX_WAVES * TS_PIECE;          // distance bias [heads][192]
-constexpr int TS_OFF_LN = TS_OFF_BIAS + TS_HEADS * TS_MAX_FRAMES * 4;    // LayerNorm parameters [layers][4][128]
-constexpr int ts_lds_bytes(int layers) { return TS_OFF_LN + layers * 4 * TS_DIM * 4; }
-static_assert(ts_lds_bytes(TS_MAX_LAYERS) <= 160 * 1024, "LDS budget exceeded");
+constexpr int TS_MAX_FRAMES = 192, TS_MAX_LAYERS = 8;
+// LDS (bytes) of the instantiation for at most MAXW waves: the K / V^T fragments need MAXW key tiles, what that leaves goes to the
+// weight ring — 4 slots (3 in flight) at 12 waves, 8 (7 in flight, 84 KB) at 4 waves: with ONE wave per SIMD a slot is consumed
+// in ~0.2 us, and a single clip (the streaming chunk) pulls its weights from beyond L2: the stream has to run that far ahead
+template <int MAXW>
+struct TsLds {
+    // MAXW <= 4 (clips of at most 64 frames: one computing wave per SIMD, nothing hides a wave's own overheads, and 60 frames of
+    // work per 1.37 MB of weights make the stream itself the bound: ~25 GB/s per issuing wave): four dedicated LOADER waves, one per
+    // SIMD, issue the LDS-DMAs (each costs its issuing wave ~60-180 cycles); slots are synchronised in PAIRS (one barrier and one
+    // exposed first-fragment read per 48 MFMAs instead of 24); the ring is 8 slots deep (a single clip — the streaming chunk —
+    // pulls its weights from beyond L2).  Otherwise six of the computing waves copy two 1-KB blocks of every slot each.
+    static constexpr bool LOADER = MAXW <= 4;
+    static constexpr int RING_SLOTS = LOADER ? 8 : 4;     // (a power of two)
+    static constexpr int SG = LOADER ? 2 : 1;              // slots per synchronisation group
+    static constexpr int NDW = LOADER ? 4 : 6;             // waves that issue the copies
+    static constexpr int BPW = 12 / NDW;                   // 1-KB blocks per such wave and slot
+    static constexpr int GROUPS = RING_SLOTS / SG, PFG = GROUPS - 1;  // groups in the ring / in flight
+    static constexpr int WAIT = BPW * SG * (PFG - 1);      // a DMA wave's copies that may stay outstanding at a group's end
+    static constexpr int THREADS = 64 * (MAXW + (LOADER ? NDW : 0));
+    static constexpr int OFF_RING = 0;
+    static constexpr int OFF_K = OFF_RING + RING_SLOTS * TS_SLOT;        // K fragments: [key tile MAXW][plane][lane] 16 B
+    static constexpr int OFF_V = OFF_K + MAXW * TS_PIECE;                // V^T fragments: [key step MAXW / 2][d tile 2][plane][lane] 16 B
+    static constexpr int OFF_BIAS = OFF_V + MAXW * TS_PIECE;             // distance bias [heads][192]
+    static constexpr int OFF_LN = OFF_BIAS + TS_HEADS * TS_MAX_FRAMES * 4;  // LayerNorm parameters [layers][4][128]
+    static constexpr int bytes(int layers) { return OFF_LN + layers * 4 * TS_DIM * 4; }
+    static_assert(bytes(TS_MAX_LAYERS) <= 160 * 1024 && WAIT <= 63 && TS_SLOTS_PER_LAYER % SG == 0, "LDS budget / vmcnt field / slot pairing");
+};
 
 struct TransStackArgs {
     float* x;                  // [batch][frames][128], updated in place
@@ -82,21 +100,42 @@ __device__ __forceinline__ float ts_exp_neg(float x) {
 // MAXW: most waves a workgroup of this instantiation is launched with (register budget 512 / ceil(MAXW / 4) per lane).  Where the
 // budget allows (MAXW <= 8: clips of at most 128 frames, e.g. the 60-token stages) the next weight fragment is fetched from LDS
 // while the current one multiplies; with one wave per SIMD nothing else covers that latency.
+#ifdef L3AC_TS_STAMPS  // diagnostic build (tools/ts_stamps.py): s_memtime sums per phase of wave 0 of workgroup 0
+__device__ long long g_ts_stamps[16];
+#define TS_STAMP(slot)                                                                        \
+    do {                                                                                      \
+        if (blockIdx.x == 0 && tid == 0) {                                                    \
+            const long long now_ = (long long)__builtin_amdgcn_s_memtime();                   \
+            g_ts_stamps[slot] += now_ - ts_last;                                              \
+            ts_last = now_;                                                                   \
+        }                                                                                     \
+    } while (0)
+#else
+#define TS_STAMP(slot) do { } while (0)
+#endif
+
+// (amdgpu_waves_per_eu: one workgroup per CU, so THREADS / 256 waves per SIMD is all the occupancy there will ever be — told so, the
+// scheduler spends the registers on keeping fragments in flight instead of re-reading them next to their use behind a full wait)
 template <int MAXW>
-__global__ __launch_bounds__(64 * MAXW) void trans_stack_kernel(const TransStackArgs p) {
+__global__ __launch_bounds__(TsLds<MAXW>::THREADS) __attribute__((amdgpu_waves_per_eu(TsLds<MAXW>::THREADS / 256, TsLds<MAXW>::THREADS / 256)))
+void trans_stack_kernel(const TransStackArgs p) {
     constexpr bool PREF = MAXW <= 8;
+    using L = TsLds<MAXW>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_ts[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fl = lane & 15, lg = lane >> 4;
     const int frames = p.frames;
+#ifdef L3AC_TS_STAMPS
+    long long ts_last = (long long)__builtin_amdgcn_s_memtime();
+#endif
     const int frame = 16 * wave + fl;            // this lane's frame (column of every tile)
     const bool frame_ok = frame < frames;
     float* const xclip = p.x + (int64_t)blockIdx.x * frames * TS_DIM;
     float* const xlane = xclip + (int64_t)(frame_ok ? frame : 0) * TS_DIM + 4 * lg;  // + 16 t: this lane's 4 channels of tile t
-    float* const bias_s = reinterpret_cast<float*>(smem_ts + TS_OFF_BIAS);
-    float* const ln_s = reinterpret_cast<float*>(smem_ts + TS_OFF_LN);
+    float* const bias_s = reinterpret_cast<float*>(smem_ts + L::OFF_BIAS);
+    float* const ln_s = reinterpret_cast<float*>(smem_ts + L::OFF_LN);
 
     // ---- the residual stream of this wave's 16 frames: xr[t][i] = x[frame][16 t + 4 g + i].  It is in registers only around a
     // LayerNorm: the products of a sub-layer accumulate from ZERO (yacc) and are added to x once, at the sub-layer's end —
@@ -117,41 +156,69 @@ __global__ __launch_bounds__(64 * MAXW) void trans_stack_kernel(const TransStack
     __syncthreads();  // (every plain load above is drained here, before the first hand-counted LDS-DMA is issued)
 
     // ---- the weight stream -------------------------------------------------------------------------------------------
-    const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(smem_ts + TS_OFF_RING);
+    const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(smem_ts + L::OFF_RING);
     const unsigned lane_off = 16u * (unsigned)lane;
     const int total_slots = p.n_layers * TS_SLOTS_PER_LAYER;
     int dma_slot = 0;  // next slot of the stream to fetch (wave-uniform); past the end it wraps around (never consumed)
-    auto issue = [&]() __attribute__((always_inline)) {
-        if (wave < 4) {
-            const int src = dma_slot < total_slots ? dma_slot : dma_slot - total_slots;
-            ring_dma_quarter(p.img + (int64_t)src * TS_SLOT + TS_PIECE * wave, lane_off,
-                           ring_lds + (unsigned)((dma_slot & (TS_RING_SLOTS - 1)) * TS_SLOT + TS_PIECE * wave));
+    const int n_compute = (int)(blockDim.x >> 6) - (L::LOADER ? L::NDW : 0);
+    const int dma_wave = L::LOADER ? (wave >= n_compute ? wave - n_compute : -1) : (wave < L::NDW ? wave : -1);  // this wave's share of the copies, -1: none
+    auto issue_group = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < L::SG; ++g) {
+            if (dma_wave >= 0) {
+                const int src = dma_slot < total_slots ? dma_slot : dma_slot - total_slots;
+                const unsigned char* sb = p.img + (int64_t)src * TS_SLOT + 1024 * dma_wave;
+                const unsigned db = ring_lds + (unsigned)((dma_slot & (L::RING_SLOTS - 1)) * TS_SLOT + 1024 * dma_wave);
+#pragma unroll
+                for (int i = 0; i < L::BPW; ++i) ring_dma_1k(sb + 1024 * L::NDW * i, lane_off, db + 1024u * (unsigned)(L::NDW * i));
+            }
+            ++dma_slot;
         }
-        ++dma_slot;
     };
-    // end of a slot step: this wave's copies of the NEXT slot have landed (all but the two youngest slots' 3 + 3 pieces; plain
-    // loads / stores of x in the queue only make the wait stronger), its own LDS reads and writes are done, then everybody's
-    // are; the slot just consumed is free for the next step's DMA
+    // end of a group of slots: this wave's copies of the NEXT group have landed (all but the youngest PFG - 1 groups'; plain loads /
+    // stores of x in the queue only make the wait stronger), its own LDS reads and writes are done, then everybody's are; the
+    // group just consumed is free for the next step's DMA
     auto step_sync = [&]() __attribute__((always_inline)) {
-        asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef L3AC_TS_NOSYNC  // (TIMING-ONLY bounding build without the group barrier: wrong results)
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(L::WAIT) : "memory");
         __builtin_amdgcn_s_barrier();
+#endif
         asm volatile("" ::: "memory");
     };
-    issue();
-    issue();
-    issue();
-    step_sync();  // slot 0 has landed
+#pragma unroll
+    for (int j = 0; j < L::PFG; ++j) issue_group();
+    step_sync();  // group 0 has landed
+    TS_STAMP(0);  // prologue
+    if (L::LOADER && wave >= n_compute) {  // a loader: one refill and one barrier per group, in step with the computing waves
+        for (int g = 0; g < total_slots / L::SG; ++g) {
+            issue_group();
+            step_sync();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
     int slot_no = 0;  // slots consumed so far (wave-uniform)
-    const unsigned char* const ring_lane = smem_ts + TS_OFF_RING + 16 * lane;
+    const unsigned char* const ring_lane = smem_ts + L::OFF_RING + 16 * lane;
     auto load_frag = [&](bf16x8 (&f)[3], const unsigned char* a) __attribute__((always_inline)) {
+#ifdef L3AC_TS_NOFRAG  // TIMING-ONLY bounding build (wrong results): every fragment is the same three registers, nothing is read
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            u32x4 v = {(unsigned)lane, 0x3f803f80u, (unsigned)wave, 0x3c003c00u};
+            asm volatile("" : "+v"(v));
+            f[pl] = __builtin_bit_cast(bf16x8, v);
+        }
+        (void)a;
+#else
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) f[pl] = *reinterpret_cast<const bf16x8*>(a + 1024 * pl);
+#endif
     };
     // One slot step: the slot's 4 weight pieces in order, body(j, fragment) for piece j (compile-time j); `last` runs after the
     // last piece's products and before the step's barrier (LDS writes other waves read after it).
     auto slot_step = [&](auto&& body, auto&& last) __attribute__((always_inline)) {
-        issue();  // refill the slot consumed one step ago
-        const unsigned char* a = ring_lane + (slot_no & (TS_RING_SLOTS - 1)) * TS_SLOT;
+        const bool group_begins = (slot_no & (L::SG - 1)) == 0, group_ends = (slot_no & (L::SG - 1)) == L::SG - 1;
+        if (!L::LOADER && group_begins) issue_group();  // refill the group consumed one step ago
+        const unsigned char* a = ring_lane + (slot_no & (L::RING_SLOTS - 1)) * TS_SLOT;
         bf16x8 f[PREF ? 2 : 1][3];
         load_frag(f[0], a);
         ring_static_for<TS_SLOT_PIECES>([&](auto j_) {
@@ -166,9 +233,44 @@ __global__ __launch_bounds__(64 * MAXW) void trans_stack_kernel(const TransStack
         });
         last();
         ++slot_no;
-        step_sync();
+        if (group_ends) step_sync();
     };
-    auto nothing = []() __attribute__((always_inline)) {};
+    // Two consecutive slot steps (every phase is a whole number of pairs and starts on an even slot).  Where slots are synchronised in
+    // pairs (LOADER) the second slot's fragments are fetched while the first slot's products run: one exposed LDS round trip per
+    // 48 MFMAs.  body(half, j, fragment), last(half).
+    auto slot_pair = [&](auto&& body, auto&& last) __attribute__((always_inline)) {
+        using H0 = std::integral_constant<int, 0>;
+        using H1 = std::integral_constant<int, 1>;
+        if constexpr (L::SG == 2) {
+            const unsigned char* a = ring_lane + (slot_no & (L::RING_SLOTS - 1)) * TS_SLOT;  // (slot_no even: the pair is contiguous in the ring)
+            bf16x8 fa[TS_SLOT_PIECES][3], fb[TS_SLOT_PIECES][3];
+#pragma unroll
+            for (int j = 0; j < TS_SLOT_PIECES; ++j) load_frag(fa[j], a + j * TS_PIECE);
+            ring_static_for<TS_SLOT_PIECES>([&](auto j_) {
+                constexpr int j = decltype(j_)::value;
+                load_frag(fb[j], a + TS_SLOT + j * TS_PIECE);
+                body(H0{}, j_, fa[j]);
+            });
+            last(H0{});
+            ring_static_for<TS_SLOT_PIECES>([&](auto j_) { body(H1{}, j_, fb[decltype(j_)::value]); });
+            // the issue order, spelled out: left alone hipcc sinks every fragment read next to its use behind a full s_waitcnt (105
+            // such waits for 360 MFMAs, ~450 cycles per slot of exposed LDS latency with one wave per SIMD)
+            __builtin_amdgcn_sched_group_barrier(0x100, 3 * TS_SLOT_PIECES, 0);  // the first slot's fragments
+#pragma unroll
+            for (int j = 0; j < TS_SLOT_PIECES; ++j) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);  // one fragment of the second slot ...
+                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);  // ... in front of one piece's products of the first
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 6 * TS_SLOT_PIECES, 0);
+            last(H1{});
+            slot_no += 2;
+            step_sync();
+        } else {
+            slot_step([&](auto j_, const bf16x8 (&f)[3]) __attribute__((always_inline)) { body(H0{}, j_, f); }, [&]() __attribute__((always_inline)) { last(H0{}); });
+            slot_step([&](auto j_, const bf16x8 (&f)[3]) __attribute__((always_inline)) { body(H1{}, j_, f); }, [&]() __attribute__((always_inline)) { last(H1{}); });
+        }
+    };
+    auto nothing = [](auto) __attribute__((always_inline)) {};
 
     // LayerNorm over the 128 channels of this lane's frame (F.layer_norm, eps 1e-5: two-pass, rstd = 1 / sqrt(var + eps) as
     // rows.hip), then the bf16x3 planes of the result: ap[s] = k step s (channels 32 s .. 32 s + 31)
@@ -177,8 +279,7 @@ __global__ __launch_bounds__(64 * MAXW) void trans_stack_kernel(const TransStack
         float s = 0.f;
 #pragma unroll
         for (int t = 0; t < 8; ++t) s += (xr[t][0] + xr[t][1]) + (xr[t][2] + xr[t][3]);
-        s += __shfl_xor(s, 16, 64);
-        s += __shfl_xor(s, 32, 64);
+        s = rows_sum(s);
         const float mean = s / (float)TS_DIM;
         float q = 0.f;
 #pragma unroll
@@ -188,8 +289,7 @@ __global__ __launch_bounds__(64 * MAXW) void trans_stack_kernel(const TransStack
                 const float d = xr[t][i] - mean;
                 q = fmaf(d, d, q);
             }
-        q += __shfl_xor(q, 16, 64);
-        q += __shfl_xor(q, 32, 64);
+        q = rows_sum(q);
         const float rstd = 1.0f / sqrtf(q / (float)TS_DIM + 1e-5f);
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) {
@@ -217,10 +317,10 @@ __global__ __launch_bounds__(64 * MAXW) void trans_stack_kernel(const TransStack
         }
     };
 
-    unsigned char* const k_mine = smem_ts + TS_OFF_K + wave * TS_PIECE + 16 * lane;                               // + 1024 plane
-    unsigned char* const v_mine = smem_ts + TS_OFF_V + (wave >> 1) * 2 * TS_PIECE + 16 * lane + 8 * (wave & 1);  // + 3072 dt + 1024 plane
-    const unsigned char* const k_lane = smem_ts + TS_OFF_K + 16 * lane;
-    const unsigned char* const v_lane = smem_ts + TS_OFF_V + 16 * lane;
+    unsigned char* const k_mine = smem_ts + L::OFF_K + wave * TS_PIECE + 16 * lane;                               // + 1024 plane
+    unsigned char* const v_mine = smem_ts + L::OFF_V + (wave >> 1) * 2 * TS_PIECE + 16 * lane + 8 * (wave & 1);  // + 3072 dt + 1024 plane
+    const unsigned char* const k_lane = smem_ts + L::OFF_K + 16 * lane;
+    const unsigned char* const v_lane = smem_ts + L::OFF_V + 16 * lane;
     const int key_steps = (wave >> 1) + 1;  // causal: keys 0 .. 16 wave + 15 in steps of 32
     const f32x4_t zero4 = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
@@ -231,44 +331,44 @@ __global__ __launch_bounds__(64 * MAXW) void trans_stack_kernel(const TransStack
         layer_norm_planes(lnp, lnp + TS_DIM);
 #pragma unroll
         for (int t = 0; t < 8; ++t) yacc[t] = zero4;
+        TS_STAMP(1);  // LayerNorm 1
 #pragma unroll 1
         for (int h = 0; h < TS_HEADS; ++h) {
             // ---- q^T, k^T (weights x activations) and V (activations x weights) of head h for this wave's frames ------
             f32x4_t qa[2] = {zero4, zero4}, ka[2] = {zero4, zero4}, va[2] = {zero4, zero4};
-            ring_static_for<2>([&](auto dt_) {
+            slot_pair([&](auto dt_, auto j_, const bf16x8 (&f)[3]) __attribute__((always_inline)) {
                 constexpr int dt = decltype(dt_)::value;
-                slot_step([&](auto j_, const bf16x8 (&f)[3]) __attribute__((always_inline)) { qa[dt] = mfma6(f, ap[decltype(j_)::value], qa[dt]); }, nothing);
-            });
+                qa[dt] = mfma6(f, ap[decltype(j_)::value], qa[dt]);
+            }, nothing);
             bf16x8 qp[3];
             {
                 f32x4_t q0 = qa[0] * p.scale, q1 = qa[1] * p.scale;  // q pre-scaled (local_attention: q = q * scale)
                 planes_of(q0, q1, qp);
             }
-            ring_static_for<2>([&](auto dt_) {
+            slot_pair([&](auto dt_, auto j_, const bf16x8 (&f)[3]) __attribute__((always_inline)) {
                 constexpr int dt = decltype(dt_)::value;
-                slot_step([&](auto j_, const bf16x8 (&f)[3]) __attribute__((always_inline)) { ka[dt] = mfma6(f, ap[decltype(j_)::value], ka[dt]); },
-                          [&]() __attribute__((always_inline)) {
-                              if constexpr (dt == 1) {  // K of this wave's 16 keys as S^T's A-operand fragment
-                                  bf16x8 kp[3];
-                                  planes_of(ka[0], ka[1], kp);
+                ka[dt] = mfma6(f, ap[decltype(j_)::value], ka[dt]);
+            }, [&](auto dt_) __attribute__((always_inline)) {
+                if constexpr (decltype(dt_)::value == 1) {  // K of this wave's 16 keys as S^T's A-operand fragment
+                    bf16x8 kp[3];
+                    planes_of(ka[0], ka[1], kp);
 #pragma unroll
-                                  for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bf16x8*>(k_mine + 1024 * pl) = kp[pl];
-                              }
-                          });
+                    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bf16x8*>(k_mine + 1024 * pl) = kp[pl];
+                }
             });
-            ring_static_for<2>([&](auto dt_) {
+            // operands swapped: va[dt][i] = V[frame 16 wave + 4 g + i][d = 16 dt + fl]
+            slot_pair([&](auto dt_, auto j_, const bf16x8 (&f)[3]) __attribute__((always_inline)) {
                 constexpr int dt = decltype(dt_)::value;
-                // operands swapped: va[dt][i] = V[frame 16 wave + 4 g + i][d = 16 dt + fl]
-                slot_step([&](auto j_, const bf16x8 (&f)[3]) __attribute__((always_inline)) { va[dt] = mfma6(ap[decltype(j_)::value], f, va[dt]); },
-                          [&]() __attribute__((always_inline)) {  // half (keys of this wave) of the V^T fragment of key step wave / 2, d tile dt
-                              unsigned w0[3], w1[3];
-                              split2(va[dt][0], va[dt][1], w0[0], w0[1], w0[2]);
-                              split2(va[dt][2], va[dt][3], w1[0], w1[1], w1[2]);
+                va[dt] = mfma6(ap[decltype(j_)::value], f, va[dt]);
+            }, [&](auto dt_) __attribute__((always_inline)) {  // half (keys of this wave) of the V^T fragment of key step wave / 2, d tile dt
+                constexpr int dt = decltype(dt_)::value;
+                unsigned w0[3], w1[3];
+                split2(va[dt][0], va[dt][1], w0[0], w0[1], w0[2]);
+                split2(va[dt][2], va[dt][3], w1[0], w1[1], w1[2]);
 #pragma unroll
-                              for (int pl = 0; pl < 3; ++pl)
-                                  *reinterpret_cast<uint2*>(v_mine + TS_PIECE * dt + 1024 * pl) = make_uint2(w0[pl], w1[pl]);
-                          });  // (the last step's barrier publishes K and V of every wave)
-            });
+                for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint2*>(v_mine + TS_PIECE * dt + 1024 * pl) = make_uint2(w0[pl], w1[pl]);
+            });  // (the pair's last barrier publishes K and V of every wave)
+            TS_STAMP(2);  // q, k, v products (6 slots)
             // ---- causal attention of this wave's 16 queries over keys 0 .. 16 wave + 15 ------------------------------
             float m_run = -INFINITY, l_run = 0.f;
             f32x4_t oa[2] = {zero4, zero4};
@@ -293,8 +393,7 @@ __global__ __launch_bounds__(64 * MAXW) void trans_stack_kernel(const TransStack
                         st[u][i] = sv;
                         mx = fmaxf(mx, sv);
                     }
-                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                mx = rows_max(mx);
                 const float m_new = fmaxf(m_run, mx);  // finite from the first step on: key 0 is visible to every query
                 const float alpha = ts_exp_neg(m_run - m_new);
                 float psum = 0.f;
@@ -317,35 +416,37 @@ __global__ __launch_bounds__(64 * MAXW) void trans_stack_kernel(const TransStack
                     oa[dt] = mfma6(vf, pp, oa[dt] * alpha);  // O^T[d = 16 dt + 4 g + i][query fl]
                 }
             }
-            float l_tot = l_run + __shfl_xor(l_run, 16, 64);
-            l_tot += __shfl_xor(l_tot, 32, 64);
+            const float l_tot = rows_sum(l_run);
             const float inv = 1.0f / l_tot;
             bf16x8 op[3];
             {
                 f32x4_t o0 = oa[0] * inv, o1 = oa[1] * inv;
                 planes_of(o0, o1, op);
             }
+            TS_STAMP(3);  // attention
             // ---- out projection of this head's 32 columns, summed over the heads in yacc -------------------------------
-            ring_static_for<2>([&](auto half_) {
-                constexpr int half = decltype(half_)::value;
-                slot_step([&](auto j_, const bf16x8 (&f)[3]) __attribute__((always_inline)) {
-                    constexpr int rt = 4 * half + decltype(j_)::value;
-                    yacc[rt] = mfma6(f, op, yacc[rt]);
-                }, nothing);
-            });
+            slot_pair([&](auto half_, auto j_, const bf16x8 (&f)[3]) __attribute__((always_inline)) {
+                constexpr int rt = 4 * decltype(half_)::value + decltype(j_)::value;
+                yacc[rt] = mfma6(f, op, yacc[rt]);
+            }, nothing);
+            TS_STAMP(4);  // out projection (2 slots)
         }
         add_residual();
         // ================= FeedForward (GEGLU) ========================================================================
         layer_norm_planes(lnp + 2 * TS_DIM, lnp + 3 * TS_DIM);
 #pragma unroll
         for (int t = 0; t < 8; ++t) yacc[t] = zero4;
+        TS_STAMP(5);  // residual + LayerNorm 2
 #pragma unroll 1
         for (int c = 0; c < TS_FF_CHUNKS; ++c) {
             f32x4_t vg[4] = {zero4, zero4, zero4, zero4};  // value tiles 0, 1 then gate tiles 0, 1 of hidden units 32 c .. 32 c + 31
-            ring_static_for<4>([&](auto u_) {
-                constexpr int u = decltype(u_)::value;
-                slot_step([&](auto j_, const bf16x8 (&f)[3]) __attribute__((always_inline)) { vg[u] = mfma6(f, ap[decltype(j_)::value], vg[u]); }, nothing);
+            ring_static_for<2>([&](auto w_) {  // value tiles 0, 1, then gate tiles 0, 1
+                slot_pair([&](auto t_, auto j_, const bf16x8 (&f)[3]) __attribute__((always_inline)) {
+                    constexpr int u = 2 * decltype(w_)::value + decltype(t_)::value;
+                    vg[u] = mfma6(f, ap[decltype(j_)::value], vg[u]);
+                }, nothing);
             });
+            TS_STAMP(6);  // FF-in products (4 slots)
             bf16x8 hp[3];
             {
                 f32x4_t h0, h1;
@@ -356,21 +457,32 @@ __global__ __launch_bounds__(64 * MAXW) void trans_stack_kernel(const TransStack
                 }
                 planes_of(h0, h1, hp);
             }
-            ring_static_for<2>([&](auto half_) {
-                constexpr int half = decltype(half_)::value;
-                slot_step([&](auto j_, const bf16x8 (&f)[3]) __attribute__((always_inline)) {
-                    constexpr int rt = 4 * half + decltype(j_)::value;
-                    yacc[rt] = mfma6(f, hp, yacc[rt]);
-                }, nothing);
-            });
+            TS_STAMP(7);  // GEGLU
+            slot_pair([&](auto half_, auto j_, const bf16x8 (&f)[3]) __attribute__((always_inline)) {
+                constexpr int rt = 4 * decltype(half_)::value + decltype(j_)::value;
+                yacc[rt] = mfma6(f, hp, yacc[rt]);
+            }, nothing);
+            TS_STAMP(8);  // FF-out products (2 slots)
         }
         add_residual();  // (also the next layer's LayerNorm input, already in xr)
+        TS_STAMP(9);  // residual
     }
     // leave no LDS-DMA in flight behind the workgroup
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 }  // namespace
+
+#ifdef L3AC_TS_STAMPS
+extern "C" int l3ac_debug_ts_stamps(long long* out, int n, int reset) {  // diagnostic builds only (not part of the ABI)
+    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ts_stamps), (size_t)n * sizeof(long long));
+    if (reset) {
+        long long zero[16] = {};
+        rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ts_stamps), zero, sizeof(zero));
+    }
+    return rc;
+}
+#endif
 
 bool trans_stack_supported(int dim, int dim_head, int heads, int ff_inner, int frames, int window, int n_layers) {
     return dim == TS_DIM && dim_head == TS_DH && heads == TS_HEADS && ff_inner == TS_FFI && frames >= 1 && frames <= TS_MAX_FRAMES &&
@@ -402,30 +514,31 @@ int launch_trans_stack(hipStream_t s, const LocalTransW& w, float* x, int batch,
     L3AC_REQUIRE(w.stack_img && w.stack_ln && batch > 0 && frames >= 1 && frames <= TS_MAX_FRAMES && frames <= w.window &&
                      n_layers >= 1 && n_layers <= TS_MAX_LAYERS,
                  "trans_stack: bad arguments (frames=%d window=%d layers=%d)", frames, w.window, n_layers);
-    const int lds = ts_lds_bytes(n_layers);
     static PerDeviceOnce configured;
     if (configured.first()) {
-        for (const void* fn : {reinterpret_cast<const void*>(trans_stack_kernel<4>), reinterpret_cast<const void*>(trans_stack_kernel<8>),
-                               reinterpret_cast<const void*>(trans_stack_kernel<12>)})
-            L3AC_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, ts_lds_bytes(TS_MAX_LAYERS)));
+        L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trans_stack_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, TsLds<4>::bytes(TS_MAX_LAYERS)));
+        L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trans_stack_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, TsLds<8>::bytes(TS_MAX_LAYERS)));
+        L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trans_stack_kernel<12>), hipFuncAttributeMaxDynamicSharedMemorySize, TsLds<12>::bytes(TS_MAX_LAYERS)));
         configured.done();
     }
     int waves = 2 * (int)ceil_div64(frames, 32);  // even: every key tile a wave reads in pairs has been written by some wave
-    if (waves < 4) waves = 4;                      // waves 0 .. 3 carry the weight stream
+    if (waves < 4) waves = 4;                      // (the 4-wave instantiation adds its loader wave at the launch)
     TransStackArgs a{};
     a.x = x; a.frames = frames; a.n_layers = n_layers; a.img = w.stack_img; a.ln = w.stack_ln; a.bias_table = w.bias_table;
     a.table_stride = 2 * w.window; a.scale = scale;
     const double rows = (double)batch * frames;
     const double lin = 2.0 * (3.0 * TS_INNER * TS_DIM + TS_DIM * TS_INNER + 3.0 * TS_FFI * TS_DIM);
     const double att = 2.0 * 2.0 * TS_INNER * 0.5 * (frames + 1.0);
-    ProfScope prof(s, "trans_stack_kernel", n_layers * rows * (lin + att), 2.0 * rows * TS_DIM * 4.0);
+    char name[64];
+    std::snprintf(name, sizeof(name), "trans_stack_kernel %dx%d L%d", batch, frames, n_layers);
+    ProfScope prof(s, name, n_layers * rows * (lin + att), 2.0 * rows * TS_DIM * 4.0);
     // (the instantiation only changes the register budget and whether weight fragments are fetched one piece ahead: same bits)
     if (waves <= 4)
-        hipLaunchKernelGGL(trans_stack_kernel<4>, dim3((unsigned)batch), dim3(64 * waves), lds, s, a);
+        hipLaunchKernelGGL(trans_stack_kernel<4>, dim3((unsigned)batch), dim3(64 * (waves + TsLds<4>::NDW)), TsLds<4>::bytes(n_layers), s, a);  // + the loader waves
     else if (waves <= 8)
-        hipLaunchKernelGGL(trans_stack_kernel<8>, dim3((unsigned)batch), dim3(64 * waves), lds, s, a);
+        hipLaunchKernelGGL(trans_stack_kernel<8>, dim3((unsigned)batch), dim3(64 * waves), TsLds<8>::bytes(n_layers), s, a);
     else
-        hipLaunchKernelGGL(trans_stack_kernel<12>, dim3((unsigned)batch), dim3(64 * waves), lds, s, a);
+        hipLaunchKernelGGL(trans_stack_kernel<12>, dim3((unsigned)batch), dim3(64 * waves), TsLds<12>::bytes(n_layers), s, a);
     L3AC_LAUNCH_CHECK();
     return L3AC_OK;
 }
