@@ -477,7 +477,7 @@ def test_fsq_fused_forward_and_roundtrip(full):
         _close(f"latents {tag}", lat.cpu(), lat_ref, atol=2e-6, rtol=2e-6)
         n_bad, ok = index_mismatch_report(idx.cpu().numpy(), ind_ref["indices"].numpy(), lat_ref.numpy(), mc2.levels, tau=1e-4)
         print(f"[fsq fused {tag}] {n_bad}/4096 tokens differ (project_in summation order)")
-        assert ok and n_bad <= 4
+        assert ok and n_bad <= 1  # observed on the MI355X: 0 (gate = observed + 1)
         # from the SAME latents the indices are bit-exact
         q2, idx2, li2, _ = G.fsq_forward(None, list(mc2.levels), None, None, dev["project_out.weight"], dev["project_out.bias"],
                                          latents_in=lat_ref.cuda())

@@ -13,8 +13,19 @@ from tests.helpers import GOLDEN, index_agreement, index_mismatch_report, load_c
 pytestmark = pytest.mark.gpu
 
 TAU = 1e-4        # a flipped index must come from a latent within TAU of a rounding boundary (in level units)
-WAVE_ATOL = 2e-3  # waveform tolerance (tanh output in [-1, 1]) for the decoder given identical indices
-FEAT_ATOL = 5e-4  # encoder / transformer feature tolerance, activations O(1)
+# Tolerances = the largest error observed on the MI355X for the cases of this file (profiles/r03/pytest_gpu.log) x 1.3.  The
+# decoder amplifies the ~1e-7 rounding noise of ANY evaluation order to a few 1e-4 at the tanh output.
+WAVE_ATOL = 7.5e-4      # 1 s clips, decoder given identical indices (observed <= 5.6e-4: 1k5bps, 8 clips)
+WAVE_ATOL_LONG = 2e-3   # 6.5 s clips and chunked long audio (observed <= 1.47e-3)
+WAVE_ATOL_ROUTES = 1e-3 # bf16x3 route against exact-fp32 route, same tokens (observed <= 7.7e-4)
+FEAT_ATOL = 1e-5        # encoder / transformer features, activations O(1) (observed <= 6.4e-6)
+
+
+def _max_err(name, got, ref):
+    """max |got - ref| over numpy arrays, printed (the observed value the tolerances are set from)."""
+    e = float(np.abs(np.asarray(got, dtype=np.float64) - np.asarray(ref, dtype=np.float64)).max())
+    print(f"[{name}] max|err|={e:.3e}")
+    return e
 
 
 def _codec(tag, seed):
@@ -120,9 +131,9 @@ def test_against_committed_reference_vectors(tag, gemm_mode):
     assert ok and n_bad <= 1  # observed: 0
     wave = codec.decode_audio(indices=torch.from_numpy(e2e["indices"]).cuda()).cpu()
     if tag == "tiny":
-        np.testing.assert_allclose(wave.numpy(), e2e["wave"], atol=WAVE_ATOL)
+        assert _max_err(f"{tag} {gemm_mode} wave vs reference e2e vector", wave.numpy(), e2e["wave"]) < WAVE_ATOL
     else:
-        np.testing.assert_allclose(strided(wave).numpy(), e2e["wave_strided"], atol=WAVE_ATOL)
+        assert _max_err(f"{tag} {gemm_mode} wave vs reference e2e vector", strided(wave).numpy(), e2e["wave_strided"]) < WAVE_ATOL
     # conv-stack-only vectors (reference code only): encoder feature and decoder waveform
     ctx = codec.network.context()
     x, _ = O.preprocess(mc, audio)
@@ -130,17 +141,17 @@ def test_against_committed_reference_vectors(tag, gemm_mode):
     feat = G.op_plain(ctx, "l3ac_op_encoder", x.cuda(), x.shape[0], x.shape[1], (x.shape[0], x.shape[1] // enc_rate, mc.feature_dim))
     feat = G.from_frames(feat)
     if tag == "tiny":
-        np.testing.assert_allclose(feat.numpy(), conv["feature"], atol=FEAT_ATOL)
+        assert _max_err(f"{tag} {gemm_mode} encoder feature vs reference vector", feat.numpy(), conv["feature"]) < FEAT_ATOL
         q_feat = torch.from_numpy(conv["q_feat"])
     else:
-        np.testing.assert_allclose(strided(feat).numpy(), conv["feature_strided"], atol=FEAT_ATOL)
+        assert _max_err(f"{tag} {gemm_mode} encoder feature vs reference vector", strided(feat).numpy(), conv["feature_strided"]) < FEAT_ATOL
         q_feat = O.to_features(w, mc, torch.from_numpy(conv["indices"]))
     wave = G.op_plain(ctx, "l3ac_op_decoder", q_feat.cuda().contiguous(), q_feat.shape[0], q_feat.shape[1],
                       (q_feat.shape[0], q_feat.shape[1] * enc_rate)).cpu()
     if tag == "tiny":
-        np.testing.assert_allclose(wave.numpy(), conv["wave"], atol=WAVE_ATOL)
+        assert _max_err(f"{tag} {gemm_mode} decoder wave vs reference vector", wave.numpy(), conv["wave"]) < WAVE_ATOL
     else:
-        np.testing.assert_allclose(strided(wave).numpy(), conv["wave_strided"], atol=WAVE_ATOL)
+        assert _max_err(f"{tag} {gemm_mode} decoder wave vs reference vector", strided(wave).numpy(), conv["wave_strided"]) < WAVE_ATOL
 
 
 def test_split_and_exact_gemm_routes_agree():
@@ -161,7 +172,7 @@ def test_split_and_exact_gemm_routes_agree():
     err = (out[True][1] - out[False][1]).abs().max().item()
     print(f"[split vs exact] token differences {n_diff}/{out[True][0].numel()}, waveform max |diff| {err:.3e}")
     assert n_diff == 0
-    assert err <= WAVE_ATOL
+    assert err <= WAVE_ATOL_ROUTES
 
 
 def test_full_batch_properties_1kbps():
@@ -242,7 +253,7 @@ def test_index_agreement_full_batch(tag):
 
 # mismatches observed on the MI355X per (config, input set), both GEMM routes (round 3; every one a +-1 flip within TAU)
 OBSERVED_WIDE_MISMATCHES = {}
-OBSERVED_WIDE_WAVE_ERR = 2e-3
+OBSERVED_WIDE_WAVE_ERR = 9.5e-4  # structured set, 64 clips, both routes: observed <= 7.2e-4
 
 
 @pytest.mark.parametrize("tag", ["1kbps", "3kbps"])
@@ -471,7 +482,7 @@ def test_long_clip_multi_window_attention():
     print(f"[long clip] index mismatches vs oracle: {n_bad}/{ind_ref['indices'].numel()}")
     assert ok and n_bad <= 1  # observed: 0
     wave = codec.decode_audio(indices=ind_ref["indices"].cuda())
-    assert _err("long clip wave", wave, O.decode_audio(w, mc, indices=ind_ref["indices"])) < WAVE_ATOL
+    assert _err("long clip wave", wave, O.decode_audio(w, mc, indices=ind_ref["indices"])) < WAVE_ATOL_LONG
 
 
 def test_weights_from_disk_and_example_flow(tmp_path):
@@ -543,7 +554,7 @@ def test_long_audio_chunker():
                                  audio_length=audio.shape[1])
         ref = CO.decode_unit(w, mc, ri)[:, :audio.shape[1]]
         assert wave.shape == (1, audio.shape[1])
-        assert _err(f"chunked wave w={window} p={prefix}", wave, ref) < WAVE_ATOL
+        assert _err(f"chunked wave w={window} p={prefix}", wave, ref) < WAVE_ATOL_LONG
         # from q_feature chunks == from index chunks, bit for bit
         assert torch.equal(codec.decode_unit(chunk_q_feature=cq), codec.decode_unit(chunk_indices=ci))
     # one window covers the clip: identical to the plain call
