@@ -245,6 +245,8 @@ int l3ac_ctx_set_gemm_split(l3ac_ctx* ctx, int32_t enable);
  * fused kernel takes the ConvUnits with C <= 96 on the split route: 0 = conv_unit_split_kernel (32 frames per wave) everywhere,
  * 1 (default) = conv_unit_ring_kernel (16 frames per wave, weights through an LDS-DMA ring) at the widths where it is the faster
  * one (C = 48, 96), 2 = wherever it exists (C = 24 too).  Both evaluate the same operations; their results agree to rounding.
+ * "ring_geometry" (diagnostics) runs conv_unit_ring_kernel in another geometry with the same results: 0 default, 1 other waves x
+ * workgroups, 5 32 frames per wave, 8 fragments read one piece ahead.
  * Unknown names return L3AC_EINVAL. */
 int l3ac_ctx_set_option(l3ac_ctx* ctx, const char* name, int32_t value);
 int32_t l3ac_ctx_get_gemm_split(const l3ac_ctx* ctx);

@@ -125,6 +125,8 @@ int l3ac_create(const l3ac_config* cfg, const l3ac_tensor* tensors, int32_t n_te
     {
         const char* e = std::getenv("L3AC_NARROW_RING");
         if (e) ctx->narrow_ring = std::atoi(e);
+        e = std::getenv("L3AC_RING_VARIANT");
+        if (e) ctx->ring_geometry = std::atoi(e);
     }
     DeviceGuard guard(device);
     int rc = guard.ok ? network_build(ctx, tensors, n_tensors) : L3AC_EHIP;
@@ -532,8 +534,9 @@ int l3ac_ctx_set_option(l3ac_ctx* ctx, const char* name, int32_t value) {
     if (n == "gemm_split") ctx->gemm_split = value != 0;
     else if (n == "head_pretanh") ctx->head_pretanh = value != 0;
     else if (n == "narrow_ring") ctx->narrow_ring = value < 0 ? 0 : (value > 2 ? 2 : value);
+    else if (n == "ring_geometry") ctx->ring_geometry = value;
     else {
-        l3ac_set_error("set_option: unknown option '%s' (gemm_split, head_pretanh, narrow_ring)", name);
+        l3ac_set_error("set_option: unknown option '%s' (gemm_split, head_pretanh, narrow_ring, ring_geometry)", name);
         return L3AC_EINVAL;
     }
     return L3AC_OK;

@@ -32,11 +32,30 @@
 
 namespace {
 
+// Timing-only builds (results wrong; never in the product library): -DL3AC_RING_BOUND=<bits> removes one cost at a time —
+//   1 the matrix products (a 3-instruction stand-in keeps every fragment read alive)   2 snake + GRN   4 the operand split of the hidden pair
+//   8 the depth-wise conv's loads and FMAs   16 the weight stream's LDS-DMA and the slot barriers   32 the fragment reads from LDS
+#ifndef L3AC_RING_BOUND
+#define L3AC_RING_BOUND 0
+#endif
+__device__ __forceinline__ f32x4_t ring_mfma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4_t acc) {
+    if constexpr ((L3AC_RING_BOUND & 1) != 0) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) acc[pl] += __builtin_bit_cast(f32x4_t, a[pl])[pl] * __builtin_bit_cast(f32x4_t, b[pl])[0];
+        return acc;
+    } else {
+        return mfma6(a, b, acc);
+    }
+}
+
 // WAVES_ waves per workgroup, PER_CU workgroups per CU (register budget 512 / (WAVES_ PER_CU / 4) per lane), SP_ pieces per ring
 // slot, RSLOTS_ ring slots.  RESIDENT: the unit's whole stream fits LDS (C = 24: 36 KB, C = 48: 126 KB) — loaded once per
 // workgroup, then no DMA, no barrier: the waves run independently of each other.
-template <int C, int WAVES_, int PER_CU_, int SP_, int RSLOTS_, bool RESIDENT_>
+template <int C, int WAVES_, int PER_CU_, int SP_, int RSLOTS_, bool RESIDENT_, int FT_ = 1, bool PRE_ = false>
 struct RGeo {
+    static constexpr bool PRE = PRE_;              // the next piece's fragment is read from LDS in front of the current piece's products
+    static constexpr int FT = FT_;                 // 16-frame column tiles per wave: 2 = every weight fragment read from LDS feeds 12 MFMAs
+    static constexpr int TF = 16 * FT_;            // frames per wave tile
     static constexpr int CT = (C + 15) / 16;       // accumulator tiles of the C channels
     static constexpr int K1 = (C + 31) / 32;       // k steps of the first product
     static constexpr int RT = CT;                  // output row tiles of the second product
@@ -100,7 +119,7 @@ __global__ __launch_bounds__(64 * G::WAVES, G::WAVES * G::PER_CU / 4) void conv_
     int dma_slot = 0;  // slot of the unit's stream to fetch next, modulo the stream length (wave-uniform)
     int ring_pos_w = 0;
     auto issue = [&]() __attribute__((always_inline)) {
-        if constexpr (!G::RESIDENT) {
+        if constexpr (!G::RESIDENT && (L3AC_RING_BOUND & 16) == 0) {
             if (wave < G::DMA_WAVES) {
                 const unsigned char* src = w.ring_img + (int64_t)dma_slot * G::SLOT + 1024 * wave;
                 const unsigned dst = ring_lds + (unsigned)(ring_pos_w * G::SLOT + 1024 * wave);
@@ -112,7 +131,7 @@ __global__ __launch_bounds__(64 * G::WAVES, G::WAVES * G::PER_CU / 4) void conv_
         }
     };
     auto step_sync = [&]() __attribute__((always_inline)) {
-        if constexpr (!G::RESIDENT) {
+        if constexpr (!G::RESIDENT && (L3AC_RING_BOUND & 16) == 0) {
             asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(G::WAIT) : "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -131,8 +150,21 @@ __global__ __launch_bounds__(64 * G::WAVES, G::WAVES * G::PER_CU / 4) void conv_
     const unsigned char* const ring_lane = smem_ring + 16 * lane;
     auto load_frag = [&](bf16x8 (&f)[3], const unsigned char* a) __attribute__((always_inline)) {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) f[pl] = *reinterpret_cast<const bf16x8*>(a + 1024 * pl);
+        for (int pl = 0; pl < 3; ++pl) {
+            if constexpr ((L3AC_RING_BOUND & 32) != 0)
+                f[pl] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)(size_t)a, (unsigned)pl, 3u, 4u});
+            else
+                f[pl] = *reinterpret_cast<const bf16x8*>(a + 1024 * pl);
+        }
     };
+    // PRE: the fragment of the piece about to be consumed, read one piece ahead (carried across hidden pairs and tiles: the stream
+    // wraps around).  A slot's barrier then sits in front of its LAST piece's products: that piece's fragment is in registers by
+    // then (the lgkmcnt(0) of step_sync), and the next slot must have landed for the read-ahead.
+    bf16x8 fcur[3];
+    if constexpr (G::PRE) {
+        issue();
+        load_frag(fcur, ring_lane);
+    }
 
     const int tile_stride = (int)gridDim.x * G::WAVES;
     // ring: every wave of the workgroup runs the same number of passes (slot barriers inside); resident: a wave stops after its last tile
@@ -141,130 +173,188 @@ __global__ __launch_bounds__(64 * G::WAVES, G::WAVES * G::PER_CU / 4) void conv_
         const bool tile_ok = tile < n_tiles;
         if (G::RESIDENT && !tile_ok) break;
         const int clip = tile_ok ? tile / tiles_per_clip : 0;
-        const int t0 = tile_ok ? (tile - clip * tiles_per_clip) * 16 : 0;
-        const int frame = t0 + fl;                       // this lane's frame inside its clip
-        const bool frame_ok = tile_ok && frame < frames;
+        const int t0 = tile_ok ? (tile - clip * tiles_per_clip) * G::TF : 0;
         const float* const xc = x + (int64_t)clip * frames * C + 4 * lg;  // (32-bit offsets inside a clip: frames * C < 2^31 / 4)
-        // ---- depth-wise conv k7 (zero padding at the clip's ends) + LayerNorm of this lane's frame: channels 16 t + 4 g + i ----
-        f32x4_t a[G::CT];
-        float s1 = 0.f;
+        bool frame_ok[G::FT];
+        bf16x8 ap[G::FT][G::K1][3];
 #pragma unroll
-        for (int t = 0; t < G::CT; ++t) {
-            const bool ch_ok = 16 * t + 4 * lg < C;  // (C = 24: the upper half of tile 1 is padding)
-            const int ch_off = ch_ok ? 16 * t : 0;    // padding lanes re-read tile 0 (their weights are zero)
-            f32x4_t acc = *reinterpret_cast<const f32x4_t*>(DWs + 7 * G::CP + 16 * t + 4 * lg);
-            f32x4_t xv[7];
-            // every load is unconditional on a clamped address and masked afterwards: a guarded load is a branch and a full
-            // wait each (the first build: 42 branches per tile, the whole front end serialised and 250 registers spilled)
+        for (int ft = 0; ft < G::FT; ++ft) {
+            const int frame = t0 + 16 * ft + fl;             // this lane's frame (of column tile ft) inside its clip
+            frame_ok[ft] = tile_ok && frame < frames;
+            // ---- depth-wise conv k7 (zero padding at the clip's ends) + LayerNorm of this lane's frame: channels 16 t + 4 g + i ----
+            f32x4_t a[G::CT];
+            float s1 = 0.f;
 #pragma unroll
-            for (int tap = 0; tap < 7; ++tap) {
-                const int frc = min(max(frame + tap - 3, 0), frames - 1);
-                xv[tap] = *reinterpret_cast<const f32x4_t*>(xc + (unsigned)(frc * C + ch_off));
-            }
+            for (int t = 0; t < G::CT; ++t) {
+                const bool ch_ok = 16 * t + 4 * lg < C;  // (C = 24: the upper half of tile 1 is padding)
+                const int ch_off = ch_ok ? 16 * t : 0;    // padding lanes re-read tile 0 (their weights are zero)
+                f32x4_t acc = *reinterpret_cast<const f32x4_t*>(DWs + 7 * G::CP + 16 * t + 4 * lg);
+                f32x4_t xv[7];
+                // every load is unconditional on a clamped address and masked afterwards: a guarded load is a branch and a full
+                // wait each (the first build: 42 branches per tile, the whole front end serialised and 250 registers spilled)
 #pragma unroll
-            for (int tap = 0; tap < 7; ++tap) {
-                const int fr = frame + tap - 3;
-                const bool ok = frame_ok && fr >= 0 && fr < frames;
-                const f32x4_t wv = *reinterpret_cast<const f32x4_t*>(DWs + tap * G::CP + 16 * t + 4 * lg);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = fmaf(ok ? xv[tap][i] : 0.f, wv[i], acc[i]);
-            }
-            a[t] = acc;
-            s1 += (acc[0] + acc[1]) + (acc[2] + acc[3]);
-            // one channel tile's 7 taps in flight at a time: nothing may be hoisted across (hipcc otherwise clusters all 7 CT loads at
-            // the top of the tile and spills them)
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        s1 = rows_sum(s1);
-        const float mean = s1 / (float)C;
-        float s2 = 0.f;
-#pragma unroll
-        for (int t = 0; t < G::CT; ++t)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float d = (16 * t + 4 * lg + i < C) ? a[t][i] - mean : 0.f;
-                s2 = fmaf(d, d, s2);
-            }
-        s2 = rows_sum(s2);
-        const float rstd = 1.0f / sqrtf(s2 / (float)C + 1e-8f);
-        bf16x8 ap[G::K1][3];
-#pragma unroll
-        for (int s = 0; s < G::K1; ++s) {
-            f32x4_t v[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int t = 2 * s + u;
-                v[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                if (t < G::CT) {
-                    const f32x4_t lw = *reinterpret_cast<const f32x4_t*>(DWs + 8 * G::CP + 16 * t + 4 * lg);  // (zeros in the padding)
-                    const f32x4_t lb = *reinterpret_cast<const f32x4_t*>(DWs + 9 * G::CP + 16 * t + 4 * lg);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[u][i] = frame_ok ? (a[t][i] - mean) * rstd * lw[i] + lb[i] : 0.f;
+                for (int tap = 0; tap < ((L3AC_RING_BOUND & 8) != 0 ? 1 : 7); ++tap) {
+                    const int frc = min(max(frame + tap - 3, 0), frames - 1);
+                    xv[tap] = *reinterpret_cast<const f32x4_t*>(xc + (unsigned)(frc * C + ch_off));
                 }
+#pragma unroll
+                for (int tap = 0; tap < ((L3AC_RING_BOUND & 8) != 0 ? 1 : 7); ++tap) {
+                    const int fr = frame + tap - 3;
+                    const bool ok = frame_ok[ft] && fr >= 0 && fr < frames;
+                    const f32x4_t wv = *reinterpret_cast<const f32x4_t*>(DWs + tap * G::CP + 16 * t + 4 * lg);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] = fmaf(ok ? xv[tap][i] : 0.f, wv[i], acc[i]);
+                }
+                a[t] = acc;
+                s1 += (acc[0] + acc[1]) + (acc[2] + acc[3]);
+                // one channel tile's 7 taps in flight at a time: nothing may be hoisted across (hipcc otherwise clusters all 7 CT loads
+                // at the top of the tile and spills them)
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
             }
-            planes_of(v[0], v[1], ap[s]);
+            s1 = rows_sum(s1);
+            const float mean = s1 / (float)C;
+            float s2 = 0.f;
+#pragma unroll
+            for (int t = 0; t < G::CT; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float d = (16 * t + 4 * lg + i < C) ? a[t][i] - mean : 0.f;
+                    s2 = fmaf(d, d, s2);
+                }
+            s2 = rows_sum(s2);
+            const float rstd = 1.0f / sqrtf(s2 / (float)C + 1e-8f);
+#pragma unroll
+            for (int s = 0; s < G::K1; ++s) {
+                f32x4_t v[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int t = 2 * s + u;
+                    v[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                    if (t < G::CT) {
+                        const f32x4_t lw = *reinterpret_cast<const f32x4_t*>(DWs + 8 * G::CP + 16 * t + 4 * lg);  // (zeros in the padding)
+                        const f32x4_t lb = *reinterpret_cast<const f32x4_t*>(DWs + 9 * G::CP + 16 * t + 4 * lg);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[u][i] = frame_ok[ft] ? (a[t][i] - mean) * rstd * lw[i] + lb[i] : 0.f;
+                    }
+                }
+                planes_of(v[0], v[1], ap[ft][s]);
+            }
         }
         // ---- output accumulators start at the pw_conv2 bias ------------------------------------------------------------------
-        f32x4_t yacc[G::RT];
+        f32x4_t yacc[G::FT][G::RT];
 #pragma unroll
-        for (int rt = 0; rt < G::RT; ++rt) yacc[rt] = *reinterpret_cast<const f32x4_t*>(B2s + 16 * rt + 4 * lg);
+        for (int rt = 0; rt < G::RT; ++rt) {
+            const f32x4_t b2v = *reinterpret_cast<const f32x4_t*>(B2s + 16 * rt + 4 * lg);
+#pragma unroll
+            for (int ft = 0; ft < G::FT; ++ft) yacc[ft][rt] = b2v;
+        }
 
 #pragma unroll 1
         for (int hp = 0; hp < G::NT; ++hp) {
-            f32x4_t hx[2];  // hidden channels 32 hp + 16 u + 4 g + i of this lane's frame, starting at the pw_conv1 bias
+            f32x4_t hx[G::FT][2];  // hidden channels 32 hp + 16 u + 4 g + i of this lane's frames, starting at the pw_conv1 bias
 #pragma unroll
-            for (int u = 0; u < 2; ++u) hx[u] = *reinterpret_cast<const f32x4_t*>(B1s + 32 * hp + 16 * u + 4 * lg);
-            bf16x8 hb[3];
-            const unsigned char* slot_a = nullptr;
+            for (int u = 0; u < 2; ++u) {
+                const f32x4_t b1v = *reinterpret_cast<const f32x4_t*>(B1s + 32 * hp + 16 * u + 4 * lg);
+#pragma unroll
+                for (int ft = 0; ft < G::FT; ++ft) hx[ft][u] = b1v;
+            }
+            bf16x8 hb[G::FT][3];
+            const unsigned char* slot_a = ring_lane + (G::RESIDENT ? hp : ring_pos_r) * G::SLOT;  // (PRE: the slot of piece 0)
             bf16x8 f[3];
-            ring_static_for<G::PP>([&](auto q_) {
+            auto products = [&](auto q_, const bf16x8 (&fr)[3]) __attribute__((always_inline)) {
                 constexpr int q = decltype(q_)::value;
-                if constexpr (q % G::SP == 0) {  // a slot step begins: refill the slot consumed one step ago
-                    issue();
-                    slot_a = ring_lane + (G::RESIDENT ? hp : ring_pos_r) * G::SLOT;
-                }
-                load_frag(f, slot_a + (q % G::SP) * 3072);
                 if constexpr (q < 2 * G::K1) {
-                    hx[q / G::K1] = mfma6(f, ap[q % G::K1], hx[q / G::K1]);
+#pragma unroll
+                    for (int ft = 0; ft < G::FT; ++ft) hx[ft][q / G::K1] = ring_mfma6(fr, ap[ft][q % G::K1], hx[ft][q / G::K1]);
                     if constexpr (q == 2 * G::K1 - 1) {
                         // snake + GRN (normaliser 1) on the accumulator registers (layers.py:29-33, :112-115), then the planes
-                        f32x4_t o[2];
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            const float* pp = Ps + 32 * hp + 16 * u + 4 * lg;
-                            const f32x4_t al = *reinterpret_cast<const f32x4_t*>(pp);
-                            const f32x4_t ia = *reinterpret_cast<const f32x4_t*>(pp + G::H4);
-                            const f32x4_t ga = *reinterpret_cast<const f32x4_t*>(pp + 2 * G::H4);
-                            const f32x4_t be = *reinterpret_cast<const f32x4_t*>(pp + 3 * G::H4);
+                        for (int ft = 0; ft < G::FT; ++ft) {
+                            f32x4_t o[2];
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const float sv = snake_act(hx[u][i], al[i], ia[i]);
-                                o[u][i] = fmaf(ga[i], sv, be[i]) + sv;
+                            for (int u = 0; u < 2; ++u) {
+                                const float* pp = Ps + 32 * hp + 16 * u + 4 * lg;
+                                const f32x4_t al = *reinterpret_cast<const f32x4_t*>(pp);
+                                const f32x4_t ia = *reinterpret_cast<const f32x4_t*>(pp + G::H4);
+                                const f32x4_t ga = *reinterpret_cast<const f32x4_t*>(pp + 2 * G::H4);
+                                const f32x4_t be = *reinterpret_cast<const f32x4_t*>(pp + 3 * G::H4);
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    if constexpr ((L3AC_RING_BOUND & 2) != 0) {
+                                        o[u][i] = hx[ft][u][i] + al[i] + ia[i] + ga[i] + be[i];
+                                    } else {
+                                        const float sv = snake_act(hx[ft][u][i], al[i], ia[i]);
+                                        o[u][i] = fmaf(ga[i], sv, be[i]) + sv;
+                                    }
+                                }
+                            }
+                            if constexpr ((L3AC_RING_BOUND & 4) != 0) {
+#pragma unroll
+                                for (int pl = 0; pl < 3; ++pl) hb[ft][pl] = __builtin_bit_cast(bf16x8, pl == 2 ? o[0] + o[1] : o[pl]);
+                            } else {
+                                planes_of(o[0], o[1], hb[ft]);
                             }
                         }
-                        planes_of(o[0], o[1], hb);
                     }
                 } else {
                     constexpr int rt = q - 2 * G::K1;
-                    yacc[rt] = mfma6(f, hb, yacc[rt]);
+#pragma unroll
+                    for (int ft = 0; ft < G::FT; ++ft) yacc[ft][rt] = ring_mfma6(fr, hb[ft], yacc[ft][rt]);
                 }
-                if constexpr ((q + 1) % G::SP == 0) {
-                    ring_pos_r = ring_pos_r + 1 == G::RSLOTS ? 0 : ring_pos_r + 1;
-                    step_sync();
+            };
+            ring_static_for<G::PP>([&](auto q_) {
+                constexpr int q = decltype(q_)::value;
+                if constexpr (G::PRE) {
+                    bf16x8 fnext[3];
+                    if constexpr ((q + 1) % G::SP == 0) {  // the slot's last piece: the next fragment comes from the next slot
+                        if constexpr (G::RESIDENT) {
+                            slot_a = ring_lane + (hp + 1 == G::NT ? 0 : hp + 1) * G::SLOT;
+                        } else {
+                            ring_pos_r = ring_pos_r + 1 == G::RSLOTS ? 0 : ring_pos_r + 1;
+                            step_sync();  // every wave holds its last fragment of this slot; the next slot has landed
+                            issue();      // refill the slot just released
+                            slot_a = ring_lane + ring_pos_r * G::SLOT;
+                        }
+                        load_frag(fnext, slot_a);
+                    } else {
+                        load_frag(fnext, slot_a + ((q + 1) % G::SP) * 3072);
+                    }
+                    products(q_, fcur);
+                    if constexpr (q != 2 * G::K1 - 1) {  // (not around the activation: its parameter reads are LDS reads too)
+                        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);           // the read-ahead ...
+                        __builtin_amdgcn_sched_group_barrier(0x008, 6 * G::FT, 0);   // ... in front of this piece's products
+                    }
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) fcur[pl] = fnext[pl];
+                } else {
+                    if constexpr (q % G::SP == 0) {  // a slot step begins: refill the slot consumed one step ago
+                        issue();
+                        slot_a = ring_lane + (G::RESIDENT ? hp : ring_pos_r) * G::SLOT;
+                    }
+                    load_frag(f, slot_a + (q % G::SP) * 3072);
+                    products(q_, f);
+                    if constexpr ((q + 1) % G::SP == 0) {
+                        ring_pos_r = ring_pos_r + 1 == G::RSLOTS ? 0 : ring_pos_r + 1;
+                        step_sync();
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);  // one fragment live at a time (left alone the scheduler front-loads a slot's reads: 250 spills)
             });
         }
         // ---- residual + store --------------------------------------------------------------------------------------------------
-        if (frame_ok) {
-            const float* xrow = xc + (int64_t)frame * C;
-            float* yrow = y + ((int64_t)clip * frames + frame) * C + 4 * lg;
 #pragma unroll
-            for (int rt = 0; rt < G::RT; ++rt) {
-                if (16 * rt + 4 * lg < C) {
-                    const f32x4_t xv = *reinterpret_cast<const f32x4_t*>(xrow + 16 * rt);
-                    *reinterpret_cast<f32x4_t*>(yrow + 16 * rt) = xv + yacc[rt];
+        for (int ft = 0; ft < G::FT; ++ft) {
+            const int frame = t0 + 16 * ft + fl;
+            if (frame_ok[ft]) {
+                const float* xrow = xc + (int64_t)frame * C;
+                float* yrow = y + ((int64_t)clip * frames + frame) * C + 4 * lg;
+#pragma unroll
+                for (int rt = 0; rt < G::RT; ++rt) {
+                    if (16 * rt + 4 * lg < C) {
+                        const f32x4_t xv = *reinterpret_cast<const f32x4_t*>(xrow + 16 * rt);
+                        *reinterpret_cast<f32x4_t*>(yrow + 16 * rt) = xv + yacc[ft][rt];
+                    }
                 }
             }
         }
@@ -279,7 +369,7 @@ int launch_ring(hipStream_t s, const ConvUnitW& w, const float* x, float* y, int
         L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_unit_ring_kernel<G, C>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
         configured.done();
     }
-    const int tiles_per_clip = (frames + 15) / 16;
+    const int tiles_per_clip = (frames + G::TF - 1) / G::TF;
     const int64_t tiles = (int64_t)batch * tiles_per_clip;
     L3AC_REQUIRE(tiles < ((int64_t)1 << 31) - 65536, "conv_unit_ring: too many tiles");
     int64_t blocks = ceil_div64(tiles, G::WAVES);
@@ -300,29 +390,38 @@ bool conv_unit_ring_supported(int c) { return c == 24 || c == 48 || c == 96; }
 bool conv_unit_ring_preferred(int c) { return c == 48 || c == 96; }
 
 // x must not alias y (neighbouring tiles read each other's halo frames)
-int launch_conv_unit_ring(hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames) {
+int launch_conv_unit_ring(hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames, int variant) {
     L3AC_REQUIRE(x != y && w.ring_img && batch > 0 && frames > 0, "conv_unit_ring: bad arguments");
-    static const int variant = [] {  // experiments: L3AC_RING_VARIANT selects another geometry of the same kernel (same results)
-        const char* e = std::getenv("L3AC_RING_VARIANT");
-        return e ? std::atoi(e) : 0;
-    }();
-    // Geometries measured on the 256-clip step (gpurun_out/r03e, r03f; ms for the stage's launches, conv_unit_split_kernel beside):
-    //   C = 96 (3 launches)  split 1.72 | ring 8 waves x 2, slots of 4 / 6 pieces: 1.55 / 1.54 | 16 waves x 1, slots of 6 / 12: 1.76 / 1.67
-    //   C = 48 (2 launches)  split 0.89 | resident 16 x 1: 0.83, 12 x 1: 0.88 | ring 8 x 2, slots of 7: 0.93
-    //   C = 24 (1 launch)    split 0.46 | resident 12 x 1: 0.58, 6 x 2: 0.79-0.81 — the 16-frame form reads every weight fragment
-    //                        from LDS twice as often per frame as the 32-frame split kernel and loses at this width: not routed here
+    // variant (context option "ring_geometry", diagnostics and tests): another geometry of the same kernel, same results —
+    // 1 other waves x workgroups, 5 32 frames per wave (FT = 2), 8 fragments read one piece ahead (PRE); anything else: the default
+    // Geometries measured on the 256-clip step (profiles/r03/README.md; ms for the stage's launches, conv_unit_split_kernel beside):
+    //   C = 96 (3 launches)  split 1.72 | ring 8 waves x 2 workgroups, slots of 4 / 6 pieces: 1.55 / 1.50-1.54 | 16 x 1: 1.67-1.76 | 4 x 4: 1.48
+    //                        | 32 frames per wave (FT = 2), 4 x 2: 1.53-1.57, 8 x 1: 1.73-1.81 | read-ahead (PRE), 6 x 2: 1.97, FT = 2 4 x 2: 1.47
+    //   C = 48 (2 launches)  split 0.89 | resident 16 x 1: 0.83-0.85, 12 x 1: 0.88 | ring 8 x 2: 0.93 | FT = 2, 8 / 12 x 1: 0.94 / 0.90
+    //                        | PRE 16 x 1: 0.84, 12 x 1: 0.87
+    //   C = 24 (1 launch)    split 0.46-0.48 | resident 12 x 1: 0.57-0.59, 6 x 2: 0.79-0.81 | FT = 2, 16 x 1: 0.55 | PRE 16 x 1: 0.54: not routed here
+    // Neither 32 frames per wave (half the fragment reads per frame) nor reading one fragment ahead moves the time: the kernel is
+    // not bound by the LDS reads.  What bounds it, from timing-only builds (L3AC_RING_BOUND above, C = 96, 1.50 ms): without the
+    // products 1.04; without snake / GRN / split / conv taps 0.99; with neither 0.70; also without the weight stream and its barriers
+    // 0.53, also without the fragment reads 0.37 (one read of x, LayerNorm, one write of y).  The parts add up to 1.78: little of
+    // the vector work (VALU active 0.46 of the cycles at C = 96, 0.74 at C = 48) hides under the products (matrix pipe 0.38 / 0.37),
+    // and at C <= 48 the vector work — 20 instructions of activation and 5.5 of operand split per hidden element — is the larger
+    // of the two: these widths are bound by vector issue, not by the matrix pipe.
     switch (w.c) {
         case 24:
             if (variant == 1) return launch_ring<RGeo<24, 6, 2, 0, 0, true>, 24>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<24>");
+            if (variant == 5) return launch_ring<RGeo<24, 16, 1, 0, 0, true, 2>, 24>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<24>");
+            if (variant == 8) return launch_ring<RGeo<24, 16, 1, 0, 0, true, 1, true>, 24>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<24>");
             return launch_ring<RGeo<24, 12, 1, 0, 0, true>, 24>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<24>");
         case 48:  // 126 KB stream: resident, one workgroup of 16 waves per CU, no barrier after the prologue
             if (variant == 1) return launch_ring<RGeo<48, 8, 2, 7, 3, false>, 48>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<48>");
-            if (variant == 2) return launch_ring<RGeo<48, 12, 1, 0, 0, true>, 48>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<48>");
+            if (variant == 5) return launch_ring<RGeo<48, 12, 1, 0, 0, true, 2>, 48>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<48>");
+            if (variant == 8) return launch_ring<RGeo<48, 16, 1, 0, 0, true, 1, true>, 48>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<48>");
             return launch_ring<RGeo<48, 16, 1, 0, 0, true>, 48>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<48>");
         case 96:  // 432 KB stream: ring of 3 slots of 6 pieces, two workgroups of 8 waves per CU
-            if (variant == 1) return launch_ring<RGeo<96, 8, 2, 4, 4, false>, 96>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<96>");
-            if (variant == 3) return launch_ring<RGeo<96, 16, 1, 6, 4, false>, 96>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<96>");
-            if (variant == 4) return launch_ring<RGeo<96, 16, 1, 12, 3, false>, 96>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<96>");
+            if (variant == 1) return launch_ring<RGeo<96, 4, 4, 3, 3, false>, 96>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<96>");
+            if (variant == 5) return launch_ring<RGeo<96, 4, 2, 6, 3, false, 2>, 96>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<96>");
+            if (variant == 8) return launch_ring<RGeo<96, 4, 2, 6, 3, false, 2, true>, 96>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<96>");
             return launch_ring<RGeo<96, 8, 2, 6, 3, false>, 96>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<96>");
         default:
             l3ac_set_error("conv_unit_ring: C=%d not supported", w.c);

@@ -611,7 +611,7 @@ int conv_unit_step(l3ac_ctx* ctx, hipStream_t s, const ConvUnitW& w, float** cur
         return L3AC_OK;
     }
     if (!ctx->cfg.grn_exact && conv_unit_fused_supported(w.c)) {
-        L3AC_TRY(launch_conv_unit_fused(s, w, *cur, *alt, batch, frames, ctx->gemm_split, ctx->narrow_ring));
+        L3AC_TRY(launch_conv_unit_fused(s, w, *cur, *alt, batch, frames, ctx->gemm_split, ctx->narrow_ring, ctx->ring_geometry));
         float* t = *cur;
         *cur = *alt;
         *alt = t;
@@ -666,7 +666,7 @@ int run_conv_units(l3ac_ctx* ctx, hipStream_t s, const std::vector<ConvUnitW>& u
 int run_conv_unit(l3ac_ctx* ctx, hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames) {
     if (x != y && use_wide(ctx, w))
         return launch_conv_unit_wide(s, w, x, y, reinterpret_cast<unsigned char*>(ctx->ws.h), ctx->ws.h_cap * sizeof(float), batch, frames);
-    if (!ctx->cfg.grn_exact && x != y && conv_unit_fused_supported(w.c)) return launch_conv_unit_fused(s, w, x, y, batch, frames, ctx->gemm_split, ctx->narrow_ring);
+    if (!ctx->cfg.grn_exact && x != y && conv_unit_fused_supported(w.c)) return launch_conv_unit_fused(s, w, x, y, batch, frames, ctx->gemm_split, ctx->narrow_ring, ctx->ring_geometry);
     const int group = conv_unit_group(ctx, w, batch, frames);
     for (int b0 = 0; b0 < batch; b0 += group) {
         const int nb = std::min(group, batch - b0);

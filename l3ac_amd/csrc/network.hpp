@@ -82,6 +82,7 @@ struct l3ac_ctx {
     // which fused kernel takes the narrow ConvUnits (C <= 96) on the split route: conv_unit_ring_kernel (16 frames per wave, LDS-DMA
     // weight ring) or conv_unit_split_kernel (32 frames per wave, chunk barriers); l3ac_ctx_set_option(ctx, "narrow_ring", 0 / 1)
     int narrow_ring = 1;  // 0: conv_unit_split_kernel everywhere, 1: the ring kernel where it is faster (C = 48, 96), 2: wherever it exists
+    int ring_geometry = 0;  // diagnostics (option "ring_geometry" / env L3AC_RING_VARIANT): another geometry of conv_unit_ring_kernel, same results
     const unsigned char* img(const float* w) const {  // null on the exact route: launch_gemm then takes the fp32 kernel
         if (!gemm_split) return nullptr;
         auto it = split_img.find(w);
@@ -129,11 +130,11 @@ int workspace_ensure_clip(l3ac_ctx* ctx, int batch, int samples, hipStream_t s);
 
 // fused ConvUnit for the narrow stages (kernels/conv_unit_fused.hip); x must not alias y
 bool conv_unit_fused_supported(int c);
-int launch_conv_unit_fused(hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames, bool split, int ring = 0);
+int launch_conv_unit_fused(hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames, bool split, int ring = 0, int ring_geometry = 0);
 // third form of the narrow ConvUnit (kernels/conv_unit_ring.hip): 16 frames per wave, weights through an LDS-DMA ring
 bool conv_unit_ring_supported(int c);
 bool conv_unit_ring_preferred(int c);  // the widths the pipeline routes there by default
-int launch_conv_unit_ring(hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames);
+int launch_conv_unit_ring(hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames, int geometry);
 std::vector<unsigned char> conv_unit_ring_image(const float* w1, const float* w2, int c);  // w1 [4c][c], w2 [c][4c]
 // bf16x3 variant (kernels/conv_unit_split.hip), chosen by launch_conv_unit_fused when the images exist and the split route is on
 int launch_conv_unit_split(hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames);

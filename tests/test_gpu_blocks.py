@@ -217,6 +217,17 @@ def test_conv_units_narrow_ring_and_split_forms(full):
         d = float((outs["ring"] - outs["split"]).abs().max())
         print(f"[ring vs split {block} B={b} T={t}] max difference {d:.3e}")
         assert d < 5e-5
+        # the kernel's other geometries (other waves x workgroups, 32 frames per wave, fragments read one piece ahead) evaluate the
+        # same operations in the same order per frame: identical results
+        for geometry in (1, 5, 8):
+            ctx.set_option("narrow_ring", 2)
+            ctx.set_option("ring_geometry", geometry)
+            try:
+                alt = G.from_frames(G.op_block(ctx, "l3ac_op_conv_unit", block, G.to_frames(x), (b, t, c)))
+            finally:
+                ctx.set_option("narrow_ring", 1)
+                ctx.set_option("ring_geometry", 0)
+            assert torch.equal(alt, outs["ring"]), f"ring geometry {geometry} differs from the default on {block} B={b} T={t}"
     block, c = "decoder.blocks.7.0.module", 96
     x = _rand((2, c, 1000), 4242)
     ref64 = O.conv_unit({k: v.double() for k, v in w.items() if k.startswith(block)}, block, x.double())
