@@ -38,6 +38,17 @@ namespace {
 #ifndef L3AC_RING_BOUND
 #define L3AC_RING_BOUND 0
 #endif
+#ifdef L3AC_RING_STAMPS  // diagnostic build (tools/ring_stamps.py): s_memtime sums per phase of every wave of workgroup 0 (read the shares)
+__device__ long long g_ring_stamps[16 * 8];
+#define RING_STAMP(slot)                                                       \
+    do {                                                                       \
+        const long long now_ = (long long)__builtin_amdgcn_s_memtime();        \
+        stamp_sum[slot] += now_ - stamp_last;                                  \
+        stamp_last = now_;                                                     \
+    } while (0)
+#else
+#define RING_STAMP(slot) do { } while (0)
+#endif
 __device__ __forceinline__ f32x4_t ring_mfma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4_t acc) {
     if constexpr ((L3AC_RING_BOUND & 1) != 0) {
 #pragma unroll
@@ -93,6 +104,12 @@ __global__ __launch_bounds__(64 * G::WAVES, G::WAVES * G::PER_CU / 4) void conv_
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fl = lane & 15, lg = lane >> 4;
+#ifdef L3AC_RING_STAMPS
+    // slots: 0 tile front (dw-conv + LayerNorm + split)  1 fragment read -> landed  2 the six products (issue + completion)
+    //        3 snake / GRN / split  4 slot barrier  5 LDS-DMA issue  6 residual + store  7 other
+    long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long stamp_last = (long long)__builtin_amdgcn_s_memtime();
+#endif
 
     // ---- parameters resident for the lifetime of the workgroup (padding channels: zeros) ---------------------------------
     for (int i = tid; i < G::H4; i += 64 * G::WAVES) {
@@ -167,7 +184,6 @@ __global__ __launch_bounds__(64 * G::WAVES, G::WAVES * G::PER_CU / 4) void conv_
     }
 
     const int tile_stride = (int)gridDim.x * G::WAVES;
-    // ring: every wave of the workgroup runs the same number of passes (slot barriers inside); resident: a wave stops after its last tile
     for (int base = (int)blockIdx.x * G::WAVES; base < n_tiles; base += tile_stride) {
         const int tile = base + wave;
         const bool tile_ok = tile < n_tiles;
@@ -175,6 +191,7 @@ __global__ __launch_bounds__(64 * G::WAVES, G::WAVES * G::PER_CU / 4) void conv_
         const int clip = tile_ok ? tile / tiles_per_clip : 0;
         const int t0 = tile_ok ? (tile - clip * tiles_per_clip) * G::TF : 0;
         const float* const xc = x + (int64_t)clip * frames * C + 4 * lg;  // (32-bit offsets inside a clip: frames * C < 2^31 / 4)
+        RING_STAMP(7);
         bool frame_ok[G::FT];
         bf16x8 ap[G::FT][G::K1][3];
 #pragma unroll
@@ -207,6 +224,8 @@ __global__ __launch_bounds__(64 * G::WAVES, G::WAVES * G::PER_CU / 4) void conv_
                 }
                 a[t] = acc;
                 s1 += (acc[0] + acc[1]) + (acc[2] + acc[3]);
+                // (tried, no change in the kernel's time: the centre taps of all channel tiles loaded first — one trip to memory instead
+                // of CT — and a cache-line touch of the NEXT tile's rows by LDS-DMA three hidden pairs ahead)
                 // one channel tile's 7 taps in flight at a time: nothing may be hoisted across (hipcc otherwise clusters all 7 CT loads
                 // at the top of the tile and spills them)
                 asm volatile("" ::: "memory");
@@ -241,6 +260,10 @@ __global__ __launch_bounds__(64 * G::WAVES, G::WAVES * G::PER_CU / 4) void conv_
                 planes_of(v[0], v[1], ap[ft][s]);
             }
         }
+#ifdef L3AC_RING_STAMPS
+        asm volatile("" : "+v"(ap[0][0][0]), "+v"(ap[G::FT - 1][G::K1 - 1][2]));
+#endif
+        RING_STAMP(0);
         // ---- output accumulators start at the pw_conv2 bias ------------------------------------------------------------------
         f32x4_t yacc[G::FT][G::RT];
 #pragma unroll
@@ -267,6 +290,10 @@ __global__ __launch_bounds__(64 * G::WAVES, G::WAVES * G::PER_CU / 4) void conv_
                 if constexpr (q < 2 * G::K1) {
 #pragma unroll
                     for (int ft = 0; ft < G::FT; ++ft) hx[ft][q / G::K1] = ring_mfma6(fr, ap[ft][q % G::K1], hx[ft][q / G::K1]);
+#ifdef L3AC_RING_STAMPS
+                    (void)__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, hx[G::FT - 1][q / G::K1][0]));  // the products have completed
+                    RING_STAMP(2);
+#endif
                     if constexpr (q == 2 * G::K1 - 1) {
                         // snake + GRN (normaliser 1) on the accumulator registers (layers.py:29-33, :112-115), then the planes
 #pragma unroll
@@ -296,11 +323,19 @@ __global__ __launch_bounds__(64 * G::WAVES, G::WAVES * G::PER_CU / 4) void conv_
                                 planes_of(o[0], o[1], hb[ft]);
                             }
                         }
+#ifdef L3AC_RING_STAMPS
+                        asm volatile("" : "+v"(hb[0][0]), "+v"(hb[G::FT - 1][2]));
+                        RING_STAMP(3);
+#endif
                     }
                 } else {
                     constexpr int rt = q - 2 * G::K1;
 #pragma unroll
                     for (int ft = 0; ft < G::FT; ++ft) yacc[ft][rt] = ring_mfma6(fr, hb[ft], yacc[ft][rt]);
+#ifdef L3AC_RING_STAMPS
+                    (void)__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, yacc[G::FT - 1][rt][0]));
+                    RING_STAMP(2);
+#endif
                 }
             };
             ring_static_for<G::PP>([&](auto q_) {
@@ -329,19 +364,29 @@ __global__ __launch_bounds__(64 * G::WAVES, G::WAVES * G::PER_CU / 4) void conv_
                     for (int pl = 0; pl < 3; ++pl) fcur[pl] = fnext[pl];
                 } else {
                     if constexpr (q % G::SP == 0) {  // a slot step begins: refill the slot consumed one step ago
+                        RING_STAMP(7);
                         issue();
+                        RING_STAMP(5);
                         slot_a = ring_lane + (G::RESIDENT ? hp : ring_pos_r) * G::SLOT;
                     }
+                    RING_STAMP(7);
                     load_frag(f, slot_a + (q % G::SP) * 3072);
+#ifdef L3AC_RING_STAMPS
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]));
+                    RING_STAMP(1);
+#endif
                     products(q_, f);
                     if constexpr ((q + 1) % G::SP == 0) {
                         ring_pos_r = ring_pos_r + 1 == G::RSLOTS ? 0 : ring_pos_r + 1;
+                        RING_STAMP(7);
                         step_sync();
+                        RING_STAMP(4);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);  // one fragment live at a time (left alone the scheduler front-loads a slot's reads: 250 spills)
             });
         }
+        RING_STAMP(7);
         // ---- residual + store --------------------------------------------------------------------------------------------------
 #pragma unroll
         for (int ft = 0; ft < G::FT; ++ft) {
@@ -358,8 +403,15 @@ __global__ __launch_bounds__(64 * G::WAVES, G::WAVES * G::PER_CU / 4) void conv_
                 }
             }
         }
+        RING_STAMP(6);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // leave no LDS-DMA in flight behind the workgroup
+#ifdef L3AC_RING_STAMPS
+    if (blockIdx.x == 0 && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g_ring_stamps[8 * wave + i] += stamp_sum[i];
+    }
+#endif
 }
 
 template <class G, int C>
@@ -383,6 +435,17 @@ int launch_ring(hipStream_t s, const ConvUnitW& w, const float* x, float* y, int
 }
 
 }  // namespace
+
+#ifdef L3AC_RING_STAMPS
+extern "C" int l3ac_debug_ring_stamps(long long* out, int n, int reset) {  // diagnostic builds only (not part of the ABI)
+    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ring_stamps), (size_t)n * sizeof(long long));
+    if (reset) {
+        long long zero[16 * 8] = {};
+        rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ring_stamps), zero, sizeof(zero));
+    }
+    return rc;
+}
+#endif
 
 bool conv_unit_ring_supported(int c) { return c == 24 || c == 48 || c == 96; }
 // the widths the pipeline routes to this kernel by default (C = 24 stays on conv_unit_split_kernel, which is faster there — see the
@@ -419,7 +482,7 @@ int launch_conv_unit_ring(hipStream_t s, const ConvUnitW& w, const float* x, flo
             if (variant == 8) return launch_ring<RGeo<48, 16, 1, 0, 0, true, 1, true>, 48>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<48>");
             return launch_ring<RGeo<48, 16, 1, 0, 0, true>, 48>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<48>");
         case 96:  // 432 KB stream: ring of 3 slots of 6 pieces, two workgroups of 8 waves per CU
-            if (variant == 1) return launch_ring<RGeo<96, 4, 4, 3, 3, false>, 96>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<96>");
+            if (variant == 1) return launch_ring<RGeo<96, 4, 3, 3, 4, false>, 96>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<96>");
             if (variant == 5) return launch_ring<RGeo<96, 4, 2, 6, 3, false, 2>, 96>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<96>");
             if (variant == 8) return launch_ring<RGeo<96, 4, 2, 6, 3, false, 2, true>, 96>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<96>");
             return launch_ring<RGeo<96, 8, 2, 6, 3, false>, 96>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<96>");
