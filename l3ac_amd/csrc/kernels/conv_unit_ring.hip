@@ -35,6 +35,7 @@ namespace {
 // Timing-only builds (results wrong; never in the product library): -DL3AC_RING_BOUND=<bits> removes one cost at a time —
 //   1 the matrix products (a 3-instruction stand-in keeps every fragment read alive)   2 snake + GRN   4 the operand split of the hidden pair
 //   8 the depth-wise conv's loads and FMAs   16 the weight stream's LDS-DMA and the slot barriers   32 the fragment reads from LDS
+//   64 the whole tile front (no x read, no conv, no LayerNorm: operand planes from the lane id)   128 the residual read and the store
 #ifndef L3AC_RING_BOUND
 #define L3AC_RING_BOUND 0
 #endif
@@ -198,6 +199,13 @@ __global__ __launch_bounds__(64 * G::WAVES, G::WAVES * G::PER_CU / 4) void conv_
         for (int ft = 0; ft < G::FT; ++ft) {
             const int frame = t0 + 16 * ft + fl;             // this lane's frame (of column tile ft) inside its clip
             frame_ok[ft] = tile_ok && frame < frames;
+            if constexpr ((L3AC_RING_BOUND & 64) != 0) {
+#pragma unroll
+                for (int s = 0; s < G::K1; ++s)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) ap[ft][s][pl] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)frame, (unsigned)(s + pl), 0x3f803f80u, 0x3c003c00u});
+                continue;
+            }
             // ---- depth-wise conv k7 (zero padding at the clip's ends) + LayerNorm of this lane's frame: channels 16 t + 4 g + i ----
             f32x4_t a[G::CT];
             float s1 = 0.f;
@@ -391,6 +399,13 @@ __global__ __launch_bounds__(64 * G::WAVES, G::WAVES * G::PER_CU / 4) void conv_
 #pragma unroll
         for (int ft = 0; ft < G::FT; ++ft) {
             const int frame = t0 + 16 * ft + fl;
+            if constexpr ((L3AC_RING_BOUND & 128) != 0) {
+                float keep = 0.f;
+#pragma unroll
+                for (int rt = 0; rt < G::RT; ++rt) keep += yacc[ft][rt][0] + yacc[ft][rt][1] + yacc[ft][rt][2] + yacc[ft][rt][3];
+                if (keep == 12345.678f) y[frame] = keep;
+                continue;
+            }
             if (frame_ok[ft]) {
                 const float* xrow = xc + (int64_t)frame * C;
                 float* yrow = y + ((int64_t)clip * frames + frame) * C + 4 * lg;

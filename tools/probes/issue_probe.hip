@@ -34,6 +34,30 @@ __global__ __launch_bounds__(1024) void probe(float* out, int reps) {
     int piece = 0;
     auto mphase = [&]() __attribute__((always_inline)) {
         if (M > 0 && do_m) {
+            if (MODE == 4) {  // fragments read one group ahead
+                bf16x8 fc[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) fc[pl] = *reinterpret_cast<const bf16x8*>(lds + (piece % 36) * 3072 + 1024 * pl + 16 * (threadIdx.x & 63));
+#pragma unroll
+                for (int g = 0; g < M / 6; ++g) {
+                    bf16x8 fn[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) fn[pl] = *reinterpret_cast<const bf16x8*>(lds + ((piece + g + 1) % 36) * 3072 + 1024 * pl + 16 * (threadIdx.x & 63));
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[2], b, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[1], b, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[0], b, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[1], b, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[0], b, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[0], b, acc, 0, 0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) fc[pl] = fn[pl];
+                }
+                piece = (piece + M / 6) % 36;
+                return;
+            }
             if (MODE >= 3) {
 #pragma unroll
                 for (int g = 0; g < M / 6; ++g) {
@@ -99,6 +123,8 @@ int main() {
         run<72, 205, 2, false>("roles: half the waves 72 mfma16, half 205 valu", out, waves);
         run<72, 205, 3, false>("72 mfma16 (fragments from LDS, 3 reads per 6) + 205 valu", out, waves);
         run<72, 0, 3, false>("72 mfma16 (fragments from LDS) only", out, waves);
+        run<72, 205, 4, false>("72 mfma16 (fragments one group ahead) + 205 valu", out, waves);
+        run<72, 0, 4, false>("72 mfma16 (fragments one group ahead) only", out, waves);
         run<36, 0, 0, true>("36 mfma32 only", out, waves);
         run<36, 205, 0, true>("36 mfma32 + 205 valu, in phase", out, waves);
         run<36, 205, 1, true>("36 mfma32 + 205 valu, half out of phase", out, waves);
