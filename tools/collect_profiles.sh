@@ -16,15 +16,15 @@ R=$GRAFT_REPO_ROOT
 SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"
 for w in $WL; do
     case $w in
-        main)  P="$R/bench.py --steps 3 --warmup 1 --pipeline-only" ;;
-        3kbps) P="$R/bench.py --config 3kbps --steps 3 --warmup 1 --pipeline-only" ;;
-        b1)    P="$R/tools/b1_profile.py" ;;
-        vq)    P="$R/tools/vq_argmin_bench.py --quick" ;;
+        main)  P="$R/bench.py --steps 3 --warmup 1 --pipeline-only"; PT="$R/bench.py --steps 12 --warmup 3 --pipeline-only" ;;  # (the trace pass runs as many steps as a bench run: its averages then include the same warm state)
+        3kbps) P="$R/bench.py --config 3kbps --steps 3 --warmup 1 --pipeline-only"; PT="$R/bench.py --config 3kbps --steps 12 --warmup 3 --pipeline-only" ;;
+        b1)    P="$R/tools/b1_profile.py"; PT=$P ;;
+        vq)    P="$R/tools/vq_argmin_bench.py --quick"; PT=$P ;;
         *) echo "unknown workload $w"; continue ;;
     esac
     D=$OUT/$w
     mkdir -p $D
-    rocprofv3 --kernel-trace --stats --output-format csv -d $D/trace -- python3 $P > $D/trace_stdout.txt 2> $D/trace_err.txt
+    rocprofv3 --kernel-trace --stats --output-format csv -d $D/trace -- python3 $PT > $D/trace_stdout.txt 2> $D/trace_err.txt
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D/pmc_fetch -- python3 $P > /dev/null 2> $D/pmc_fetch_err.txt
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/pmc_write -- python3 $P > /dev/null 2> $D/pmc_write_err.txt
     rocprofv3 --pmc $SQ --output-format csv -d $D/pmc_sq -- python3 $P > /dev/null 2> $D/pmc_sq_err.txt
