@@ -616,3 +616,32 @@ def test_vq_argmin_graph_capture():
             graph.replay()
             torch.cuda.synchronize()
             assert torch.equal(out, eager[i]), f"n={n} set {i}"
+
+
+def test_context_options_by_name(full):
+    """l3ac_ctx_set_option: the route switches by name belong to ONE context, unknown names are refused (L3AC_EINVAL with a
+    message naming the options), out-of-range values of `narrow_ring` are clamped, and an unknown `ring_geometry` runs the default
+    geometry (same bits)."""
+    codec, mc, w = full
+    ctx = codec.network.context()
+    with pytest.raises(RuntimeError, match="unknown option"):
+        ctx.set_option("no_such_option", 1)
+    other = l3ac_amd.get_model("1kbps", synthetic_seed=0)
+    other.network.cuda().eval()
+    octx = other.network.context()
+    try:
+        ctx.set_option("gemm_split", 0)
+        assert ctx.get_gemm_split() is False and octx.get_gemm_split() is True  # another context is untouched
+    finally:
+        ctx.set_option("gemm_split", 1)
+    block, c, b, t = "decoder.blocks.7.0.module", 96, 3, 333
+    x = _rand((b, c, t), 77)
+    ref = G.from_frames(G.op_block(ctx, "l3ac_op_conv_unit", block, G.to_frames(x), (b, t, c)))
+    try:
+        ctx.set_option("narrow_ring", 99)     # clamped to 2: still the ring kernel at this width
+        ctx.set_option("ring_geometry", 12345)  # not a known geometry: the default one
+        got = G.from_frames(G.op_block(ctx, "l3ac_op_conv_unit", block, G.to_frames(x), (b, t, c)))
+    finally:
+        ctx.set_option("narrow_ring", 1)
+        ctx.set_option("ring_geometry", 0)
+    assert torch.equal(got, ref)
