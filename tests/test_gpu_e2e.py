@@ -669,3 +669,15 @@ def test_two_streams_alternate_on_one_context():
     torch.cuda.synchronize()
     for i, idx, wave in got:
         assert torch.equal(idx, ref[i][0]) and torch.equal(wave, ref[i][1]), f"clip set {i}"
+
+
+def test_graph_capture_in_a_cold_process():
+    """reserve -> capture with NO eager call before it, in a fresh process (in this one every kernel has long been configured):
+    the replayed graph returns the tokens and the waveform of the eager path."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    script = Path(__file__).resolve().parent / "capture_cold.py"
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "captured without warm-up; tokens equal True wave equal True" in r.stdout, r.stdout[-2000:]
