@@ -76,6 +76,8 @@ def test_submodules_against_oracle(tag, seed, batch, samples):
                                                     # ragged sizes: one sample, one short of / one past a hop, a tile-unfriendly length
                                                     ("1kbps", 0, 1, 1), ("1kbps", 0, 2, 269), ("1kbps", 0, 1, 271), ("1kbps", 0, 5, 8191),
                                                     ("3kbps", 0, 1, 97),
+                                                    # either side of the longest clip the one-workgroup transformer stack takes (192 frames)
+                                                    ("1kbps", 0, 2, 17280), ("1kbps", 0, 2, 17281), ("3kbps", 0, 2, 18432), ("3kbps", 0, 2, 18433),
                                                     # the reference's default geometry: 128-channel fused stage, 64 / 32-channel units
                                                     ("refdefault", 5, 3, 9000), ("refdefault", 5, 1, 46)])
 def test_encode_decode_against_oracle(tag, seed, batch, samples):
