@@ -46,10 +46,12 @@ def source_fingerprint():
     """sha256 over the kernel sources and headers: what a profiles/*/traffic.json must have been collected on to still
     describe this build (the .so itself is not hashed: it is rebuilt on other boxes)."""
     h = hashlib.sha256()
-    files = sorted((REPO / "l3ac_amd" / "csrc").rglob("*.h*")) + sorted((REPO / "include").glob("*.h"))
+    csrc = REPO / "l3ac_amd" / "csrc"
+    # sources only (*.hip, *.hpp, *.h), never a build directory of any tag (build/, build_<tag>/: their *.hip.o would match "*.h*")
+    files = sorted(f for f in csrc.rglob("*") if f.suffix in (".hip", ".hpp", ".h") and f.is_file()
+                   and not any(part.startswith("build") for part in f.relative_to(csrc).parts[:-1]))
+    files += sorted((REPO / "include").glob("*.h"))
     for f in files:
-        if "build" in f.parts:
-            continue
         h.update(f.name.encode())
         h.update(f.read_bytes())
     return h.hexdigest()[:16]

@@ -191,6 +191,20 @@ def test_traffic_summary_is_tied_to_the_kernel_sources(tmp_path):
     roof = {"kernel": "gemm_split_kernel"}
     bench.attach_traffic(roof, tmp_path, "3kbps b256 s16000 split")  # another workload: not attached at all
     assert roof["traffic"] is None and "traffic_stale" not in roof
+    # the fingerprint covers SOURCES only: objects of a tagged diagnostic build next to them (csrc/build_<tag>/*.hip.o travel to the
+    # GPU box with the tree) must not change it — they once did, and a profile collected beside such a directory went stale when it was removed
+    csrc = bench.REPO / "l3ac_amd" / "csrc"
+    before = bench.source_fingerprint()
+    stray = csrc / "build_fingerprint_test"
+    stray.mkdir(exist_ok=True)
+    try:
+        (stray / "kernels_x.hip.o").write_bytes(b"not a source")
+        (stray / "y.hpp").write_text("// inside a build directory")
+        assert bench.source_fingerprint() == before
+    finally:
+        for f in stray.iterdir():
+            f.unlink()
+        stray.rmdir()
 
 
 def test_chunk_bookkeeping_matches_the_reference_restatement():

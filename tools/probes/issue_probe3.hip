@@ -21,6 +21,23 @@ __device__ __forceinline__ float sin_squared_b(float u) {
     const float sign = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, t) << 31) | 0x3f800000u);
     return fmaf(sign, s2, fmaf(sign, -0.5f, 0.5f));
 }
+// the packed form's arithmetic (device_math.hpp sin_squared2 / snake_act2), one element at a time: the same operations in the same
+// order, so the same bits
+__device__ __forceinline__ float snake_cosform(float h, float alpha, float inv_alpha) {
+    float u = alpha * h;
+    u = __builtin_amdgcn_fmed3f(u, -SIN2_ARG_MAX, SIN2_ARG_MAX);
+    const float n = __builtin_rintf(u * 0.636619772367581343f);
+    float r = fmaf(n, -1.57079637050628662109375f, u);
+    r = fmaf(n, 4.37113900018624283e-8f, r);
+    const float z = r * r;
+    float p = fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+    p = fmaf(p, z, -1.6666654611e-1f);
+    const float s = fmaf(p * z, r, r);
+    const float c = fmaf(s * s, -2.0f, 1.0f);
+    const int cb = __builtin_bit_cast(int, c) ^ ((int)n << 31);
+    const float s2 = fmaf(__builtin_bit_cast(float, cb), -0.5f, 0.5f);
+    return fmaf(inv_alpha, s2, h);
+}
 template <int KIND>
 __global__ __launch_bounds__(1024) void probe(float* out, int reps, float thr) {
     float v[8];
@@ -53,6 +70,22 @@ __global__ __launch_bounds__(1024) void probe(float* out, int reps, float thr) {
             for (int k = 0; k < 4; ++k)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = fmaf(0.99f, sin_squared_b(1.01f * v[i]), v[i]) * 0.5f;
+        }
+        if (KIND == 6) {  // the packed form, two elements per call
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int i = 0; i < 8; i += 2) {
+                    const f32x2 r = snake_act2(f32x2{v[i], v[i + 1]}, f32x2{1.01f, 1.02f}, f32x2{0.99f, 0.98f});
+                    v[i] = r.x * 0.5f;
+                    v[i + 1] = r.y * 0.5f;
+                }
+        }
+        if (KIND == 7) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = snake_cosform(v[i], 1.01f + 0.01f * (i & 1), 0.99f - 0.01f * (i & 1)) * 0.5f;
         }
         if (KIND == 4) {  // compiled: split2 on 4 pairs x 4
 #pragma unroll
@@ -96,6 +129,8 @@ int main() {
     run<2>("compiled select (cmp + mul + cndmask), per element", out, 256);
     run<3>("compiled snake_act (+ 1 mul), per element", out, 32);
     run<5>("snake with magic-number rounding, no select, per element", out, 32);
+    run<6>("snake_act2 (packed f32x2), per element", out, 32);
+    run<7>("the packed form's arithmetic, scalar, per element", out, 32);
     run<4>("compiled split2 (+ 2 and/shift + 2 mul), per pair", out, 16);
     return 0;
 }
