@@ -91,6 +91,43 @@ def roofline_of(dom, total_ms):
     return roof
 
 
+def _template_args(name):
+    """('base', [top-level template arguments]) of a kernel name, whitespace removed: 'k<RGeo<96, 8>, 96>' -> ('k', ['RGeo<96,8>', '96'])."""
+    name = name.replace(" ", "")
+    if "<" not in name:
+        return name, None
+    base, rest = name.split("<", 1)
+    rest = rest[:rest.rindex(">")]
+    args, depth, cur = [], 0, ""
+    for ch in rest:
+        if ch == "," and depth == 0:
+            args.append(cur)
+            cur = ""
+            continue
+        depth += ch == "<"
+        depth -= ch == ">"
+        cur += ch
+    args.append(cur)
+    return base, args
+
+
+def match_traffic_kernels(kernel, profiled):
+    """Entries of a traffic.json (`profiled`: rocprofv3's full template names) that are the SAME kernel as `kernel` (the library's
+    profile name, which abbreviates template arguments).  Rules, in order: (1) the full name, whitespace aside; (2) a name without
+    template arguments stands for every instantiation of that base name (the library aggregates them the same way);
+    (3) a name WITH arguments matches the instantiations whose top-level arguments contain all of its own — and is attached only if
+    exactly one instantiation does (round 3 averaged conv_unit_wide_kernel<256> with <192> by matching on the base name alone)."""
+    base, args = _template_args(kernel)
+    exact = [k for k in profiled if k.replace(" ", "") == kernel.replace(" ", "")]
+    if exact:
+        return exact
+    same_base = [k for k in profiled if _template_args(k)[0] == base]
+    if args is None:
+        return same_base
+    hits = [k for k in same_base if set(args) <= set(_template_args(k)[1] or [])]
+    return hits if len(hits) == 1 else []
+
+
 def attach_traffic(roof, profiles_dir, workload_key, prefix=""):
     """HBM bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE), which cannot run inside
     this process: the summary tools/collect_profiles.sh + tools/summarize_profiles.py wrote for this same workload is
@@ -101,19 +138,27 @@ def attach_traffic(roof, profiles_dir, workload_key, prefix=""):
         return
     t = json.load(open(tfile))
     fp = source_fingerprint()
-    hits = [v for k, v in t["kernels"].items() if k.split("<")[0].strip() == roof["kernel"].split("<")[0]]
-    ok = t.get("workload") == workload_key and bool(hits)
+    names = match_traffic_kernels(roof["kernel"], list(t["kernels"])) if t.get("workload") == workload_key else []
+    hits = [t["kernels"][k] for k in names]
     stale = t.get("source_sha256") != fp
-    if ok:
+    if hits:
         n = sum(h["launches"] for h in hits)
         val = sum(h["hbm_bytes_per_launch_corrected"] * h["launches"] for h in hits) / n
-        roof.update(traffic=None if stale else val, traffic_stale=stale,
+        roof.update(traffic=None if stale else val, traffic_stale=stale, traffic_kernels=names,
                     traffic_source=f"{tfile.relative_to(REPO) if tfile.is_relative_to(REPO) else tfile} (rocprofv3 --pmc FETCH_SIZE / "
                                    f"WRITE_SIZE; collected on sources {t.get('source_sha256')}, this build {fp})")
+        if "algorithmic_bytes_per_launch" in roof and not stale:
+            roof["traffic_over_algorithmic"] = val / roof["algorithmic_bytes_per_launch"]
         if stale:
             roof["traffic_of_stale_profile"] = val
     else:
         roof.update(traffic=None, traffic_source=None)
+
+
+def latest_profiles_dir():
+    """profiles/rNN of the highest round that holds a traffic.json (a stale one is reported as stale, never attached)."""
+    rounds = sorted(d for d in (REPO / "profiles").glob("r[0-9][0-9]") if (d / "traffic.json").exists())
+    return rounds[-1] if rounds else REPO / "profiles"
 
 
 def launch_command(n_gpus, argv, port=None):
@@ -195,7 +240,7 @@ def main():
     ap.add_argument("--gemm", choices=["split", "exact"], default="split",
                     help="split: large fp32 contractions as exact bf16x3 operand splits on the bf16 matrix cores (default); "
                          "exact: every product on the fp32 MFMA instruction")
-    ap.add_argument("--profiles-dir", default=str(REPO / "profiles" / "r03"),
+    ap.add_argument("--profiles-dir", default=str(latest_profiles_dir()),
                     help="directory whose traffic.json (rocprofv3 PMC summary of this workload) is attached as roofline.traffic")
     ap.add_argument("--print-launch", action="store_true",
                     help="with --gpus N > 1 and no WORLD_SIZE: print the torch.distributed.run command this would start, and exit")

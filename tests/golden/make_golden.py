@@ -12,6 +12,7 @@ What is pinned (see oracle/l3ac_oracle.py docstring):
                        absent PyPI dependency ``local_attention`` replaced by a stand-in built on the oracle's
                        own restatement.  Pins the WIRING only; the attention arithmetic stays unpinned.
   * ``fsq_kat.npz``  — known-answer vectors from the reference ``SuperFSQ`` (half-even ties, saturation, decode).
+  * ``binding_names.npz`` — INTEGRATION.md §2's ``folded_tensors()`` run on the reference ``EnCodec``: tensor names + checksums.
   * ``chunk_kat.npz`` — the reference's ``ChunkData`` cut / merge results and ``Codec.extract_unit`` / ``decode_unit`` run on the
                        tiny model (pins oracle/chunk_oracle.py).
 """
@@ -343,9 +344,41 @@ def make_chunk_kat():
     print(f"[chunk_kat] written ({len(cases)} ChunkData cases, {len(eu)} extract_unit cases; extract_unit as written raises: {as_written})")
 
 
+def make_binding_fixture():
+    """INTEGRATION.md §2's `folded_tensors()` — the reference-side stub a maintainer would add — run as written on the reference's
+    own ``EnCodec`` (weight-norm parametrizations, ``trainable_modules``: en_codec.py:46-51, layers.py:11-25): the names it hands
+    to ``l3ac_create`` and a checksum of every folded tensor.  tests/test_host.py asserts that ``l3ac_amd.weights.folded_weights``
+    (the fold the package applies to the ``.pt`` files) yields exactly these, i.e. that the library looks up the names the snippet
+    produces."""
+    from tests.helpers import integration_snippet
+    ns = integration_snippet()
+    out = {}
+    for tag, cfg_file, seed in (("tiny", HERE / "tiny.toml", 3), ("1kbps", resolve_config_file("1kbps"), 0),
+                                ("3kbps", resolve_config_file("3kbps"), 0)):
+        mc, ref, _ = build_reference(cfg_file, seed)
+        tensors = ns["folded_tensors"](ref)
+        names = sorted(tensors)
+        out[f"{tag}_seed"] = np.int64(seed)
+        out[f"{tag}_names"] = np.array(names)
+        out[f"{tag}_numel"] = np.array([tensors[k].numel() for k in names], dtype=np.int64)
+        out[f"{tag}_sum"] = np.array([tensors[k].double().sum().item() for k in names], dtype=np.float64)
+        out[f"{tag}_abssum"] = np.array([tensors[k].double().abs().sum().item() for k in names], dtype=np.float64)
+        # reference ModelConfig attributes HipPath.__init__ reads
+        for attr in ("feature_dim", "encoder_dims", "encoder_depths", "compress_rates", "decoder_dims", "decoder_depths", "decode_rates",
+                     "en_coder_depth", "en_coder_window_size", "en_coder_compress_rate", "hop_length"):
+            out[f"{tag}_mc_{attr}"] = np.array(getattr(ref.mc, attr), dtype=np.int64)
+        out[f"{tag}_mc_levels"] = np.array(ref.mc.vq_config["levels"], dtype=np.int64)
+        print(f"[binding {tag}] {len(names)} tensors, {int(out[f'{tag}_numel'].sum())} values")
+    np.savez_compressed(HERE / "binding_names.npz", **out)
+    print("[binding_names] written")
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if "--binding-only" in sys.argv:
+        make_binding_fixture()
+        sys.exit(0)
     if "--boundary-only" in sys.argv:
         make_fsq_boundary_kat()
         sys.exit(0)
@@ -353,6 +386,7 @@ if __name__ == "__main__":
         make_chunk_kat()
         sys.exit(0)
     make_chunk_kat()
+    make_binding_fixture()
     make_fsq_kat()
     make_fsq_boundary_kat()
     make_model_fixtures("tiny", HERE / "tiny.toml", seed=3, batch=2, samples=250, full_tensors=True)

@@ -124,3 +124,61 @@ def index_agreement(idx, idx_ref, latents_ref, levels):
     return {"tokens": int(idx.size), "mismatches": int(bad.size), "max_margin_of_mismatches": max_margin,
             "single_step": bool(single), "decisions_within_1e-4": int((margins < 1e-4).sum()),
             "decisions_within_1e-5": int((margins < 1e-5).sum()), "min_margin": float(margins.min())}
+
+
+def integration_snippet():
+    """INTEGRATION.md §2's reference-side binding (`l3ac/_hip.py`), extracted from the document and executed as written — the only
+    adaptation is where `ctypes.CDLL("libl3ac_hip.so")` finds the library (the in-tree build instead of the loader path).
+    Returns the namespace the block defines (`_Cfg`, `_Tensor`, `folded_tensors`, `HipPath`, ...)."""
+    import ctypes
+    import re
+
+    from l3ac_amd import _capi
+    text = (Path(__file__).resolve().parent.parent / "INTEGRATION.md").read_text()
+    section = text[text.index("## 2."):text.index("## 3.")]
+    code = re.search(r"```python\n(# l3ac/_hip\.py.*?)```", section, re.S).group(1)
+    real_cdll = ctypes.CDLL
+
+    def cdll(name, *a, **k):
+        return real_cdll(str(_capi.LIB_PATH) if name == "libl3ac_hip.so" else name, *a, **k)
+    ns = {"__name__": "l3ac._hip"}
+    ctypes.CDLL = cdll
+    try:
+        exec(compile(code, "INTEGRATION.md#l3ac/_hip.py", "exec"), ns)
+    finally:
+        ctypes.CDLL = real_cdll
+    return ns
+
+
+def module_tree_from_state_dict(sd):
+    """An nn.Module whose ``state_dict()`` has exactly the keys / shapes of `sd` (one of the reference's five per-module state dicts),
+    with real ``torch.nn.utils.parametrizations.weight_norm`` parametrizations wherever `sd` holds ``<m>.parametrizations.weight.
+    original{0,1}`` (reference layers.py:11-25), loaded with ``strict=True``.  Stands where a reference sub-module stands when the
+    reference tree itself is absent (the GPU box): INTEGRATION.md's ``folded_tensors()`` walks it as it would walk the real one."""
+    import torch.nn as nn
+    from torch.nn.utils.parametrizations import weight_norm
+
+    class Node(nn.Module):
+        pass
+
+    root = Node()
+
+    def node_at(path):
+        m = root
+        for part in path:
+            if not hasattr(m, part):
+                m.add_module(part, Node())
+            m = getattr(m, part)
+        return m
+    normed = sorted({k[:-len(".parametrizations.weight.original0")] for k in sd if k.endswith(".parametrizations.weight.original0")})
+    for prefix in normed:
+        leaf = node_at(prefix.split("."))
+        leaf.weight = nn.Parameter(torch.zeros_like(sd[f"{prefix}.parametrizations.weight.original1"]) + 1.0)
+        weight_norm(leaf)  # dim 0: the norm over all dims but the output channel, as the reference's wrapper
+    for k, v in sd.items():
+        if ".parametrizations." in k:
+            continue
+        *path, name = k.split(".")
+        node_at(path).register_parameter(name, nn.Parameter(torch.zeros_like(v)))
+    root.load_state_dict(sd, strict=True)
+    return root.eval()

@@ -527,6 +527,36 @@ def test_weights_from_disk_and_example_flow(tmp_path):
         l3ac_amd.get_model("1kbps", model_dir=tmp_path)
 
 
+@pytest.mark.parametrize("tag,seed", [("tiny", 3), ("1kbps", 0)])
+def test_integration_snippet_runs_as_written(tag, seed):
+    """INTEGRATION.md §2 (the ctypes stub a reference maintainer would add as l3ac/_hip.py), extracted from the document and run as
+    written: `folded_tensors()` walks module trees with real weight-norm parametrizations carrying the reference's state-dict keys
+    (strict load; tests/helpers.py::module_tree_from_state_dict — the names were compared with the reference's own EnCodec in the
+    build container, tests/test_host.py), `HipPath` creates a context through `l3ac_create` with the snippet's own `_Cfg` / `_Tensor`
+    and its `encode` / `decode` must return what the package's drop-in surface returns, bit for bit."""
+    import types
+
+    from tests.helpers import integration_snippet, module_tree_from_state_dict
+    codec = _codec(tag, seed)
+    mc = codec.network.mc
+    sds = codec.network.state_dicts()
+    net = types.SimpleNamespace(mc=mc, trainable_modules={m: module_tree_from_state_dict(sds[m]) for m in W.MODULE_NAMES})
+    ns = integration_snippet()
+    path = ns["HipPath"](net, torch.cuda.current_device())
+    audio = seeded_audio(3, 250 if tag == "tiny" else 16000).cuda()
+    q, ind = path.encode(audio)
+    q0, ind0 = codec.encode_audio(audio)
+    assert torch.equal(ind["indices"], ind0["indices"]) and torch.equal(q, q0) and torch.equal(ind["level_indices"], ind0["level_indices"])
+    assert torch.equal(path.decode(feature=q), codec.decode_audio(q0))
+    assert torch.equal(path.decode(indices=ind["indices"]), codec.decode_audio(indices=ind0["indices"]))
+    # a wrong ABI version is refused with a message, through the snippet's own error path
+    cfg = ns["_Cfg"](abi_version=2)
+    out = ns["C"].c_void_p()
+    with pytest.raises(RuntimeError, match="(?i)abi"):
+        ns["_check"](ns["_lib"].l3ac_create(ns["C"].byref(cfg), None, 0, 0, ns["C"].byref(out)))
+    ns["_lib"].l3ac_destroy(path.ctx)
+
+
 def test_long_audio_chunker():
     """extract_unit / decode_unit (reference l3ac/codec.py:124-156, corrected to run en_encoder / en_decoder on every
     chunk and to overlap by the attention look-back) against (i) the oracle run chunk by chunk with the reference's ChunkData

@@ -191,6 +191,25 @@ def test_traffic_summary_is_tied_to_the_kernel_sources(tmp_path):
     roof = {"kernel": "gemm_split_kernel"}
     bench.attach_traffic(roof, tmp_path, "3kbps b256 s16000 split")  # another workload: not attached at all
     assert roof["traffic"] is None and "traffic_stale" not in roof
+    # the figure belongs to ONE kernel: an instantiation is matched by its full name, never averaged with its siblings (round 3
+    # printed the mean of conv_unit_wide_kernel<256> and <192> beside the algorithmic bytes of <256> alone)
+    t = {"source_sha256": bench.source_fingerprint(), "workload": "1kbps b256 s16000 split",
+         "kernels": {"conv_unit_wide_kernel<256>": {"launches": 15, "hbm_bytes_per_launch_corrected": 1600.0},
+                     "conv_unit_wide_kernel<192>": {"launches": 10, "hbm_bytes_per_launch_corrected": 150.0},
+                     "conv_unit_ring_kernel<RGeo<96, 8, 2, 6, 3, false, 1, false>, 96>": {"launches": 15, "hbm_bytes_per_launch_corrected": 566.0},
+                     "conv_unit_ring_kernel<RGeo<48, 16, 1, 0, 0, true, 1, false>, 48>": {"launches": 10, "hbm_bytes_per_launch_corrected": 623.0},
+                     "row_kernel<2, 2, unsigned int, 12, 1>": {"launches": 5, "hbm_bytes_per_launch_corrected": 1.0},
+                     "row_kernel<2, 2, unsigned int, 6, 1>": {"launches": 5, "hbm_bytes_per_launch_corrected": 2.0}}}
+    (tmp_path / "traffic.json").write_text(json.dumps(t))
+    for kernel, want in (("conv_unit_wide_kernel<256>", 1600.0), ("conv_unit_wide_kernel<192>", 150.0),
+                         ("conv_unit_ring_kernel<96>", 566.0), ("conv_unit_ring_kernel<48>", 623.0),
+                         ("row_kernel<LERP,CN>", None),       # abbreviated arguments that name no single instantiation: not attached
+                         ("conv_unit_wide_kernel<128>", None)):
+        roof = {"kernel": kernel, "algorithmic_bytes_per_launch": 800.0}
+        bench.attach_traffic(roof, tmp_path, "1kbps b256 s16000 split")
+        assert roof["traffic"] == want, (kernel, roof)
+        if want is not None:
+            assert roof["traffic_over_algorithmic"] == want / 800.0 and len(roof["traffic_kernels"]) == 1
     # the fingerprint covers SOURCES only: objects of a tagged diagnostic build next to them (csrc/build_<tag>/*.hip.o travel to the
     # GPU box with the tree) must not change it — they once did, and a profile collected beside such a directory went stale when it was removed
     csrc = bench.REPO / "l3ac_amd" / "csrc"
@@ -256,3 +275,42 @@ def test_bench_self_launch_command():
     r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                        env={**env, "WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0"}, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=4" in (r.stderr + r.stdout)
+
+
+def test_integration_snippet_binding_matches_the_library():
+    """INTEGRATION.md §2 is executable: the block is extracted and executed (tests/helpers.py::integration_snippet), its `_Cfg` has
+    the size and field offsets of the struct this package passes to `l3ac_create`, it asks the LIBRARY for the ABI version (round 3's
+    text passed a literal 2 to an ABI-3 library), and the tensor names + values its `folded_tensors()` produced on the reference's own
+    `EnCodec` (tests/golden/binding_names.npz, written by make_golden.py in the build container) are exactly the names + values
+    `l3ac_amd.weights.folded_weights` hands to `l3ac_create` for the same weights."""
+    import numpy as np
+
+    from tests.helpers import integration_snippet
+    ns = integration_snippet()
+    cfg_a, cfg_b = ns["_Cfg"], _capi.Config
+    assert ctypes.sizeof(cfg_a) == ctypes.sizeof(cfg_b)
+    assert [(n, getattr(cfg_a, n).offset, getattr(cfg_a, n).size) for n, _ in cfg_a._fields_] == \
+           [(n, getattr(cfg_b, n).offset, getattr(cfg_b, n).size) for n, _ in cfg_b._fields_]
+    ta, tb = ns["_Tensor"], _capi.Tensor
+    assert ctypes.sizeof(ta) == ctypes.sizeof(tb) and [n for n, _ in ta._fields_] == [n for n, _ in tb._fields_]
+    assert ns["_lib"].l3ac_abi_version() == _capi.ABI_VERSION
+    text = (REPO / "INTEGRATION.md").read_text()
+    assert "abi_version=_lib.l3ac_abi_version()" in text and not re.search(r"abi_version=\d", text)
+    assert isinstance(ns["_lib"].l3ac_last_error(), (bytes, type(None)))  # restype set: a 64-bit char* is not truncated to int
+    fx = np.load(GOLDEN / "binding_names.npz")
+    for tag in ("tiny", "1kbps", "3kbps"):
+        cfg_file = GOLDEN / "tiny.toml" if tag == "tiny" else resolve_config_file(tag)
+        mc = L3ACConfig(config_file=cfg_file).network_config
+        folded = W.folded_weights(W.synthetic_state_dicts(mc, seed=int(fx[f"{tag}_seed"])))
+        names = sorted(folded)
+        assert names == [str(n) for n in fx[f"{tag}_names"]], set(names) ^ set(map(str, fx[f"{tag}_names"]))
+        assert [folded[k].numel() for k in names] == fx[f"{tag}_numel"].tolist()
+        s = np.array([folded[k].double().sum().item() for k in names])
+        a = np.array([folded[k].double().abs().sum().item() for k in names])
+        assert (np.abs(s - fx[f"{tag}_sum"]) <= 1e-6 * np.maximum(1.0, fx[f"{tag}_abssum"])).all()
+        np.testing.assert_allclose(a, fx[f"{tag}_abssum"], rtol=1e-6)
+        # the attributes HipPath.__init__ reads from the REFERENCE's ModelConfig have the values this package's config gives
+        for attr in ("feature_dim", "encoder_dims", "encoder_depths", "compress_rates", "decoder_dims", "decoder_depths", "decode_rates",
+                     "en_coder_depth", "en_coder_window_size", "en_coder_compress_rate", "hop_length"):
+            assert np.array_equal(np.array(getattr(mc, attr), dtype=np.int64), fx[f"{tag}_mc_{attr}"]), attr
+        assert list(mc.levels) == fx[f"{tag}_mc_levels"].tolist() == list(mc.vq_config["levels"])
