@@ -176,6 +176,25 @@ def launch_command(n_gpus, argv, port=None):
     return cmd, env
 
 
+def visible_gpu_count():
+    """GPUs this node exposes, counted WITHOUT initialising HIP in this process (it is about to start the ranks as children and
+    must stay GPU-untouched): KFD topology nodes with SIMDs, cut down by a *_VISIBLE_DEVICES list when one is set.  None if the
+    topology is not readable (then the ranks themselves report a missing device)."""
+    nodes = Path("/sys/class/kfd/kfd/topology/nodes")
+    try:
+        n = 0
+        for d in nodes.iterdir():
+            props = dict(l.split(None, 1) for l in (d / "properties").read_text().splitlines() if " " in l)
+            n += int(props.get("simd_count", "0")) > 0
+    except OSError:
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def self_launch(args):
     """Run the N-rank bench as child processes of this (GPU-untouched) one; rank 0's JSON line is relayed as the LAST
     line of stdout, everything else the children print goes to stderr; returns the launcher's exit code."""
@@ -184,8 +203,8 @@ def self_launch(args):
     if args.print_launch:
         print(json.dumps({"cmd": cmd, "env": env}))
         return 0
-    n_dev = torch.cuda.device_count()  # counting devices does not initialise the GPU
-    if n_dev < args.gpus:
+    n_dev = None if args.dry_run_cpu else visible_gpu_count()
+    if n_dev is not None and n_dev < args.gpus:
         print(f"bench.py: --gpus {args.gpus} but this node exposes {n_dev} GPU(s)", file=sys.stderr)
         return 2
     proc = subprocess.run(cmd, env={**os.environ, **env}, stdout=subprocess.PIPE, text=True)
@@ -244,7 +263,17 @@ def main():
                     help="directory whose traffic.json (rocprofv3 PMC summary of this workload) is attached as roofline.traffic")
     ap.add_argument("--print-launch", action="store_true",
                     help="with --gpus N > 1 and no WORLD_SIZE: print the torch.distributed.run command this would start, and exit")
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="plumbing check, NOT a measurement: the same launcher / rank / barrier / gather / timing / JSON code on CPU "
+                         "ranks over gloo, with the codec taken from --codec-factory (tests/standin_codec.py); the line says dry_run_cpu")
+    ap.add_argument("--codec-factory", default=None,
+                    help="module:function returning an object with the codec's surface (--dry-run-cpu only)")
     args = ap.parse_args()
+    dry = args.dry_run_cpu
+    if dry and not args.codec_factory:
+        raise SystemExit("--dry-run-cpu needs --codec-factory module:function (the product has no CPU path)")
+    if args.codec_factory and not dry:
+        raise SystemExit("--codec-factory is a --dry-run-cpu option: measurements always run the HIP library")
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: start one fresh process per GPU BEFORE anything here touches the GPU (a process
@@ -260,22 +289,35 @@ def main():
     import l3ac_amd
     from l3ac_amd import _capi
 
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
-
-    l3ac_amd.set_gemm_split(args.gemm == "split")
-    codec = l3ac_amd.get_model(args.config, synthetic_seed=0)  # identical weights on every rank
-    codec.network.to(device=dev).eval()
+    if dry:  # CPU ranks over gloo: everything below is the code the GPU ranks run, minus the device calls
+        import importlib
+        dev = torch.device("cpu")
+        sync = lambda: None
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend="gloo")
+        mod, fn = args.codec_factory.split(":")
+        codec = getattr(importlib.import_module(mod), fn)()
+    else:
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank} but this node exposes {torch.cuda.device_count()} GPU(s)")
+        dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev)
+        sync = torch.cuda.synchronize
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        l3ac_amd.set_gemm_split(args.gemm == "split")
+        codec = l3ac_amd.get_model(args.config, synthetic_seed=0)  # identical weights on every rank
+        codec.network.to(device=dev).eval()
     mc = codec.network.mc
     samples = int(round(args.seconds * codec.config.sample_rate))
     b = args.batch
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     audio = ((torch.rand(b, samples, generator=g) * 2 - 1) * 0.5).to(dev)
-    codec.network.context().reserve(b, samples)
-    force_dist = world == 1 and os.environ.get("L3AC_BENCH_FORCE_DIST") == "1"  # test hook: 1-rank RCCL collectives
+    if not dry:
+        codec.network.context().reserve(b, samples)
+    force_dist = world == 1 and not dry and os.environ.get("L3AC_BENCH_FORCE_DIST") == "1"  # test hook: 1-rank RCCL collectives
     if force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -311,7 +353,7 @@ def main():
 
     # the quantiser's stand-alone HBM roofline (its own large-N launch) is taken first, on an idle chip: after the MFMA-heavy
     # pipeline the same launch measures ~10 % lower while the clocks recover
-    extras = rank == 0 and world == 1 and not args.pipeline_only
+    extras = rank == 0 and world == 1 and not args.pipeline_only and not dry
     fsq_line = fsq_microbench(codec, dev) if extras else None
     rccl_ranks = None
     if world > 1 or force_dist:  # proof that RCCL sees every rank: an all-reduce of ones
@@ -323,15 +365,16 @@ def main():
     pending.drain()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ind, wave = run()
     pending.drain()  # the last step's gathers are part of the timed work
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
     elapsed_local = elapsed = time.perf_counter() - t0
+    gathered_shapes = [tuple(r.shape) for r in pending.results] if gather else None
     per_rank_ms = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -345,15 +388,19 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = world * b * samples * args.steps / elapsed
         gflop_clip = algorithmic_gflop_per_clip_second(mc) * args.seconds
-        # ---- per-kernel roofline: one extra, untimed step with HIP events around every launch ----------
-        with _capi.profile() as prof:
-            codec.decode_audio(codec.encode_audio(audio)[0])
-        kernels, shapes = aggregate(prof.entries)
-        total_ms = sum(e["ms_total"] for e in kernels)
-        roof = roofline_of(kernels[0], total_ms)
-        attach_traffic(roof, args.profiles_dir, f"{args.config} b{b} s{samples} {args.gemm}")
+        if dry:
+            kernels, shapes, total_ms, roof = [], [], 0.0, None
+        else:
+            # ---- per-kernel roofline: one extra, untimed step with HIP events around every launch ----------
+            with _capi.profile() as prof:
+                codec.decode_audio(codec.encode_audio(audio)[0])
+            kernels, shapes = aggregate(prof.entries)
+            total_ms = sum(e["ms_total"] for e in kernels)
+            roof = roofline_of(kernels[0], total_ms)
+            attach_traffic(roof, args.profiles_dir, f"{args.config} b{b} s{samples} {args.gemm}")
         out = {
-            "metric": "audio samples/sec encode+decode, 1kbps@16kHz, batch 256; indices bit-exact",
+            "metric": "audio samples/sec encode+decode, 1kbps@16kHz, batch 256; indices bit-exact" if not dry else
+                      "DRY RUN ON CPU (gloo ranks, stand-in codec): plumbing check of the N-rank bench path, not a measurement",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -362,6 +409,7 @@ def main():
                            "(error vs fp64 <= the fp32 fmaf chain's, tests/test_gpu_blocks.py::test_gemm_split_accuracy); "
                            "all other products use v_mfma_f32_32x32x2_f32") if l3ac_amd.get_gemm_split() else
                           "fp32 everywhere: every product on v_mfma_f32_32x32x2_f32 (--gemm exact)",
+            "dry_run_cpu": dry,
             "parity_note": "'indices bit-exact' is the BASELINE metric's wording; what is measured: the quantiser kernel is bit-exact "
                            "for identical inputs (reference known-answer vectors incl. exact rounding boundaries), and end to end "
                            "every token of this batch is compared with the CPU oracle in cpu_baseline.index_agreement (mismatch "
@@ -382,10 +430,13 @@ def main():
                              "tflops": round(e["flops"] / e["ms_total"] / 1e9, 2)} for e in shapes[:16]],
         }
         if rccl_ranks is not None:
-            out["rccl_ranks"] = rccl_ranks
+            out["rccl_ranks"] = rccl_ranks  # an all-reduce of ones over the process group (gloo_ranks in a dry run)
             out["per_rank_ms_per_step"] = per_rank_ms if per_rank_ms is not None else [elapsed_local / args.steps * 1e3]
+            out["gathered_shapes"] = gathered_shapes  # [indices, waveforms] of the last retired step: world * batch rows each
+        if dry:
+            out["collective_backend"] = "gloo"
         ind_exact = None
-        if args.gemm == "split" and world == 1 and not args.graph and not args.pipeline_only:
+        if args.gemm == "split" and world == 1 and not args.graph and not args.pipeline_only and not dry:
             # the same step with every product on the exact fp32 MFMA instruction, for reference (5 steps, untimed above)
             l3ac_amd.set_gemm_split(False)
             dt, (ind_x, _) = time_steps(step, 5, 2, pending.drain)
@@ -396,7 +447,7 @@ def main():
         out["fsq_kernel"] = fsq_line
         if extras and not args.no_configs and not args.graph:
             out["configs"] = other_configs(dev, args)
-        if not args.no_cpu_baseline and not args.pipeline_only and world == 1:  # rank 0 at N = 1 only
+        if not args.no_cpu_baseline and not args.pipeline_only and world == 1 and not dry:  # rank 0 at N = 1 only
             routes = {"split" if l3ac_amd.get_gemm_split() else "exact": ind["indices"]}
             if ind_exact is not None:
                 routes["exact"] = ind_exact

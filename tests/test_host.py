@@ -314,3 +314,33 @@ def test_integration_snippet_binding_matches_the_library():
                      "en_coder_depth", "en_coder_window_size", "en_coder_compress_rate", "hop_length"):
             assert np.array_equal(np.array(getattr(mc, attr), dtype=np.int64), fx[f"{tag}_mc_{attr}"]), attr
         assert list(mc.levels) == fx[f"{tag}_mc_levels"].tolist() == list(mc.vq_config["levels"])
+
+
+def test_bench_rank_path_runs_at_world_2_on_cpu():
+    """bench.py's N > 1 code — self-launch through torch.distributed.run, rendezvous on 127.0.0.1, the ranks' warm-up, barriers,
+    async output gathers retired one step late, per-rank times all-gathered, max over ranks, rank 0's JSON relayed as the LAST line of
+    stdout, launcher's exit code — executed with two real processes (`--dry-run-cpu`: gloo ranks on CPU, the oracle stand-in codec
+    of tests/standin_codec.py).  The first run of this code with more than one rank must not be the driver's 8-GPU run."""
+    import json
+    import os
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "2"
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run-cpu",
+                        "--codec-factory", "tests.standin_codec:make_codec", "--batch", "4", "--seconds", "0.05"],
+                       capture_output=True, text=True, env=env, timeout=600, cwd=str(REPO))
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1]
+    line = json.loads(last)
+    assert line["dry_run_cpu"] is True and line["metric"].startswith("DRY RUN") and line["collective_backend"] == "gloo"
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert len(line["per_rank_ms_per_step"]) == 2 and all(t > 0 for t in line["per_rank_ms_per_step"])
+    assert abs(line["ms_per_step"] - max(line["per_rank_ms_per_step"])) < 1e-6       # the slowest rank's time is the step time
+    assert abs(line["value"] - 2 * 4 * 800 * 3 / (line["ms_per_step"] * 3e-3)) < 1e-6 * line["value"]  # whole-job samples / max time
+    assert line["gathered_shapes"] == [[8, 67], [8, 804]]                              # both ranks' clips: indices and waveforms
+    assert line["roofline"] is None and "cpu_baseline" not in line
+    # without the factory, or with the factory outside a dry run, it refuses: measurements always run the HIP library
+    for extra in (["--dry-run-cpu"], ["--codec-factory", "tests.standin_codec:make_codec"]):
+        r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2"] + extra, capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode != 0
