@@ -30,7 +30,7 @@ from . import weights as _weights
 from .chunking import ChunkData, plan as _chunk_plan
 from .config import CONFIG_DIR, L3ACConfig, ModelConfig, list_models, resolve_config_file
 
-__all__ = ["set_gemm_split", "get_gemm_split", "list_models", "get_model", "get_model_info", "L3AC", "L3ACConfig", "ModelConfig", "Network",
+__all__ = ["set_gemm_split", "get_gemm_split", "gemm_split_routes", "restore_gemm_split_routes", "list_models", "get_model", "get_model_info", "L3AC", "L3ACConfig", "ModelConfig", "Network",
            "bits_per_token", "pack_indices", "unpack_indices", "ChunkData"]
 __version__ = "0.1.0"
 
@@ -39,7 +39,18 @@ log = logging.getLogger("L3AC")
 # GEMM route: state of each Network's own HIP context.  The module-level setter below keeps the
 # round-1/2 convenience (one call switches every live network and the default of later ones) without any process-wide
 # state inside the library.
-_default_gemm_split = os.environ.get("L3AC_GEMM_SPLIT", "1") not in ("0", "")
+def _env_atoi_flag(name: str, default: bool) -> bool:
+    """The library's own reading of a 0/1 environment switch (`std::atoi(value) != 0`, kernels/gemm_split.hip): leading
+    whitespace, an optional sign, then digits; anything else ("off", "") counts as 0."""
+    import re
+    v = os.environ.get(name)
+    if v is None:
+        return default
+    m = re.match(r"\s*([+-]?\d+)", v)
+    return bool(m) and int(m.group(1)) != 0
+
+
+_default_gemm_split = _env_atoi_flag("L3AC_GEMM_SPLIT", True)
 _networks: "weakref.WeakSet[Network]" = weakref.WeakSet()
 
 
@@ -56,7 +67,7 @@ class Network:
         # literal two-pass formula is evaluated (correct for any input) and min_grn_norm() reports the smallest g seen, i.e.
         # whether the fast path would have been exact for the data that went through.
         self.grn_exact = False
-        self.gemm_split = _default_gemm_split
+        self._gemm_split = _default_gemm_split
         _networks.add(self)
         self._state_dicts = None
         self._folded = None
@@ -120,19 +131,26 @@ class Network:
         if self._folded is None:
             raise RuntimeError("no weights loaded (get_model / load_state_dicts first)")
         self._ctx = _capi.Context(self.mc, self._folded, self.device.index, grn_exact=self.grn_exact)
-        self._ctx.set_gemm_split(self.gemm_split)
+        self._ctx.set_gemm_split(self._gemm_split)
+
+    @property
+    def gemm_split(self) -> bool:
+        """The route of this network: its context's own state once it has one (whoever set it — `set_gemm_split`,
+        `ctx.set_option("gemm_split", ...)`, `ctx.set_gemm_split`), else the route its context will be created on."""
+        return self._ctx.get_gemm_split() if self._ctx is not None else self._gemm_split
 
     def set_gemm_split(self, enable: bool) -> "Network":
         """Route of THIS network's context: True = the large fp32 contractions as exact bf16x3 operand splits on the bf16 matrix
         cores (default), False = every product on the exact fp32 MFMA instruction.  Not to be called while another thread
         runs or captures a graph on this network."""
-        self.gemm_split = bool(enable)
+        self._gemm_split = bool(enable)
         if self._ctx is not None:
-            self._ctx.set_gemm_split(self.gemm_split)
+            self._ctx.set_gemm_split(self._gemm_split)
         return self
 
     def _drop_ctx(self):
         if self._ctx is not None:
+            self._gemm_split = self._ctx.get_gemm_split()  # the route travels with the network to its next device
             self._ctx.close()
             self._ctx = None
 
@@ -320,8 +338,26 @@ def set_gemm_split(enable: bool) -> None:
 
 
 def get_gemm_split() -> bool:
-    """The route networks created from now on start with (and, after ``set_gemm_split``, the route of every live one)."""
+    """The DEFAULT route: what networks created from now on start with (``L3AC_GEMM_SPLIT`` read the way the library reads it, or
+    the last module-level ``set_gemm_split``).  It is not the state of any live network — a network whose route was changed on
+    its own (``Network.set_gemm_split``, a context option) reports it in ``network.gemm_split``.  Code that switches routes
+    temporarily should save and restore per network, or use ``gemm_split_routes()``."""
     return _default_gemm_split
+
+
+def gemm_split_routes() -> dict:
+    """{network: route} of every live network — the snapshot ``restore_gemm_split_routes`` takes back."""
+    return {net: net.gemm_split for net in list(_networks)}
+
+
+def restore_gemm_split_routes(routes: dict, default: Optional[bool] = None) -> None:
+    """Undo a module-level ``set_gemm_split``: every network in `routes` gets ITS previous route back (a module-level
+    ``set_gemm_split(before)`` would overwrite individually routed networks with the default)."""
+    global _default_gemm_split
+    if default is not None:
+        _default_gemm_split = bool(default)
+    for net, route in routes.items():
+        net.set_gemm_split(route)
 
 
 def bits_per_token(mc) -> int:

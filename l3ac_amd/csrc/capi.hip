@@ -22,14 +22,15 @@ void l3ac_set_error(const char* fmt, ...) {
 }
 
 int l3ac_device_cu_count() {  // per device ordinal: several devices may be driven from one process
-    static int cus[L3AC_MAX_DEVICES] = {};
+    static std::atomic<int> cus[L3AC_MAX_DEVICES] = {};
     const int slot = l3ac_device_slot();
-    if (cus[slot] <= 0) {
-        int dev = 0, v = 0;
+    int v = slot >= 0 ? cus[slot].load(std::memory_order_relaxed) : 0;
+    if (v <= 0) {
+        int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        cus[slot] = v;
+        if (slot >= 0) cus[slot].store(v, std::memory_order_relaxed);
     }
-    return cus[slot];
+    return v;
 }
 
 static thread_local Profiler* g_profiler = nullptr;
@@ -112,8 +113,12 @@ const char* l3ac_last_error(void) { return g_last_error.c_str(); }
 int l3ac_abi_version(void) { return L3AC_ABI_VERSION; }
 
 int l3ac_create(const l3ac_config* cfg, const l3ac_tensor* tensors, int32_t n_tensors, int32_t device, l3ac_ctx** out) {
-    L3AC_REQUIRE(cfg && tensors && out && n_tensors > 0, "l3ac_create: null argument");
+    L3AC_REQUIRE(cfg && out, "l3ac_create: null argument");
     *out = nullptr;
+    // first of all: a caller built against another version of the header must hear THAT, not a geometry or weight error
+    L3AC_REQUIRE(cfg->abi_version == L3AC_ABI_VERSION, "l3ac_create: config abi_version %d but this library is ABI %d "
+                 "(fill l3ac_config.abi_version from l3ac_abi_version())", cfg->abi_version, L3AC_ABI_VERSION);
+    L3AC_REQUIRE(tensors && n_tensors > 0, "l3ac_create: no weight tensors");
     int n_dev = 0;
     L3AC_HIP_CHECK(hipGetDeviceCount(&n_dev));
     L3AC_REQUIRE(device >= 0 && device < n_dev, "l3ac_create: device %d out of range (%d visible)", device, n_dev);

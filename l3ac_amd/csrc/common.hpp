@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -39,17 +40,25 @@ void l3ac_set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // Launch-side state that is a property of the DEVICE (function attributes set with hipFuncSetAttribute, the CU count) is
-// kept per device ordinal: the header allows one context per device, i.e. several devices in one process.
+// kept per device ordinal: the header allows one context per device, i.e. several devices in one process.  The flags are
+// atomics (two threads may first-launch on two contexts at once; the configuration they guard is idempotent), and an ordinal
+// outside the table is never folded onto another device's slot: it has no cached state and is configured on every launch.
 constexpr int L3AC_MAX_DEVICES = 64;
-static inline int l3ac_device_slot() {
+static inline int l3ac_device_slot() {  // -1: no slot (hipGetDevice failed or ordinal >= L3AC_MAX_DEVICES)
     int d = 0;
-    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= L3AC_MAX_DEVICES) d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= L3AC_MAX_DEVICES) return -1;
     return d;
 }
 struct PerDeviceOnce {  // `if (once.first()) { ...configure...; once.done(); }` — per device of the calling thread
-    bool flag[L3AC_MAX_DEVICES] = {};
-    bool first() const { return !flag[l3ac_device_slot()]; }
-    void done() { flag[l3ac_device_slot()] = true; }
+    std::atomic<bool> flag[L3AC_MAX_DEVICES] = {};
+    bool first() const {
+        const int s = l3ac_device_slot();
+        return s < 0 || !flag[s].load(std::memory_order_acquire);
+    }
+    void done() {
+        const int s = l3ac_device_slot();
+        if (s >= 0) flag[s].store(true, std::memory_order_release);
+    }
 };
 int l3ac_device_cu_count();  // multiprocessor count of the current device (cached per device; 256 if the query fails)
 static inline int64_t round_up64(int64_t a, int64_t b) { return ceil_div64(a, b) * b; }

@@ -259,12 +259,17 @@ int launch_fsq_t(hipStream_t s, const FsqDev& p) {
     // (2 048 blocks on 6 x 256 places: the last quarter of the work at a third of the bytes in flight).
     const int form = nv == 4 ? 1 : 0;
     const void* fns[2] = {reinterpret_cast<const void*>(fsq_kernel<D, 2>), reinterpret_cast<const void*>(fsq_kernel<D, 4>)};
-    static int per_cu[L3AC_MAX_DEVICES][2] = {};
-    int& resident = per_cu[l3ac_device_slot()][form];
+    // resident workgroups per CU of THIS launch's kernel and LDS size, cached per device as (lds << 8 | count): another feature
+    // width on the same instantiation asks again (the query is a host-side computation)
+    static std::atomic<uint64_t> per_cu[L3AC_MAX_DEVICES][2] = {};
+    const int slot = l3ac_device_slot();
+    const uint64_t cached = slot >= 0 ? per_cu[slot][form].load(std::memory_order_relaxed) : 0;
+    int resident = (cached >> 8) == (uint64_t)lds ? (int)(cached & 0xff) : 0;
     if (resident <= 0) {
         int v = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, fns[form], THREADS, lds) != hipSuccess || v <= 0) v = 3;
         resident = v > 8 ? 8 : v;
+        if (slot >= 0) per_cu[slot][form].store(((uint64_t)lds << 8) | (uint64_t)resident, std::memory_order_relaxed);
     }
     const int64_t places = (int64_t)l3ac_device_cu_count() * resident;
     if (blocks > places) blocks = places;

@@ -13,12 +13,14 @@ from tests.helpers import GOLDEN, index_agreement, index_mismatch_report, load_c
 pytestmark = pytest.mark.gpu
 
 TAU = 1e-4        # a flipped index must come from a latent within TAU of a rounding boundary (in level units)
-# Tolerances = the largest error observed on the MI355X for the cases of this file (profiles/r03/pytest_gpu.log) x 1.3.  The
-# decoder amplifies the ~1e-7 rounding noise of ANY evaluation order to a few 1e-4 at the tanh output.
-WAVE_ATOL = 7.5e-4      # 1 s clips, decoder given identical indices (observed <= 5.6e-4: 1k5bps, 8 clips)
-WAVE_ATOL_LONG = 2e-3   # 6.5 s clips and chunked long audio (observed <= 1.47e-3)
-WAVE_ATOL_ROUTES = 1e-3 # bf16x3 route against exact-fp32 route, same tokens (observed <= 7.7e-4)
-FEAT_ATOL = 1e-5        # encoder / transformer features, activations O(1) (observed <= 6.4e-6)
+# Tolerances = the largest error observed on the MI355X for the cases of this file (profiles/r03/pytest_gpu.log) x ~2: the values
+# come from one box, one hipcc and one seed set, and a different summation order (a new kernel geometry, a compiler update) moves
+# them by tens of % without any defect (round 3 gated at x 1.3).  The decoder amplifies the ~1e-7 rounding noise of ANY evaluation
+# order to a few 1e-4 at the tanh output.  Every test prints what it observed.
+WAVE_ATOL = 1.1e-3      # 1 s clips, decoder given identical indices (observed <= 5.6e-4: 1k5bps, 8 clips)
+WAVE_ATOL_LONG = 3e-3   # 6.5 s clips and chunked long audio (observed <= 1.47e-3)
+WAVE_ATOL_ROUTES = 1.5e-3 # bf16x3 route against exact-fp32 route, same tokens (observed <= 7.7e-4)
+FEAT_ATOL = 1.3e-5      # encoder / transformer features, activations O(1) (observed <= 6.4e-6)
 
 
 def _max_err(name, got, ref):
@@ -113,10 +115,10 @@ def test_encode_decode_against_oracle(tag, seed, batch, samples):
 def gemm_mode(request):
     """Runs a test under one GEMM route: "split" (default: bf16x3 operands on the bf16 matrix cores) or "exact"
     (every product on v_mfma_f32_32x32x2_f32)."""
-    before = l3ac_amd.get_gemm_split()
+    default, routes = l3ac_amd.get_gemm_split(), l3ac_amd.gemm_split_routes()
     l3ac_amd.set_gemm_split(request.param == "split")
     yield request.param
-    l3ac_amd.set_gemm_split(before)
+    l3ac_amd.restore_gemm_split_routes(routes, default=default)  # every live network gets ITS route back, not the default
 
 
 @pytest.mark.parametrize("gemm_mode", ["split", "exact"], indirect=True)
@@ -162,14 +164,14 @@ def test_split_and_exact_gemm_routes_agree():
     codec = _codec("1kbps", 0)
     audio = seeded_audio(8, 16000).cuda()
     out = {}
-    before = l3ac_amd.get_gemm_split()
+    before = codec.network.gemm_split  # this network's own route (its context's state)
     try:
         for mode in (True, False):
-            l3ac_amd.set_gemm_split(mode)
+            codec.network.set_gemm_split(mode)
             q, ind = codec.encode_audio(audio)
             out[mode] = (ind["indices"].cpu(), codec.decode_audio(indices=ind["indices"]).cpu())
     finally:
-        l3ac_amd.set_gemm_split(before)
+        codec.network.set_gemm_split(before)
     n_diff = int((out[True][0] != out[False][0]).sum())
     err = (out[True][1] - out[False][1]).abs().max().item()
     print(f"[split vs exact] token differences {n_diff}/{out[True][0].numel()}, waveform max |diff| {err:.3e}")
@@ -239,10 +241,10 @@ def test_index_agreement_full_batch(tag):
     w = W.folded_weights(codec.network.state_dicts())
     audio = seeded_audio(256, 16000)
     idx_ref, lat_ref = _oracle_indices(w, mc, audio)
-    before = l3ac_amd.get_gemm_split()
+    before = codec.network.gemm_split  # this network's own route (its context's state)
     try:
         for route in (True, False):
-            l3ac_amd.set_gemm_split(route)
+            codec.network.set_gemm_split(route)
             _, ind = codec.encode_audio(audio.cuda())
             rep = index_agreement(ind["indices"].cpu().numpy(), idx_ref.numpy(), lat_ref.numpy(), mc.levels)
             print(f"[index agreement {tag} {'split' if route else 'exact'}] {rep}")
@@ -250,12 +252,12 @@ def test_index_agreement_full_batch(tag):
             assert rep["single_step"] and rep["max_margin_of_mismatches"] < TAU
             assert rep["mismatches"] <= OBSERVED_FULL_BATCH_MISMATCHES[tag] + 1
     finally:
-        l3ac_amd.set_gemm_split(before)
+        codec.network.set_gemm_split(before)
 
 
 # mismatches observed on the MI355X per (config, input set), both GEMM routes (round 3; every one a +-1 flip within TAU)
 OBSERVED_WIDE_MISMATCHES = {}
-OBSERVED_WIDE_WAVE_ERR = 9.5e-4  # structured set, 64 clips, both routes: observed <= 7.2e-4
+OBSERVED_WIDE_WAVE_ERR = 1.4e-3  # structured set, 64 clips, both routes: observed <= 7.2e-4 (x ~2, see WAVE_ATOL)
 
 
 @pytest.mark.parametrize("tag", ["1kbps", "3kbps"])
@@ -271,12 +273,12 @@ def test_index_agreement_other_seeds_and_structured_inputs(tag):
     w = W.folded_weights(codec.network.state_dicts())
     sets = {f"noise seed {sd}": seeded_audio(64, 16000, seed=sd) for sd in (1, 2, 3)}
     sets["structured"], kinds = structured_audio(8, 16000)
-    before = l3ac_amd.get_gemm_split()
+    before = codec.network.gemm_split  # this network's own route (its context's state)
     try:
         for name, audio in sets.items():
             idx_ref, lat_ref = _oracle_indices(w, mc, audio)
             for route in (True, False):
-                l3ac_amd.set_gemm_split(route)
+                codec.network.set_gemm_split(route)
                 _, ind = codec.encode_audio(audio.cuda())
                 rep = index_agreement(ind["indices"].cpu().numpy(), idx_ref.numpy(), lat_ref.numpy(), mc.levels)
                 print(f"[index agreement {tag} {name} {'split' if route else 'exact'}] {rep}")
@@ -291,7 +293,7 @@ def test_index_agreement_other_seeds_and_structured_inputs(tag):
                           + ", ".join(f"{k} {v:.2e}" for k, v in per_kind.items()))
                     assert float(err.max()) < OBSERVED_WIDE_WAVE_ERR
     finally:
-        l3ac_amd.set_gemm_split(before)
+        codec.network.set_gemm_split(before)
 
 
 def test_batch_invariance_3kbps_256():
@@ -357,11 +359,12 @@ def test_decoder_before_tanh_full_size():
     pre_ref = torch.atanh(wave_ref.clamp(-0.999, 0.999))  # where the oracle's tanh has not saturated, atanh recovers its input
     other = _codec("1kbps", 0)  # a second context: the switch is per context and must not reach it
     ctx = codec.network.context()
+    other_before = other.decode_audio(indices=ind_ref["indices"].cuda())
     ctx.set_head_pretanh(True)
     try:
         pre = codec.decode_audio(indices=ind_ref["indices"].cuda()).cpu().double()
-        if other is not codec:
-            assert float(other.decode_audio(indices=ind_ref["indices"].cuda()).abs().max()) <= 1.0
+        # isolation: the other context's output is what it was before the switch, bit for bit (|wave| <= 1 alone could hide a leak)
+        assert torch.equal(other.decode_audio(indices=ind_ref["indices"].cuda()), other_before)
     finally:
         ctx.set_head_pretanh(False)
     wave = codec.decode_audio(indices=ind_ref["indices"].cuda()).cpu().double()

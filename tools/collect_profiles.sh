@@ -8,11 +8,14 @@
 # usage: tools/collect_profiles.sh <outdir under gpurun_out> [workloads...]      (default: all four)
 # The program goes directly after `--` (no env / bash -c hop: the profiler has initialised the GPU by then).
 OUT=$GRAFT_REPO_ROOT/${1:-gpurun_out/prof}
-shift
+[ $# -gt 0 ] && shift
 WL=${@:-main 3kbps b1 vq}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
+# the fingerprint of the sources being profiled is written FIRST: a run cut short by a timeout must not be stamped later with
+# the fingerprint of whatever tree the summary is made on
+python3 -c "import sys; sys.path.insert(0, '$R'); from bench import source_fingerprint; print(source_fingerprint())" > $OUT/source_sha256.txt
 SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"
 for w in $WL; do
     case $w in
@@ -29,5 +32,4 @@ for w in $WL; do
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/pmc_write -- python3 $P > /dev/null 2> $D/pmc_write_err.txt
     rocprofv3 --pmc $SQ --output-format csv -d $D/pmc_sq -- python3 $P > /dev/null 2> $D/pmc_sq_err.txt
 done
-python3 -c "import sys; sys.path.insert(0, '$R'); from bench import source_fingerprint; print(source_fingerprint())" > $OUT/source_sha256.txt
 find $OUT -name "*_kernel_stats.csv" | head -20

@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the fused FSQ kernel (closed form) at large N, next to its own copy ceiling (same grid and per-lane
-accesses, no arithmetic) and a plain device copy.  L3AC_FSQ_OCC=5|6|8 selects the register budget of the kernel (waves per
-SIMD); the launcher reads it once per process, so compare them with one run each."""
+accesses, no arithmetic) and a plain device copy."""
 import ctypes as C
 import os
 import sys
@@ -29,7 +28,6 @@ if __name__ == "__main__":
     lib = _capi.load_library()
     dev = torch.device("cuda")
     s = torch.cuda.current_stream().cuda_stream
-    print(f"L3AC_FSQ_OCC={os.environ.get('L3AC_FSQ_OCC', '(default 8)')}")
     for levels in ([7] * 6, [9, 9, 9, 7, 7, 7]):
         d, feat = len(levels), 128
         lv = (C.c_int32 * d)(*levels)
