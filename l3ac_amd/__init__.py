@@ -397,14 +397,16 @@ def unpack_indices(packed: torch.Tensor, n_tok: int, bits: int) -> torch.Tensor:
     return out
 
 
-def get_model(config_name, model_dir=None, synthetic_seed: Optional[int] = None) -> L3AC:
+def get_model(config_name, model_dir=None, synthetic_seed: Optional[int] = None, synthetic_profile: str = "mild") -> L3AC:
     """reference l3ac/__init__.py:21-25.  ``config_name`` is a shipped model name (``list_models()``) or a path
     to a TOML file of the same schema.  Weights come from ``{model_dir}/{name}.{version}/*.pt`` (default
-    ``~/.cache/l3ac``, the reference's cache), or — with ``synthetic_seed`` — from the seeded generator."""
+    ``~/.cache/l3ac``, the reference's cache), or — with ``synthetic_seed`` — from the seeded generator
+    (``synthetic_profile``: "mild", or "stress" = the statistics of a trained network, see ``weights.synthetic_state_dicts``)."""
     overrides = {} if model_dir is None else {"model_dir": Path(model_dir)}
     codec = L3AC(L3ACConfig(config_file=resolve_config_file(config_name), **overrides))
     if synthetic_seed is not None:
-        codec.network.load_state_dicts(_weights.synthetic_state_dicts(codec.config.network_config, seed=synthetic_seed))
+        codec.network.load_state_dicts(_weights.synthetic_state_dicts(codec.config.network_config, seed=synthetic_seed,
+                                                                      profile=synthetic_profile))
     else:
         codec.load_pretrained()
     return codec

@@ -180,20 +180,33 @@ def raw_keys(mc, module: str) -> list[tuple[str, tuple]]:
 # ---------------------------------------------------------------------------------------------
 # seeded synthetic weights (no network on either box: SURVEY F5)
 # ---------------------------------------------------------------------------------------------
-def synthetic_state_dicts(mc, seed: int = 0, gain: float = 0.8) -> dict[str, dict[str, torch.Tensor]]:
+def synthetic_state_dicts(mc, seed: int = 0, gain: float = 0.8, profile: str = "mild") -> dict[str, dict[str, torch.Tensor]]:
     """Deterministic random weights in the reference's file format.
 
-    Weight-normed tensors follow the reference initialiser (trunc-normal std .02, layers.py:15) but with a
-    perturbed gain ``g`` and non-zero biases; parameters the reference initialises to 0/1 (norm affine,
-    snake alpha, GRN gamma/beta) are perturbed too, so that a bug in any of them is visible in parity tests.
-    """
-    gen = torch.Generator(device="cpu").manual_seed(1_000_003 * (seed + 1))
+    ``profile="mild"`` (every fixture and test of rounds 1-3): weight-normed tensors follow the reference initialiser
+    (trunc-normal std .02, layers.py:15) but with a perturbed gain ``g`` and non-zero biases; parameters the reference
+    initialises to 0/1 (norm affine, snake alpha, GRN gamma/beta) are perturbed too, so that a bug in any of them is visible
+    in parity tests.
+
+    ``profile="stress"`` stands in for the statistics of a TRAINED network, which the mild profile does not reach (no pretrained
+    weights can be had offline): weight-norm gains with a heavy tail (a quarter of the output channels x 4), snake alpha
+    log-uniform in [0.05, 20] (layers.py:29-47 — far from its init of 1: large sine arguments and large 1/alpha), GRN gamma / beta
+    ~ N(0, 1) (layers.py:101-102 initialises them to 0: the mild profile's 0.1 leaves GRN nearly an identity), heavy-tailed
+    biases, norm affines far from (1, 0), and a quantiser ``project_in`` scaled up until a good part of the latents sit in
+    tanh's saturation (vq/fsq_act.py:38-39), i.e. at the outermost levels."""
+    if profile not in ("mild", "stress"):
+        raise ValueError(f"unknown weight profile {profile!r}")
+    stress = profile == "stress"
+    gen = torch.Generator(device="cpu").manual_seed(1_000_003 * (seed + 1) + (7919 if stress else 0))
 
     def randn(shape, std=1.0):
         return torch.randn(shape, generator=gen, dtype=torch.float32) * std
 
     def uniform(shape, bound):
         return (torch.rand(shape, generator=gen, dtype=torch.float32) * 2 - 1) * bound
+
+    def rand(shape):
+        return torch.rand(shape, generator=gen, dtype=torch.float32)
 
     out = {}
     for module in MODULE_NAMES:
@@ -203,18 +216,30 @@ def synthetic_state_dicts(mc, seed: int = 0, gain: float = 0.8) -> dict[str, dic
                 v = randn(shape, 0.02).clamp_(-0.04, 0.04)
                 # ||w_row|| = g: a gain near 1 keeps a unit-variance input at roughly unit variance
                 g_shape = (shape[0],) + (1,) * (len(shape) - 1)
-                g = gain * (0.75 + 0.5 * torch.rand(g_shape, generator=gen, dtype=torch.float32))
-                sd[f"{key}.bias"] = randn((shape[0],), 0.05)
+                g = gain * (0.75 + 0.5 * rand(g_shape))
+                bias = randn((shape[0],), 0.05)
+                if stress:
+                    # a quarter of the output channels at 4 x the gain of the rest, the layer's rms gain unchanged (x 4 on top of
+                    # the mild gains compounds to 1e2 at the quantiser and a waveform that is 90 % tanh-saturated)
+                    g = g * torch.where(rand(g_shape) < 0.25, 4.0, 1.0) / (0.75 + 0.25 * 16.0) ** 0.5
+                    bias = 0.4 * bias * (1.0 + 9.0 * (rand((shape[0],)) < 0.1).float()) / rand((shape[0],)).clamp_min(0.05).sqrt()
+                sd[f"{key}.bias"] = bias
                 sd[f"{key}.parametrizations.weight.original0"] = g.contiguous()
                 sd[f"{key}.parametrizations.weight.original1"] = v.contiguous()
             elif kind == "norm_w":
-                sd[key] = 1.0 + randn(shape, 0.1)
+                sd[key] = 1.0 + randn(shape, 0.5 if stress else 0.1)
             elif kind == "norm_b":
-                sd[key] = randn(shape, 0.05)
+                sd[key] = randn(shape, 0.1 if stress else 0.05)
             elif kind == "alpha":
-                sd[key] = (1.0 + randn(shape, 0.25)).clamp_(0.3, 2.5)
+                if stress:
+                    lo, hi = torch.log(torch.tensor(0.05)), torch.log(torch.tensor(20.0))
+                    sd[key] = torch.exp(lo + (hi - lo) * rand(shape))
+                else:
+                    sd[key] = (1.0 + randn(shape, 0.25)).clamp_(0.3, 2.5)
             elif kind == "grn":
-                sd[key] = randn(shape, 0.1)
+                # stress: gamma ~ N(0, 1); beta ~ N(0, 0.3) — a per-channel constant of O(1) on 4C hidden channels drowns the signal
+                # (measured: frame-to-frame variation of the encoder output 0.13 against channel means of 1.1)
+                sd[key] = randn(shape, (1.0 if key.endswith("gamma") else 0.3) if stress else 0.1)
             elif kind == "plain_w":
                 fan_in = 1
                 for s in shape[1:]:
@@ -224,8 +249,15 @@ def synthetic_state_dicts(mc, seed: int = 0, gain: float = 0.8) -> dict[str, dic
                 sd[key] = uniform(shape, int(kind.split(":")[1]) ** -0.5)
             else:  # pragma: no cover
                 raise AssertionError(kind)
+        if stress and module == "quantizer":
+            sd["project_in.weight"] = sd["project_in.weight"] * STRESS_PROJECT_IN_SCALE
         out[module] = sd
     return out
+
+
+# project_in (vq/__init__.py:14) scale of the stress profile: chosen so that >= 10 % of the latents of the seeded 1kbps / 3kbps
+# models land on an outermost level (tests/golden/make_golden.py prints and asserts the fraction)
+STRESS_PROJECT_IN_SCALE = 1.5
 
 
 # ---------------------------------------------------------------------------------------------

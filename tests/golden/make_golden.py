@@ -8,6 +8,8 @@ What is pinned (see oracle/l3ac_oracle.py docstring):
   * ``*_conv.npz``   — reference ``Codec`` (encoder / quantizer / to_features / decoder) outputs, produced by
                        reference code only.  Weights come from l3ac_amd.weights.synthetic_state_dicts and are
                        loaded into the reference with ``load_state_dict(strict=True)`` (also pins the schema).
+                       ``stress_*``: the same with ``synthetic_state_dicts(profile="stress")`` — heavy-tailed gains, snake alpha in
+                       [0.05, 20], GRN gamma / beta of O(1), saturating latents: the statistics of a trained network.
   * ``*_e2e.npz``    — reference ``EnCodec`` wiring (l3ac/local_trans.py, en_codec.py) run end to end, with the
                        absent PyPI dependency ``local_attention`` replaced by a stand-in built on the oracle's
                        own restatement.  Pins the WIRING only; the attention arithmetic stays unpinned.
@@ -102,13 +104,13 @@ def seeded_audio(batch, samples, seed=1234):
     return (torch.rand(batch, samples, generator=g) * 2 - 1) * 0.5
 
 
-def build_reference(cfg_file, seed):
+def build_reference(cfg_file, seed, profile="mild"):
     cfg = L3ACConfig(config_file=cfg_file)
     mc = cfg.network_config
     ref_mc = l3ac.en_codec.ModelConfig(**mc.model_dump(exclude={"hop_length"}))
     assert ref_mc.hop_length == mc.hop_length
     ref = l3ac.en_codec.EnCodec(ref_mc).eval()
-    sds = W.synthetic_state_dicts(mc, seed=seed)
+    sds = W.synthetic_state_dicts(mc, seed=seed, profile=profile)
     for name, module in ref.trainable_modules.items():
         want = {k: tuple(v.shape) for k, v in module.state_dict().items()}
         have = dict(W.raw_keys(mc, name))
@@ -124,10 +126,11 @@ def strided(t, n=4096):
 
 
 @torch.inference_mode()
-def make_model_fixtures(tag, cfg_file, seed, batch, samples, full_tensors):
-    mc, ref, _ = build_reference(cfg_file, seed)
+def make_model_fixtures(tag, cfg_file, seed, batch, samples, full_tensors, profile="mild"):
+    mc, ref, _ = build_reference(cfg_file, seed, profile)
     audio = seeded_audio(batch, samples)
-    out = {"seed": np.int64(seed), "audio_seed": np.int64(1234), "batch": np.int64(batch), "samples": np.int64(samples)}
+    out = {"seed": np.int64(seed), "audio_seed": np.int64(1234), "batch": np.int64(batch), "samples": np.int64(samples),
+           "profile": np.array(profile)}
 
     # ---- conv stacks + quantiser: reference code only ------------------------------------------------
     x, length = ref.preprocess(audio)
@@ -187,6 +190,11 @@ def make_model_fixtures(tag, cfg_file, seed, batch, samples, full_tensors):
             e2e[k + "_shape"] = np.array(v.shape, dtype=np.int64)
     np.savez_compressed(HERE / f"{tag}_e2e.npz", **e2e)
     hist = np.bincount(ind2["level_indices"].numpy().astype(np.int64).reshape(-1), minlength=max(mc.levels))
+    if profile == "stress":  # the profile's promise (l3ac_amd/weights.py): a good part of the latents at an outermost level
+        li, lv = ind2["level_indices"], torch.tensor(mc.levels, dtype=torch.float32)
+        sat = float(((li == 0) | (li == lv - 1)).float().mean())
+        print(f"[{tag}] outermost-level fraction {sat:.3f}")
+        assert sat >= 0.10
     print(f"[{tag}] hop={mc.hop_length} tokens={ind2['indices'].shape} wave std={wave2.std():.4f} "
           f"|wave|max={wave2.abs().max():.4f} level hist={hist.tolist()}")
 
@@ -385,6 +393,10 @@ if __name__ == "__main__":
     if "--chunk-only" in sys.argv:
         make_chunk_kat()
         sys.exit(0)
+    if "--stress-only" in sys.argv:
+        for name in ("1kbps", "3kbps"):
+            make_model_fixtures(f"stress_{name}", resolve_config_file(name), seed=0, batch=2, samples=16000, full_tensors=False, profile="stress")
+        sys.exit(0)
     make_chunk_kat()
     make_binding_fixture()
     make_fsq_kat()
@@ -392,3 +404,5 @@ if __name__ == "__main__":
     make_model_fixtures("tiny", HERE / "tiny.toml", seed=3, batch=2, samples=250, full_tensors=True)
     make_model_fixtures("1kbps", resolve_config_file("1kbps"), seed=0, batch=2, samples=16000, full_tensors=False)
     make_model_fixtures("3kbps", resolve_config_file("3kbps"), seed=0, batch=2, samples=16000, full_tensors=False)
+    for name in ("1kbps", "3kbps"):  # trained-weight statistics stand-in (weights.synthetic_state_dicts(profile="stress"))
+        make_model_fixtures(f"stress_{name}", resolve_config_file(name), seed=0, batch=2, samples=16000, full_tensors=False, profile="stress")

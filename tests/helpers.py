@@ -60,11 +60,14 @@ def structured_audio(per_kind, samples, seed=4321, sample_rate=16000):
 
 def load_case(tag):
     """(mc, folded weights, conv fixture, e2e fixture) for a golden case; weights regenerate from the seed."""
-    cfg_file = GOLDEN / "tiny.toml" if tag == "tiny" else resolve_config_file(tag)
+    name = tag[len("stress_"):] if tag.startswith("stress_") else tag  # stress_<config>: the trained-statistics weight profile
+    cfg_file = GOLDEN / "tiny.toml" if name == "tiny" else resolve_config_file(name)
     mc = L3ACConfig(config_file=cfg_file).network_config
     conv = np.load(GOLDEN / f"{tag}_conv.npz")
     e2e = np.load(GOLDEN / f"{tag}_e2e.npz")
-    sds = W.synthetic_state_dicts(mc, seed=int(conv["seed"]))
+    profile = str(conv["profile"]) if "profile" in conv.files else "mild"
+    assert profile == ("stress" if tag.startswith("stress_") else "mild")
+    sds = W.synthetic_state_dicts(mc, seed=int(conv["seed"]), profile=profile)
     return mc, W.folded_weights(sds), conv, e2e
 
 

@@ -30,9 +30,12 @@ def _max_err(name, got, ref):
     return e
 
 
-def _codec(tag, seed):
+def _codec(tag, seed, grn_exact=False):
+    profile = "stress" if tag.startswith("stress_") else "mild"  # stress_<config>: trained-weight statistics (weights.py)
+    tag = tag[len("stress_"):] if profile == "stress" else tag
     cfg = GOLDEN / f"{tag}.toml" if tag in ("tiny", "refdefault") else tag  # refdefault: the reference ModelConfig's default geometry
-    codec = l3ac_amd.get_model(cfg, synthetic_seed=seed)
+    codec = l3ac_amd.get_model(cfg, synthetic_seed=seed, synthetic_profile=profile)
+    codec.network.grn_exact = grn_exact
     codec.network.to(device="cuda").eval()
     return codec
 
@@ -122,9 +125,10 @@ def gemm_mode(request):
 
 
 @pytest.mark.parametrize("gemm_mode", ["split", "exact"], indirect=True)
-@pytest.mark.parametrize("tag", ["tiny", "1kbps", "3kbps"])
+@pytest.mark.parametrize("tag", ["tiny", "1kbps", "3kbps", "stress_1kbps", "stress_3kbps"])
 def test_against_committed_reference_vectors(tag, gemm_mode):
-    """tests/golden/*_e2e.npz were produced by the reference's own EnCodec wiring (see make_golden.py)."""
+    """tests/golden/*_e2e.npz were produced by the reference's own EnCodec wiring (see make_golden.py); stress_*: the same with
+    the trained-statistics weight profile."""
     mc, w, conv, e2e = load_case(tag)
     codec = _codec(tag, int(e2e["seed"]))
     audio = seeded_audio(int(e2e["batch"]), int(e2e["samples"]))
@@ -148,7 +152,9 @@ def test_against_committed_reference_vectors(tag, gemm_mode):
         assert _max_err(f"{tag} {gemm_mode} encoder feature vs reference vector", feat.numpy(), conv["feature"]) < FEAT_ATOL
         q_feat = torch.from_numpy(conv["q_feat"])
     else:
-        assert _max_err(f"{tag} {gemm_mode} encoder feature vs reference vector", strided(feat).numpy(), conv["feature_strided"]) < FEAT_ATOL
+        # FEAT_ATOL is for activations of O(1) (mild profile: max |feature| ~ 3); the stress profile's reach 10
+        tol = FEAT_ATOL * max(1.0, float(np.abs(conv["feature_strided"]).max()) / 3.0)
+        assert _max_err(f"{tag} {gemm_mode} encoder feature vs reference vector", strided(feat).numpy(), conv["feature_strided"]) < tol
         q_feat = O.to_features(w, mc, torch.from_numpy(conv["indices"]))
     wave = G.op_plain(ctx, "l3ac_op_decoder", q_feat.cuda().contiguous(), q_feat.shape[0], q_feat.shape[1],
                       (q_feat.shape[0], q_feat.shape[1] * enc_rate)).cpu()
@@ -253,6 +259,76 @@ def test_index_agreement_full_batch(tag):
             assert rep["mismatches"] <= OBSERVED_FULL_BATCH_MISMATCHES[tag] + 1
     finally:
         codec.network.set_gemm_split(before)
+
+
+# observed on the MI355X with the stress profile (round 4; printed by the test): index mismatches per (config, route) and the
+# largest waveform error given identical indices
+OBSERVED_STRESS_MISMATCHES = {}
+STRESS_WAVE_ATOL = 3.7e-3  # observed <= 1.84e-3 (stress_1kbps, split route, 48 clips, unsaturated output)
+
+
+@pytest.mark.parametrize("tag", ["stress_1kbps", "stress_3kbps"])
+def test_parity_under_trained_weight_statistics(tag):
+    """VERDICT r3 item 7.  Every other parity number is on the mild synthetic weights (trunc-normal 0.02, parameters near their
+    init).  A trained network has what that profile lacks — weight-norm gains with a heavy tail, snake alpha far from 1 (large sine
+    arguments, large 1/alpha), GRN gamma / beta of O(1), heavy-tailed biases, latents in tanh's saturation: `profile="stress"`
+    (l3ac_amd/weights.py; oracle pinned to the reference on these weights by tests/golden/stress_*.npz).  32 noise clips + 16
+    structured clips, both GEMM routes: index agreement with the oracle (flips reported with their margins), waveform error given
+    identical indices, how far the snake arguments go (the +-1e5 clamp of the kernels' sine), and the GRN fast path's guard."""
+    from tests.helpers import structured_audio
+    codec = _codec(tag, 0)
+    mc = codec.network.mc
+    w = W.folded_weights(codec.network.state_dicts())
+    audio = torch.cat([seeded_audio(32, 16000, seed=11), structured_audio(2, 16000, seed=12)[0]])
+    seen = {"max_arg": 0.0, "over_clamp": 0, "n": 0}
+    orig_snake = O.snake
+
+    def counting_snake(x, alpha):
+        a = (x * alpha).abs()
+        seen["max_arg"] = max(seen["max_arg"], float(a.max()))
+        seen["over_clamp"] += int((a > 1e5).sum())
+        seen["n"] += a.numel()
+        return orig_snake(x, alpha)
+    O.snake = counting_snake
+    try:
+        idx_ref, lat_ref = _oracle_indices(w, mc, audio)
+        wave_ref = torch.cat([O.decode_audio(w, mc, indices=idx_ref[b0:b0 + ORACLE_CHUNK]) for b0 in range(0, len(idx_ref), ORACLE_CHUNK)])
+    finally:
+        O.snake = orig_snake
+    print(f"[{tag}] snake arguments seen by the oracle: max |alpha x| = {seen['max_arg']:.1f} over {seen['n']} evaluations, "
+          f"{seen['over_clamp']} beyond the kernels' 1e5 clamp")
+    assert seen["over_clamp"] == 0  # were it ever non-zero the clamp's 1e-5 relative bound (DESIGN §4) would be what is compared
+    lv = torch.tensor(mc.levels)
+    li = (idx_ref.unsqueeze(-1) // torch.tensor(np.concatenate([[1], np.cumprod(mc.levels[:-1])]))) % lv
+    sat = float(((li == 0) | (li == lv - 1)).float().mean())
+    print(f"[{tag}] latents: std {float(lat_ref.std()):.2f}, max |z| {float(lat_ref.abs().max()):.2f}, outermost-level fraction {sat:.3f}")
+    assert sat >= 0.10
+    before = codec.network.gemm_split
+    try:
+        for route in (True, False):
+            name = "split" if route else "exact"
+            codec.network.set_gemm_split(route)
+            _, ind = codec.encode_audio(audio.cuda())
+            rep = index_agreement(ind["indices"].cpu().numpy(), idx_ref.numpy(), lat_ref.numpy(), mc.levels)
+            print(f"[index agreement {tag} {name}] {rep}")
+            assert rep["single_step"] and rep["max_margin_of_mismatches"] < TAU
+            assert rep["mismatches"] <= OBSERVED_STRESS_MISMATCHES.get((tag, name), 0) + 1
+            wave = codec.decode_audio(indices=idx_ref.cuda()).cpu()
+            err = (wave - wave_ref).abs()
+            print(f"[{tag} {name}] waveform given identical indices: max|err| {float(err.max()):.3e} rms {float(err.pow(2).mean().sqrt()):.3e} "
+                  f"(|wave| max {float(wave_ref.abs().max()):.3f}, {float((wave_ref.abs() > 0.999).float().mean()):.3f} saturated)")
+            assert float(err.max()) < STRESS_WAVE_ATOL
+    finally:
+        codec.network.set_gemm_split(before)
+    # the GRN fast path (n = g / (g + 1e-8) taken as 1) under gamma / beta of O(1): the validation mode evaluates the literal formula,
+    # must give the same tokens, and its smallest per-clip norm must stay above the 0.25 at which the two are bit-identical
+    exact = _codec(tag, 0, grn_exact=True)
+    _, ind_x = exact.encode_audio(audio.cuda())
+    exact.decode_audio(indices=ind_x["indices"])
+    g_min = exact.network.min_grn_norm()
+    _, ind_f = codec.encode_audio(audio.cuda())
+    print(f"[{tag}] smallest GRN norm {g_min:.3f}; tokens of the fast path equal the literal formula's: {bool(torch.equal(ind_x['indices'], ind_f['indices']))}")
+    assert g_min >= 0.25 and torch.equal(ind_x["indices"], ind_f["indices"])
 
 
 # mismatches observed on the MI355X per (config, input set), both GEMM routes (round 3; every one a +-1 flip within TAU)

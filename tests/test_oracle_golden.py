@@ -20,7 +20,7 @@ def _check(name, got, fx, full):
         assert abs(got.double().abs().sum().item() - float(fx[name + "_abssum"])) <= 1e-5 * float(fx[name + "_abssum"]) + 1e-3
 
 
-@pytest.mark.parametrize("tag", ["tiny", "1kbps", "3kbps"])
+@pytest.mark.parametrize("tag", ["tiny", "1kbps", "3kbps", "stress_1kbps", "stress_3kbps"])
 def test_conv_stacks_and_quantizer_match_reference(tag):
     mc, w, conv, _ = load_case(tag)
     full = tag == "tiny"
@@ -64,7 +64,7 @@ def test_tiny_per_block_outputs_match_reference():
         np.testing.assert_allclose(dt["dec.up1"].numpy(), conv["dec_block6"], atol=ATOL, rtol=RTOL)
 
 
-@pytest.mark.parametrize("tag", ["tiny", "1kbps", "3kbps"])
+@pytest.mark.parametrize("tag", ["tiny", "1kbps", "3kbps", "stress_1kbps", "stress_3kbps"])
 def test_end_to_end_wiring_matches_reference(tag):
     """Reference EnCodec wiring (local_trans.py) with the stand-in attention: pins wiring, not attention maths."""
     mc, w, conv, e2e = load_case(tag)
