@@ -511,7 +511,8 @@ def fsq_microbench(codec, dev, n_tokens=1 << 22):
         cms = e0.elapsed_time(e1) / reps
         cgbs = n_tokens * bytes_per_token / cms / 1e6
         out["copy_ceiling"] = {"achieved": cgbs, "unit": "GB/s", "frac_of_peak": cgbs / PEAK_HBM_GBS, "ms": cms,
-                               "what": "fsq_copy_ceiling_kernel: fsq_kernel's grid and per-lane loads / stores, no arithmetic"}
+                               "what": "fsq_copy_ceiling_kernel: fsq_kernel's grid (3 workgroups per CU), token order and per-lane "
+                                       "non-temporal loads / stores incl. the 4-B and 24-B side outputs, no arithmetic"}
         out["frac_of_copy_ceiling"] = gbs / cgbs
     return out
 

@@ -67,12 +67,41 @@ __device__ __forceinline__ void nt_store4(float* p, const float4& v) {
 
 // Every mode: forward, quantise-from-activations, decode-from-indices, latents in / out; any feat = 8 * 2^j.
 // NV 16-byte chunks (4 channels each) per lane: lanes per token = feat / (4 NV).
-// Round 3 measurements (profiles/r03/fsq_notes.md): hipcc keeps the 2 D NV projection-weight quads of a lane in registers across
-// the token loop (158 registers, 3 blocks per CU).  A variant that re-read them from LDS at 64-96 registers and 4 / 6 / 8 blocks
-// per CU was SLOWER (4.75 / 4.75 / 4.42 vs 4.83 TB/s): the kernel is bound by the instructions of an iteration, not by bytes in
-// flight.  What did pay: one resident round (the 2 048-block grid left the last round a third full) and the level indices as
-// ONE contiguous store per wave.  The same grid and accesses with no arithmetic (fsq_copy_ceiling_kernel) reach 5.15 TB/s on the
-// same box, a plain copy in this access pattern 5.3-5.6, hipMemcpy 4.8-5.2: the kernel runs at 0.93-0.94 of its own ceiling.
+// Round 3 measurements (profiles/r03/fsq_notes.md): hipcc keeps most of the 2 D NV projection-weight quads of a lane in registers
+// across the token loop (158 registers, 3 blocks per CU).  A variant that re-read them from LDS at 64-96 registers and 4 / 6 / 8
+// blocks per CU was SLOWER: removed.  What paid: one resident round, the level indices as ONE contiguous store per wave, and
+// (round 4, profiles/r04/fsq_notes.md) the ORDER in which the chip walks the tokens + non-temporal accesses: 4.97 -> 5.46 TB/s.
+// Access order and cache policy of the streamed rows (round 4, tools/probes/fsq_pattern_probe.hip: the quantiser's traffic with no
+// arithmetic, by how tokens are dealt to blocks / waves / lanes).  Build-time switches so that variants can be timed side by side
+// as tagged builds (L3AC_BUILD_TAG + L3AC_EXTRA_HIPCC_FLAGS); the defaults are what the library ships.
+//   L3AC_FSQ_ORDER 0: every block walks one contiguous token range; 1: grid-stride (block b takes groups b, b + G, ...: the chip
+//                  sweeps one compact window of memory at a time); 3: grid-stride inside each XCD's own eighth of the tokens
+//   L3AC_FSQ_NT    bit 0: non-temporal loads of x, bit 1: non-temporal stores of q_feature, bit 2: of indices / level indices
+#ifndef L3AC_FSQ_ORDER
+#define L3AC_FSQ_ORDER 1
+#endif
+#ifndef L3AC_FSQ_NT
+#define L3AC_FSQ_NT 7
+#endif
+template <typename T>
+__device__ __forceinline__ void side_store(T* p, T v) {
+    if (L3AC_FSQ_NT & 4) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+// the it-th token group of block `b` of `G` (n_groups = none left)
+__device__ __forceinline__ int64_t fsq_group_at(int64_t it, int64_t b, int64_t G, int64_t n_groups) {
+    if (L3AC_FSQ_ORDER == 0) {
+        const int64_t per_block = (n_groups + G - 1) / G;
+        return it < per_block && b * per_block + it < n_groups ? b * per_block + it : n_groups;
+    }
+    if (L3AC_FSQ_ORDER == 3 && (G & 7) == 0 && n_groups >= 8 * G) {
+        const int64_t span = (n_groups + 7) / 8, j = it * (G >> 3) + (b >> 3), g = (b & 7) * span + j;
+        return j < span && g < n_groups ? g : n_groups;
+    }
+    const int64_t g = it * G + b;
+    return g < n_groups ? g : n_groups;
+}
+
 template <int D, int NV>
 __global__ __launch_bounds__(THREADS) void fsq_kernel(const FsqDev p, const int lpt) {
     const int feat = p.feat;
@@ -100,9 +129,6 @@ __global__ __launch_bounds__(THREADS) void fsq_kernel(const FsqDev p, const int 
     const int cq = 4 * sub, cstep = 4 * lpt;
     const int tok_per_block = THREADS / lpt;
     const int64_t n_groups = (p.n + tok_per_block - 1) / tok_per_block;
-    const int64_t per_block = (n_groups + gridDim.x - 1) / gridDim.x;  // contiguous token range per block
-    const int64_t g_begin = (int64_t)blockIdx.x * per_block;
-    const int64_t g_end = g_begin + per_block < n_groups ? g_begin + per_block : n_groups;
     const bool spread = lpt >= D;       // one latent per lane; otherwise every lane quantises all D
 
     float4 x_next[NV];
@@ -110,24 +136,30 @@ __global__ __launch_bounds__(THREADS) void fsq_kernel(const FsqDev p, const int 
     for (int v = 0; v < NV; ++v) x_next[v] = make_float4(0.f, 0.f, 0.f, 0.f);
     auto fetch = [&](int64_t g) {
         const int64_t t = g * tok_per_block + tid / lpt;
-        if (p.x && g < g_end && t < p.n) {
+        if (p.x && g < n_groups && t < p.n) {
 #pragma unroll
-            for (int v = 0; v < NV; ++v) x_next[v] = *reinterpret_cast<const float4*>(p.x + t * feat + cq + cstep * v);
+            for (int v = 0; v < NV; ++v) {
+                const float* src = p.x + t * feat + cq + cstep * v;
+                x_next[v] = (L3AC_FSQ_NT & 1) ? nt_load4(src) : *reinterpret_cast<const float4*>(src);
+            }
         }
     };
     auto quantise = [&](float lat, int d) -> float {
         const float act = p.act_in ? lat : (tanhf(lat) + 1.0f) * 0.5f;  // fsq_act.py:39
         return rintf(__fmul_rn(act, (float)(p.levels[d] - 1)));       // vq/fsq.py:59 (half-to-even)
     };
-    fetch(g_begin);
-    for (int64_t g = g_begin; g < g_end; ++g) {
+    int64_t g_next = fsq_group_at(0, blockIdx.x, gridDim.x, n_groups);
+    fetch(g_next);
+    for (int64_t it = 0; g_next < n_groups; ++it) {
+        const int64_t g = g_next;
         const int64_t tok = g * tok_per_block + tid / lpt;
         const bool ok = tok < p.n;
         const int64_t tk = ok ? tok : 0;
         float4 xv[NV];
 #pragma unroll
         for (int v = 0; v < NV; ++v) xv[v] = x_next[v];
-        fetch(g + 1);
+        g_next = fsq_group_at(it + 1, blockIdx.x, gridDim.x, n_groups);
+        fetch(g_next);
         float li[D];
         float li_mine = 0.f;  // spread mode: level index `sub` of this token (lanes sub < D)
         if (p.idx_in) {  // decode: indices -> level indices (vq/fsq.py:70-71)
@@ -193,16 +225,19 @@ __global__ __launch_bounds__(THREADS) void fsq_kernel(const FsqDev p, const int 
         if (ok) {
             float* dst = p.q_feature + tok * feat + cq;
 #pragma unroll
-            for (int v = 0; v < NV; ++v) *reinterpret_cast<float4*>(dst + cstep * v) = o[v];
-            if (sub == 0 && p.indices) p.indices[tok] = (int32_t)idx_f;
+            for (int v = 0; v < NV; ++v) {
+                if (L3AC_FSQ_NT & 2) nt_store4(dst + cstep * v, o[v]);
+                else *reinterpret_cast<float4*>(dst + cstep * v) = o[v];
+            }
+            if (sub == 0 && p.indices) side_store(p.indices + tok, (int32_t)idx_f);
             if (p.level_indices) {
                 if (spread && !p.idx_in) {
                     // lane d of the token's group holds level index d: ONE store instruction per wave, the tokens' D values
                     // contiguous (a wave's tokens are consecutive: 8 x 24 B in a row) instead of D scattered 4-byte stores
-                    if (sub < D) p.level_indices[tok * D + sub] = li_mine;
+                    if (sub < D) side_store(p.level_indices + tok * D + sub, li_mine);
                 } else if (sub == 0) {
 #pragma unroll
-                    for (int d = 0; d < D; ++d) p.level_indices[tok * D + d] = li[d];
+                    for (int d = 0; d < D; ++d) side_store(p.level_indices + tok * D + d, li[d]);
                 }
             }
         }
@@ -211,37 +246,42 @@ __global__ __launch_bounds__(THREADS) void fsq_kernel(const FsqDev p, const int 
 
 // The ceiling fsq_kernel is measured against: the same grid, the same per-lane access pattern (4 x 16 B loads per lane one
 // token group ahead, 4 x 16 B stores, 4 B per token of indices, 24 B per token of level indices) and NO arithmetic.
-__global__ __launch_bounds__(THREADS, 8) void fsq_copy_ceiling_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ q,
-                                                                    int32_t* __restrict__ idx, float* __restrict__ li) {
+__global__ __launch_bounds__(THREADS) void fsq_copy_ceiling_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ q,
+                                                                 int32_t* __restrict__ idx, float* __restrict__ li) {
     constexpr int FEAT = 128, NV = 4, LPT = 8, D = 6, TPB = THREADS / LPT;
     const int tid = threadIdx.x, sub = tid % LPT;
     const int cq = 4 * sub, cstep = 4 * LPT;
     const int64_t n_groups = (n + TPB - 1) / TPB;
-    const int64_t per_block = (n_groups + gridDim.x - 1) / gridDim.x;
-    const int64_t g_begin = (int64_t)blockIdx.x * per_block;
-    const int64_t g_end = g_begin + per_block < n_groups ? g_begin + per_block : n_groups;
     float4 nxt[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) nxt[v] = make_float4(0.f, 0.f, 0.f, 0.f);
     auto fetch = [&](int64_t g) {
         const int64_t t = g * TPB + tid / LPT;
-        if (g < g_end && t < n) {
+        if (g < n_groups && t < n) {
 #pragma unroll
-            for (int v = 0; v < NV; ++v) nxt[v] = *reinterpret_cast<const float4*>(x + t * FEAT + cq + cstep * v);
+            for (int v = 0; v < NV; ++v) {
+                const float* src = x + t * FEAT + cq + cstep * v;
+                nxt[v] = (L3AC_FSQ_NT & 1) ? nt_load4(src) : *reinterpret_cast<const float4*>(src);
+            }
         }
     };
-    fetch(g_begin);
-    for (int64_t g = g_begin; g < g_end; ++g) {
-        const int64_t tok = g * TPB + tid / LPT;
+    int64_t g_next = fsq_group_at(0, blockIdx.x, gridDim.x, n_groups);
+    fetch(g_next);
+    for (int64_t it = 0; g_next < n_groups; ++it) {
+        const int64_t tok = g_next * TPB + tid / LPT;
         float4 cur[NV];
 #pragma unroll
         for (int v = 0; v < NV; ++v) cur[v] = nxt[v];
-        fetch(g + 1);
+        g_next = fsq_group_at(it + 1, blockIdx.x, gridDim.x, n_groups);
+        fetch(g_next);
         if (tok < n) {
 #pragma unroll
-            for (int v = 0; v < NV; ++v) *reinterpret_cast<float4*>(q + tok * FEAT + cq + cstep * v) = cur[v];
-            if (sub == 0) idx[tok] = __float_as_int(cur[0].x);
-            if (sub < D) li[tok * D + sub] = cur[0].y;
+            for (int v = 0; v < NV; ++v) {
+                if (L3AC_FSQ_NT & 2) nt_store4(q + tok * FEAT + cq + cstep * v, cur[v]);
+                else *reinterpret_cast<float4*>(q + tok * FEAT + cq + cstep * v) = cur[v];
+            }
+            if (sub == 0) side_store(idx + tok, __float_as_int(cur[0].x));
+            if (sub < D) side_store(li + tok * D + sub, cur[0].y);
         }
     }
 }
@@ -965,7 +1005,10 @@ int launch_fsq(hipStream_t s, const FsqArgs& a) {
 int launch_fsq_copy_ceiling(hipStream_t s, const float* x, int64_t n, float* q, int32_t* idx, float* li) {
     L3AC_REQUIRE(x && q && idx && li && n > 0, "fsq_copy_ceiling: bad arguments");
     int64_t blocks = ceil_div64(n, THREADS / 8);
-    const int64_t places = (int64_t)l3ac_device_cu_count() * 8;
+#ifndef L3AC_FSQ_CEILING_PER_CU
+#define L3AC_FSQ_CEILING_PER_CU 3  // the quantiser kernel's own residency (register-bound): the ceiling of ITS launch shape
+#endif
+    const int64_t places = (int64_t)l3ac_device_cu_count() * L3AC_FSQ_CEILING_PER_CU;
     if (blocks > places) blocks = places;
     ProfScope prof(s, "fsq_copy_ceiling_kernel", 0.0, (double)n * 1052.0);
     hipLaunchKernelGGL(fsq_copy_ceiling_kernel, dim3((unsigned)blocks), dim3(THREADS), 0, s, x, n, q, idx, li);
