@@ -612,6 +612,56 @@ def other_configs(dev, args):
                                           "of encode_audio + decode_audio(indices) replayed per chunk; tokens and waveform kept per chunk",
                               "steps": 600, "ms_per_chunk": dt / 600 * 1e3, "x_real_time": 600.0 / dt, "value": 600 * 16000 / dt,
                               "unit": "samples/s", "last_chunk_tokens_equal_eager": bool(torch.equal(tokens[599:600], eager_ind))}
+    # ---- the same stream with encoder and decoder PIPELINED (reported beside the figure above, never instead of it): one graph whose two
+    # branches run encode_audio(chunk i) and decode_audio(tokens of chunk i - 1) side by side on two contexts (two workspaces) — what a
+    # streaming deployment does, sender and receiver being different processes anyway.  The waveform of a chunk leaves one replay later.
+    try:
+        codec_d = l3ac_amd.get_model("1kbps", synthetic_seed=0)
+        codec_d.network.to(device=dev).eval()
+        codec_d.network.context().reserve(1, 16000)
+        n_tok = ind1["indices"].shape[1]
+        tok_prev = torch.zeros(1, n_tok, dtype=torch.int32, device=dev)
+        side = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):  # warm both contexts outside capture
+            codec1.encode_audio(static_in)
+            codec_d.decode_audio(indices=tok_prev)
+        torch.cuda.current_stream().wait_stream(s)
+        graph2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph2):
+            cap = torch.cuda.current_stream()
+            side.wait_stream(cap)
+            with torch.cuda.stream(side):
+                wave_p = codec_d.decode_audio(indices=tok_prev)
+            _, ind_p = codec1.encode_audio(static_in)
+            cap.wait_stream(side)
+
+        def replay_pipelined():
+            for i in range(601):  # replay i encodes chunk i (the last one: a flush) and decodes chunk i - 1
+                static_in.copy_(chunks[min(i, 599):min(i, 599) + 1])
+                graph2.replay()
+                if i > 0:
+                    waves[i - 1].copy_(wave_p[0])
+                if i < 600:
+                    tokens[i].copy_(ind_p["indices"][0])
+                tok_prev.copy_(ind_p["indices"])
+        replay_pipelined()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        replay_pipelined()
+        torch.cuda.synchronize()
+        dtp = time.perf_counter() - t0
+        eager_wave = codec1.decode_audio(indices=eager_ind)
+        out["stream_1s_graph"]["pipelined_encode_decode"] = {
+            "what": "one graph, two branches on two contexts: encode_audio(chunk i) beside decode_audio(tokens of chunk i - 1); 601 replays for "
+                    "600 chunks; a chunk's waveform leaves one replay later.  Throughput of the stream, NOT the latency of a chunk "
+                    "(ms_per_chunk above is the sequential encode + decode of one chunk)",
+            "steps": 601, "ms_per_chunk": dtp / 600 * 1e3, "x_real_time": 600.0 / dtp,
+            "last_chunk_tokens_equal_eager": bool(torch.equal(tokens[599:600], eager_ind)),
+            "last_chunk_wave_equal_eager": bool(torch.equal(waves[599:600], eager_wave))}
+        del codec_d
+    except Exception as e:  # a diagnostic extra: never let it take the line down
+        out["stream_1s_graph"]["pipelined_encode_decode"] = {"error": repr(e)}
     del chunks, waves
     # ---- explicit-codebook L2 nearest neighbour at config-3 size: K = 250 047 codes, N = 42 752 queries -------------
     from oracle import l3ac_oracle as O  # the checker: codebook table + closed-form answers for the parity count

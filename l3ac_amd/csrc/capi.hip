@@ -540,8 +540,9 @@ int l3ac_ctx_set_option(l3ac_ctx* ctx, const char* name, int32_t value) {
     else if (n == "head_pretanh") ctx->head_pretanh = value != 0;
     else if (n == "narrow_ring") ctx->narrow_ring = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "ring_geometry") ctx->ring_geometry = value;
+    else if (n == "trans_coop") ctx->trans_coop_enabled = value != 0;
     else {
-        l3ac_set_error("set_option: unknown option '%s' (gemm_split, head_pretanh, narrow_ring, ring_geometry)", name);
+        l3ac_set_error("set_option: unknown option '%s' (gemm_split, head_pretanh, narrow_ring, ring_geometry, trans_coop)", name);
         return L3AC_EINVAL;
     }
     return L3AC_OK;

@@ -27,7 +27,16 @@
 //     ring of 4 slots of 4 pieces behind a counted s_waitcnt vmcnt and one raw s_barrier per slot.
 // Online softmax over key steps of 32 (as attention_mfma_kernel) with ts_exp_neg (1-2 ulp); erff is the OCML one.
 // Results differ from the unfused route's in rounding only (other summation orders); clip i of a batch is bit-identical to
-// clip i alone (one workgroup per clip, nothing depends on the batch).
+// clip i alone (nothing depends on the batch).
+//
+// Few clips (a streaming chunk is ONE): a clip on one workgroup is a clip on one of 256 CUs.  The COOPERATIVE form (KS = 6) gives a
+// clip six co-resident workgroups: workgroup j runs head j of every attention sub-layer and hidden chunks 2 j, 2 j + 1 of every
+// FeedForward for ALL frames of the clip, streaming only those weights (20 of a layer's 114 ring slots).  A sub-layer's output is
+// then a sum of six PARTIAL tiles (one per head / per chunk pair), each accumulated from zero; the partials cross workgroups through
+// write-through slabs in global memory behind an arrival counter (guide: 'inter-workgroup visibility', producer sc1 stores ->
+// vmcnt(0) -> barrier -> agent-scope add; consumer: poll -> acquire fence -> barrier -> loads) and EVERY workgroup adds them in the
+// same fixed order ((((p0 + p1) + p2) + p3) + p4) + p5 — which is also how the one-workgroup form (KS = 1) now sums its heads and
+// chunk pairs, so the two forms return the same bits and batch invariance holds across them.
 #include "../kernels.hpp"
 #include "../network.hpp"
 #include "device_math.hpp"
@@ -48,6 +57,7 @@ constexpr int TS_PIECES_PER_LAYER = TS_HEADS * TS_PIECES_PER_HEAD + TS_FF_CHUNKS
 constexpr int TS_SLOTS_PER_LAYER = TS_PIECES_PER_LAYER / TS_SLOT_PIECES;                                // 114
 static_assert(TS_PIECES_PER_LAYER % TS_SLOT_PIECES == 0, "a layer is a whole number of ring slots");
 constexpr int TS_MAX_FRAMES = 192, TS_MAX_LAYERS = 8;
+static_assert(TS_MAX_FRAMES == 192, "slab geometry");
 // LDS (bytes) of the instantiation for at most MAXW waves: the K / V^T fragments need MAXW key tiles, what that leaves goes to the
 // weight ring — 4 slots (3 in flight) at 12 waves, 8 (7 in flight, 84 KB) at 4 waves: with ONE wave per SIMD a slot is consumed
 // in ~0.2 us, and a single clip (the streaming chunk) pulls its weights from beyond L2: the stream has to run that far ahead
@@ -83,7 +93,17 @@ struct TransStackArgs {
     const float* bias_table;   // [heads][table_stride], entry = bias at distance i - j
     int table_stride;
     float scale;               // dim_head^-0.5 (applied to q before the scores, as the package does)
+    // cooperative form only (KS > 1): per clip slot, TS_COOP_SLAB_FLOATS of partial slabs [parity 2][part KS][frame 192][128],
+    // KS private copies of the residual stream [192][128], and two counters (arrivals of the current launch, workgroups done)
+    float* coop_slab;
+    float* coop_x;
+    unsigned* coop_cnt;
+    int batch;
 };
+constexpr int TS_KS = 6;                                    // workgroups per clip of the cooperative form (= heads)
+constexpr int TS_COOP_CLIPS = 8;                            // clip slots: blocks b and b + 8 are dealt to the same XCD (speed only)
+constexpr int64_t TS_COOP_SLAB_FLOATS = 2LL * TS_KS * 192 * TS_DIM;
+constexpr int64_t TS_COOP_X_FLOATS = (int64_t)TS_KS * 192 * TS_DIM;
 
 // exp(x) for x <= 0 (softmax terms; x = -inf for masked entries): the hardware's 2^t on t = x log2(e) carried in two parts — the
 // rounded product and its residual (exact by fma) plus the constant's low part — with the residual applied to first order:
@@ -116,11 +136,18 @@ __device__ long long g_ts_stamps[16];
 
 // (amdgpu_waves_per_eu: one workgroup per CU, so THREADS / 256 waves per SIMD is all the occupancy there will ever be — told so, the
 // scheduler spends the registers on keeping fragments in flight instead of re-reading them next to their use behind a full wait)
-template <int MAXW>
+template <int MAXW, int KS>
 __global__ __launch_bounds__(TsLds<MAXW>::THREADS) __attribute__((amdgpu_waves_per_eu(TsLds<MAXW>::THREADS / 256, TsLds<MAXW>::THREADS / 256)))
 void trans_stack_kernel(const TransStackArgs p) {
     constexpr bool PREF = MAXW <= 8;
+    constexpr bool COOP = KS > 1;
+    static_assert(KS == 1 || KS == TS_HEADS, "one workgroup per clip, or one per head");
     using L = TsLds<MAXW>;
+    // cooperative form: block = part * TS_COOP_CLIPS + clip slot (the KS workgroups of a clip are 8 blocks apart: one XCD under the
+    // observed round-robin placement); slots beyond the batch have nothing to do
+    const int clip = COOP ? (int)(blockIdx.x % TS_COOP_CLIPS) : (int)blockIdx.x;
+    const int part = COOP ? (int)(blockIdx.x / TS_COOP_CLIPS) : 0;
+    if (COOP && clip >= p.batch) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_ts[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -132,8 +159,11 @@ void trans_stack_kernel(const TransStackArgs p) {
 #endif
     const int frame = 16 * wave + fl;            // this lane's frame (column of every tile)
     const bool frame_ok = frame < frames;
-    float* const xclip = p.x + (int64_t)blockIdx.x * frames * TS_DIM;
-    float* const xlane = xclip + (int64_t)(frame_ok ? frame : 0) * TS_DIM + 4 * lg;  // + 16 t: this lane's 4 channels of tile t
+    float* const xclip = p.x + (int64_t)clip * frames * TS_DIM;
+    float* const xtrue = xclip + (int64_t)(frame_ok ? frame : 0) * TS_DIM + 4 * lg;  // + 16 t: this lane's 4 channels of tile t
+    // where this workgroup keeps the residual stream between sub-layers: the tensor itself, or (cooperative form: six workgroups
+    // hold the same stream and none may see another's update early) a private copy
+    float* const xlane = COOP ? p.coop_x + ((int64_t)clip * TS_KS + part) * (192 * TS_DIM) + (int64_t)(frame_ok ? frame : 0) * TS_DIM + 4 * lg : xtrue;
     float* const bias_s = reinterpret_cast<float*>(smem_ts + L::OFF_BIAS);
     float* const ln_s = reinterpret_cast<float*>(smem_ts + L::OFF_LN);
 
@@ -145,7 +175,8 @@ void trans_stack_kernel(const TransStackArgs p) {
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         xr[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        if (frame_ok) xr[t] = *reinterpret_cast<const f32x4_t*>(xlane + 16 * t);
+        if (frame_ok) xr[t] = *reinterpret_cast<const f32x4_t*>(xtrue + 16 * t);
+        if (COOP && frame_ok) *reinterpret_cast<f32x4_t*>(xlane + 16 * t) = xr[t];
     }
     // distance bias (distances 0 .. frames - 1 of every head) and the stack's LayerNorm parameters
     for (int i = tid; i < TS_HEADS * TS_MAX_FRAMES; i += blockDim.x) {
@@ -158,7 +189,16 @@ void trans_stack_kernel(const TransStackArgs p) {
     // ---- the weight stream -------------------------------------------------------------------------------------------
     const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(smem_ts + L::OFF_RING);
     const unsigned lane_off = 16u * (unsigned)lane;
-    const int total_slots = p.n_layers * TS_SLOTS_PER_LAYER;
+    // slots this workgroup consumes per layer, in its own order: all 114, or (cooperative) head `part` (8 slots) then hidden chunks
+    // 2 part, 2 part + 1 (6 slots each; the last workgroup has chunk 10 alone)
+    const int my_chunks = COOP ? (2 * part + 1 < TS_FF_CHUNKS ? 2 : 1) : TS_FF_CHUNKS;
+    const int slots_per_layer = COOP ? 8 + 6 * my_chunks : TS_SLOTS_PER_LAYER;
+    const int total_slots = p.n_layers * slots_per_layer;
+    auto image_slot = [&](int n) -> int {  // n-th slot of this workgroup's sequence -> slot of the image (wave-uniform)
+        if (!COOP) return n;
+        const int layer = n / slots_per_layer, r = n - layer * slots_per_layer;
+        return layer * TS_SLOTS_PER_LAYER + (r < 8 ? 8 * part + r : 8 * TS_HEADS + 12 * part + (r - 8));
+    };
     int dma_slot = 0;  // next slot of the stream to fetch (wave-uniform); past the end it wraps around (never consumed)
     const int n_compute = (int)(blockDim.x >> 6) - (L::LOADER ? L::NDW : 0);
     const int dma_wave = L::LOADER ? (wave >= n_compute ? wave - n_compute : -1) : (wave < L::NDW ? wave : -1);  // this wave's share of the copies, -1: none
@@ -167,7 +207,7 @@ void trans_stack_kernel(const TransStackArgs p) {
         for (int g = 0; g < L::SG; ++g) {
             if (dma_wave >= 0) {
                 const int src = dma_slot < total_slots ? dma_slot : dma_slot - total_slots;
-                const unsigned char* sb = p.img + (int64_t)src * TS_SLOT + 1024 * dma_wave;
+                const unsigned char* sb = p.img + (int64_t)image_slot(src) * TS_SLOT + 1024 * dma_wave;
                 const unsigned db = ring_lds + (unsigned)((dma_slot & (L::RING_SLOTS - 1)) * TS_SLOT + 1024 * dma_wave);
 #pragma unroll
                 for (int i = 0; i < L::BPW; ++i) ring_dma_1k(sb + 1024 * L::NDW * i, lane_off, db + 1024u * (unsigned)(L::NDW * i));
@@ -190,9 +230,18 @@ void trans_stack_kernel(const TransStackArgs p) {
     step_sync();  // group 0 has landed
     TS_STAMP(0);  // prologue
     if (L::LOADER && wave >= n_compute) {  // a loader: one refill and one barrier per group, in step with the computing waves
+        const int groups_per_layer = slots_per_layer / L::SG;
         for (int g = 0; g < total_slots / L::SG; ++g) {
             issue_group();
             step_sync();
+            if (COOP) {  // the computing waves' exchange of partials has two workgroup barriers: after the head's last group and
+                         // after the layer's last group (coop_combine below) — joined here, or the group barriers would pair up wrongly
+                const int r = g % groups_per_layer;
+                if (r == 8 / L::SG - 1 || r == groups_per_layer - 1) {
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_s_barrier();
+                }
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;
@@ -305,8 +354,68 @@ void trans_stack_kernel(const TransStackArgs p) {
             planes_of(a[0], a[1], ap[s2]);
         }
     };
+    // A sub-layer's output is the sum of TS_HEADS partial tiles, each accumulated from zero in `tacc` (one per head; one per pair of
+    // hidden chunks), added in index order: yacc = ((((p0 + p1) + p2) + p3) + p4) + p5.  One workgroup per clip: it computes them one
+    // after the other.  Cooperative form: workgroup `part` computes partial `part`, all six exchange them through the slabs.
+    f32x4_t yacc[8], tacc[8];
+    int coop_phase = 0;  // sub-layers finished so far (wave-uniform)
+    const __amdgpu_buffer_rsrc_t slab_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(COOP ? p.coop_slab + (int64_t)clip * TS_COOP_SLAB_FLOATS : p.x), 0, (int)(TS_COOP_SLAB_FLOATS * 4), 0x00020000);
+    auto add_partial = [&](int index) __attribute__((always_inline)) {  // KS == 1: partial `index` is complete in tacc
+#pragma unroll
+        for (int t = 0; t < 8; ++t) yacc[t] = index == 0 ? tacc[t] : yacc[t] + tacc[t];
+    };
+    auto coop_combine = [&]() __attribute__((always_inline)) {  // KS > 1: tacc (this workgroup's partial) -> yacc (the sum of all six)
+        // byte offset of this lane's 16 B of tile t in partial k of the phase's slab: + 64 t + k * 192 * 512
+        const unsigned slab_off = (unsigned)(coop_phase & 1) * (unsigned)(TS_KS * 192 * TS_DIM * 4) + (unsigned)(frame_ok ? frame : 0) * (TS_DIM * 4) + 16u * (unsigned)lg;
+        if (frame_ok) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t)  // write-through (sc1) 16-byte stores: the bytes are in memory when the wait below returns
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, tacc[t]), slab_rsrc, slab_off + (unsigned)part * (192 * TS_DIM * 4) + 64 * t, 0, 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (also drains this wave's LDS-DMAs: the ring refills behind the exchange)
+        __builtin_amdgcn_s_barrier();                      // every wave's stores have left
+        TS_STAMP(10);  // partial stored
+        unsigned* const cnt = p.coop_cnt + 2 * clip;
+        if (tid == 0) {
+            __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned want = (unsigned)TS_KS * (unsigned)(coop_phase + 1);
+            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(2);
+        }
+        __builtin_amdgcn_s_barrier();                      // the poll has matched: all six partials of this phase are in memory
+        TS_STAMP(11);  // arrival + wait for the other five
+#pragma unroll
+        for (int t = 0; t < 8; ++t) yacc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (frame_ok) {
+            // sc1 loads (never served from this CU's L1), TB tiles x six partials requested before the first add (the 12-wave form
+            // has 168 registers): left to itself hipcc issued them one by one, each behind a full wait (40 round trips per exchange)
+            constexpr int TB = MAXW > 8 ? 2 : 4;  // (8 at <= 8 waves spilled 16 registers and was 10 % slower)
+#pragma unroll
+            for (int tb = 0; tb < 8; tb += TB) {
+                u32x4 v[TS_KS][TB];
+#pragma unroll
+                for (int k = 0; k < TS_KS; ++k)
+#pragma unroll
+                    for (int tt = 0; tt < TB; ++tt)
+                        v[k][tt] = __builtin_amdgcn_raw_buffer_load_b128(slab_rsrc, slab_off + (unsigned)k * (192 * TS_DIM * 4) + 64 * (tb + tt), 0, 16);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tt = 0; tt < TB; ++tt) {
+                    f32x4_t sum = __builtin_bit_cast(f32x4_t, v[0][tt]);
+#pragma unroll
+                    for (int k = 1; k < TS_KS; ++k) sum = sum + __builtin_bit_cast(f32x4_t, v[k][tt]);  // ((((p0 + p1) + p2) + p3) + p4) + p5
+                    yacc[tb + tt] = sum;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#ifdef L3AC_TS_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        TS_STAMP(12);  // six partials read and added
+        ++coop_phase;
+    };
     // end of a sub-layer: x += yacc, back to its rows (the next sub-layer's end re-reads them), and into xr for the LayerNorm
-    f32x4_t yacc[8];
     auto add_residual = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
@@ -329,11 +438,11 @@ void trans_stack_kernel(const TransStackArgs p) {
         const float* const lnp = ln_s + layer * 4 * TS_DIM;
         // ================= LocalMHA ===================================================================================
         layer_norm_planes(lnp, lnp + TS_DIM);
-#pragma unroll
-        for (int t = 0; t < 8; ++t) yacc[t] = zero4;
         TS_STAMP(1);  // LayerNorm 1
 #pragma unroll 1
-        for (int h = 0; h < TS_HEADS; ++h) {
+        for (int h = COOP ? part : 0; h < (COOP ? part + 1 : TS_HEADS); ++h) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) tacc[t] = zero4;
             // ---- q^T, k^T (weights x activations) and V (activations x weights) of head h for this wave's frames ------
             f32x4_t qa[2] = {zero4, zero4}, ka[2] = {zero4, zero4}, va[2] = {zero4, zero4};
             slot_pair([&](auto dt_, auto j_, const bf16x8 (&f)[3]) __attribute__((always_inline)) {
@@ -424,21 +533,25 @@ void trans_stack_kernel(const TransStackArgs p) {
                 planes_of(o0, o1, op);
             }
             TS_STAMP(3);  // attention
-            // ---- out projection of this head's 32 columns, summed over the heads in yacc -------------------------------
+            // ---- out projection of this head's 32 columns: partial h of the sub-layer's output ------------------------------
             slot_pair([&](auto half_, auto j_, const bf16x8 (&f)[3]) __attribute__((always_inline)) {
                 constexpr int rt = 4 * decltype(half_)::value + decltype(j_)::value;
-                yacc[rt] = mfma6(f, op, yacc[rt]);
+                tacc[rt] = mfma6(f, op, tacc[rt]);
             }, nothing);
+            if (!COOP) add_partial(h);
             TS_STAMP(4);  // out projection (2 slots)
         }
+        if (COOP) coop_combine();
         add_residual();
         // ================= FeedForward (GEGLU) ========================================================================
         layer_norm_planes(lnp + 2 * TS_DIM, lnp + 3 * TS_DIM);
-#pragma unroll
-        for (int t = 0; t < 8; ++t) yacc[t] = zero4;
         TS_STAMP(5);  // residual + LayerNorm 2
 #pragma unroll 1
-        for (int c = 0; c < TS_FF_CHUNKS; ++c) {
+        for (int c = COOP ? 2 * part : 0; c < (COOP ? 2 * part + my_chunks : TS_FF_CHUNKS); ++c) {
+            if ((c & 1) == 0) {  // a partial = a pair of hidden chunks (2 i, 2 i + 1), accumulated from zero
+#pragma unroll
+                for (int t = 0; t < 8; ++t) tacc[t] = zero4;
+            }
             f32x4_t vg[4] = {zero4, zero4, zero4, zero4};  // value tiles 0, 1 then gate tiles 0, 1 of hidden units 32 c .. 32 c + 31
             ring_static_for<2>([&](auto w_) {  // value tiles 0, 1, then gate tiles 0, 1
                 slot_pair([&](auto t_, auto j_, const bf16x8 (&f)[3]) __attribute__((always_inline)) {
@@ -460,12 +573,29 @@ void trans_stack_kernel(const TransStackArgs p) {
             TS_STAMP(7);  // GEGLU
             slot_pair([&](auto half_, auto j_, const bf16x8 (&f)[3]) __attribute__((always_inline)) {
                 constexpr int rt = 4 * decltype(half_)::value + decltype(j_)::value;
-                yacc[rt] = mfma6(f, hp, yacc[rt]);
+                tacc[rt] = mfma6(f, hp, tacc[rt]);
             }, nothing);
+            if (!COOP && ((c & 1) || c == TS_FF_CHUNKS - 1)) add_partial(c >> 1);
             TS_STAMP(8);  // FF-out products (2 slots)
         }
+        if (COOP) coop_combine();
         add_residual();  // (also the next layer's LayerNorm input, already in xr)
         TS_STAMP(9);  // residual
+    }
+    if (COOP) {
+        // every workgroup holds the same final stream; workgroup 0 writes it to the tensor.  The last workgroup to get here zeroes
+        // the clip's counters for the next launch (the others have all passed their last poll: they counted themselves done after it)
+        if (part == 0 && frame_ok) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) *reinterpret_cast<f32x4_t*>(xtrue + 16 * t) = xr[t];
+        }
+        if (tid == 0) {
+            unsigned* const cnt = p.coop_cnt + 2 * clip;
+            if (__hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)TS_KS - 1) {
+                __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
     // leave no LDS-DMA in flight behind the workgroup
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -509,36 +639,59 @@ void trans_stack_layer_image(std::vector<unsigned char>& img, const float* wqkv,
 }
 int64_t trans_stack_layer_image_bytes() { return (int64_t)TS_SLOTS_PER_LAYER * TS_SLOT; }
 
-int launch_trans_stack(hipStream_t s, const LocalTransW& w, float* x, int batch, int frames, float scale) {
+size_t trans_stack_coop_bytes() {  // scratch of the cooperative form: slabs + private streams of TS_COOP_CLIPS clip slots, then the counters
+    return (size_t)TS_COOP_CLIPS * (size_t)(TS_COOP_SLAB_FLOATS + TS_COOP_X_FLOATS) * sizeof(float) + 2 * TS_COOP_CLIPS * sizeof(unsigned);
+}
+int trans_stack_coop_max_batch() { return TS_COOP_CLIPS; }
+
+template <int MAXW>
+static void launch_ts(hipStream_t s, bool coop, int batch, int waves, int n_layers, const TransStackArgs& a) {
+    const unsigned threads = 64 * (waves + (TsLds<MAXW>::LOADER ? TsLds<MAXW>::NDW : 0));  // (+ the loader waves)
+    if (coop)
+        hipLaunchKernelGGL((trans_stack_kernel<MAXW, TS_KS>), dim3(TS_KS * TS_COOP_CLIPS), dim3(threads), TsLds<MAXW>::bytes(n_layers), s, a);
+    else
+        hipLaunchKernelGGL((trans_stack_kernel<MAXW, 1>), dim3((unsigned)batch), dim3(threads), TsLds<MAXW>::bytes(n_layers), s, a);
+}
+
+// `coop`: scratch of trans_stack_coop_bytes() bytes whose counters (the last 2 * TS_COOP_CLIPS words) were zeroed when it was
+// allocated, or null.  With it, batches of at most TS_COOP_CLIPS clips run in the cooperative form (six workgroups per clip).
+int launch_trans_stack(hipStream_t s, const LocalTransW& w, float* x, int batch, int frames, float scale, void* coop) {
     const int n_layers = (int)w.layers.size();
     L3AC_REQUIRE(w.stack_img && w.stack_ln && batch > 0 && frames >= 1 && frames <= TS_MAX_FRAMES && frames <= w.window &&
                      n_layers >= 1 && n_layers <= TS_MAX_LAYERS,
                  "trans_stack: bad arguments (frames=%d window=%d layers=%d)", frames, w.window, n_layers);
     static PerDeviceOnce configured;
     if (configured.first()) {
-        L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trans_stack_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, TsLds<4>::bytes(TS_MAX_LAYERS)));
-        L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trans_stack_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, TsLds<8>::bytes(TS_MAX_LAYERS)));
-        L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trans_stack_kernel<12>), hipFuncAttributeMaxDynamicSharedMemorySize, TsLds<12>::bytes(TS_MAX_LAYERS)));
+        L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trans_stack_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, TsLds<4>::bytes(TS_MAX_LAYERS)));
+        L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trans_stack_kernel<8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, TsLds<8>::bytes(TS_MAX_LAYERS)));
+        L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trans_stack_kernel<12, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, TsLds<12>::bytes(TS_MAX_LAYERS)));
+        L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trans_stack_kernel<4, TS_KS>), hipFuncAttributeMaxDynamicSharedMemorySize, TsLds<4>::bytes(TS_MAX_LAYERS)));
+        L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trans_stack_kernel<8, TS_KS>), hipFuncAttributeMaxDynamicSharedMemorySize, TsLds<8>::bytes(TS_MAX_LAYERS)));
+        L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trans_stack_kernel<12, TS_KS>), hipFuncAttributeMaxDynamicSharedMemorySize, TsLds<12>::bytes(TS_MAX_LAYERS)));
         configured.done();
     }
     int waves = 2 * (int)ceil_div64(frames, 32);  // even: every key tile a wave reads in pairs has been written by some wave
     if (waves < 4) waves = 4;                      // (the 4-wave instantiation adds its loader wave at the launch)
+    // the cooperative form needs its TS_KS workgroups per clip co-resident (they wait for each other): 48 workgroups of one per CU
+    const bool use_coop = coop != nullptr && batch <= TS_COOP_CLIPS && l3ac_device_cu_count() >= TS_KS * TS_COOP_CLIPS;
     TransStackArgs a{};
     a.x = x; a.frames = frames; a.n_layers = n_layers; a.img = w.stack_img; a.ln = w.stack_ln; a.bias_table = w.bias_table;
-    a.table_stride = 2 * w.window; a.scale = scale;
+    a.table_stride = 2 * w.window; a.scale = scale; a.batch = batch;
+    if (use_coop) {
+        a.coop_slab = reinterpret_cast<float*>(coop);
+        a.coop_x = a.coop_slab + (int64_t)TS_COOP_CLIPS * TS_COOP_SLAB_FLOATS;
+        a.coop_cnt = reinterpret_cast<unsigned*>(a.coop_x + (int64_t)TS_COOP_CLIPS * TS_COOP_X_FLOATS);
+    }
     const double rows = (double)batch * frames;
     const double lin = 2.0 * (3.0 * TS_INNER * TS_DIM + TS_DIM * TS_INNER + 3.0 * TS_FFI * TS_DIM);
     const double att = 2.0 * 2.0 * TS_INNER * 0.5 * (frames + 1.0);
     char name[64];
-    std::snprintf(name, sizeof(name), "trans_stack_kernel %dx%d L%d", batch, frames, n_layers);
+    std::snprintf(name, sizeof(name), "trans_stack_kernel%s %dx%d L%d", use_coop ? "<coop>" : "", batch, frames, n_layers);
     ProfScope prof(s, name, n_layers * rows * (lin + att), 2.0 * rows * TS_DIM * 4.0);
     // (the instantiation only changes the register budget and whether weight fragments are fetched one piece ahead: same bits)
-    if (waves <= 4)
-        hipLaunchKernelGGL(trans_stack_kernel<4>, dim3((unsigned)batch), dim3(64 * (waves + TsLds<4>::NDW)), TsLds<4>::bytes(n_layers), s, a);  // + the loader waves
-    else if (waves <= 8)
-        hipLaunchKernelGGL(trans_stack_kernel<8>, dim3((unsigned)batch), dim3(64 * waves), TsLds<8>::bytes(n_layers), s, a);
-    else
-        hipLaunchKernelGGL(trans_stack_kernel<12>, dim3((unsigned)batch), dim3(64 * waves), TsLds<12>::bytes(n_layers), s, a);
+    if (waves <= 4) launch_ts<4>(s, use_coop, batch, waves, n_layers, a);
+    else if (waves <= 8) launch_ts<8>(s, use_coop, batch, waves, n_layers, a);
+    else launch_ts<12>(s, use_coop, batch, waves, n_layers, a);
     L3AC_LAUNCH_CHECK();
     return L3AC_OK;
 }

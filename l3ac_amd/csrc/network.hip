@@ -453,6 +453,18 @@ int network_build(l3ac_ctx* ctx, const l3ac_tensor* tensors, int n_tensors) {
 
     L3AC_HIP_CHECK(hipMalloc((void**)&ctx->bad_index_count, sizeof(int)));
     L3AC_HIP_CHECK(hipMemset(ctx->bad_index_count, 0, sizeof(int)));
+    {  // cooperative form of the transformer stacks (few clips: the streaming chunk): its scratch, counters zeroed ONCE here —
+       // every launch leaves them zeroed again
+        bool any = false;
+        for (const std::vector<LocalTransW>* v : {&ctx->en_enc, &ctx->en_dec})
+            for (const LocalTransW& t : *v) any = any || t.stack_img != nullptr;
+        if (any) {
+            L3AC_HIP_CHECK(hipMalloc(&ctx->trans_coop, trans_stack_coop_bytes()));
+            L3AC_HIP_CHECK(hipMemset(ctx->trans_coop, 0, trans_stack_coop_bytes()));
+        }
+        const char* e = std::getenv("L3AC_TRANS_COOP");
+        if (e) ctx->trans_coop_enabled = std::atoi(e);
+    }
     {  // GRN guard: starts at +inf
         const float inf = INFINITY;
         L3AC_HIP_CHECK(hipMalloc((void**)&ctx->grn_min_sumsq, sizeof(float)));
@@ -492,6 +504,8 @@ int network_build(l3ac_ctx* ctx, const l3ac_tensor* tensors, int n_tensors) {
 void network_free(l3ac_ctx* ctx) {
     if (ctx->bad_index_count) (void)hipFree(ctx->bad_index_count);
     ctx->bad_index_count = nullptr;
+    if (ctx->trans_coop) (void)hipFree(ctx->trans_coop);
+    ctx->trans_coop = nullptr;
     if (ctx->grn_min_sumsq) (void)hipFree(ctx->grn_min_sumsq);
     ctx->grn_min_sumsq = nullptr;
     if (ctx->arena) (void)hipFree(ctx->arena);
@@ -807,7 +821,8 @@ static bool use_trans_stack(const l3ac_ctx* ctx, const LocalTransW& w, int frame
 
 int run_local_trans(l3ac_ctx* ctx, hipStream_t s, const LocalTransW& w, float* x, int batch, int frames) {
     if (use_trans_stack(ctx, w, frames))  // one launch for the whole stack, one workgroup per clip
-        return launch_trans_stack(s, w, x, batch, frames, (float)std::pow((double)ctx->dim_head, -0.5));
+        return launch_trans_stack(s, w, x, batch, frames, (float)std::pow((double)ctx->dim_head, -0.5),
+                                  ctx->trans_coop_enabled ? ctx->trans_coop : nullptr);
     Workspace& ws = ctx->ws;
     const int dim = ctx->cfg.feature_dim;
     const int64_t rows = (int64_t)batch * frames;

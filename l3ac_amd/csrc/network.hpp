@@ -115,6 +115,10 @@ struct l3ac_ctx {
     Workspace ws;
     // Cross-stream ordering of the (single, in-place) workspace: every call that touches `ws` records `ws_done` on its stream
     // when it has enqueued its last kernel, and a later call on a DIFFERENT stream first makes that stream wait for it.
+    // scratch of trans_stack_kernel's cooperative form (partial slabs, private residual streams, arrival counters); option
+    // "trans_coop" (default 1) switches the form off without freeing it
+    void* trans_coop = nullptr;
+    int trans_coop_enabled = 1;
     int* bad_index_count = nullptr;  // device: indices outside [0, codebook size) seen by l3ac_decode since the last reset
     float* grn_min_sumsq = nullptr;  // device: smallest per-clip sum of squares any GRN of this context has seen (grn_exact only)
     hipEvent_t ws_done = nullptr;
@@ -151,7 +155,11 @@ bool trans_stack_supported(int dim, int dim_head, int heads, int ff_inner, int f
 void trans_stack_layer_image(std::vector<unsigned char>& img, const float* wqkv, const float* wout, const float* wff1, int ff_n,
                              const float* wff2, int ff_pad);
 int64_t trans_stack_layer_image_bytes();
-int launch_trans_stack(hipStream_t s, const LocalTransW& w, float* x, int batch, int frames, float scale);
+// `coop` (trans_stack_coop_bytes() bytes, counters zeroed at allocation; null = never): batches of at most
+// trans_stack_coop_max_batch() clips run in the cooperative form, six workgroups per clip — same bits as the one-workgroup form
+int launch_trans_stack(hipStream_t s, const LocalTransW& w, float* x, int batch, int frames, float scale, void* coop = nullptr);
+size_t trans_stack_coop_bytes();
+int trans_stack_coop_max_batch();
 // fused LegacyUnit / head (kernels/last_block.hip); x must not alias y
 bool last_block_fused_supported(int c, int max_dil);
 // host builders of the LegacyUnit weight images: w1 [c][7][c] (tap-major rows), w2 [c][c]

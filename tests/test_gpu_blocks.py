@@ -431,6 +431,52 @@ def test_local_trans_stack_kernel(full):
     assert float(e_f.pow(2).mean().sqrt()) <= 2.0 * float(e_u.pow(2).mean().sqrt()) + 1e-9
 
 
+def test_local_trans_stack_cooperative_form(full):
+    """The cooperative form of trans_stack_kernel (batches of at most 8 clips — a streaming chunk is one: six co-resident workgroups
+    per clip, one head / one pair of FeedForward chunks each, partial tiles exchanged through write-through slabs behind an arrival
+    counter and added in a fixed order) must return the SAME BITS as the one-workgroup form, which sums its heads and chunk pairs in
+    that order too: checked through the context option that switches the form off, for every wave-count instantiation (<= 64, <=
+    128, <= 192 frames), ragged lengths, 1 .. 8 clips, a single frame; against clips of a large batch (batch invariance across the
+    two forms); and launch after launch on one context (the arrival counters are left zeroed by every launch)."""
+    codec, mc, w = full
+    ctx = codec.network.context()
+    cases = [("en_encoder.down_trans.trans", 180, 1), ("en_decoder.up_trans.trans", 180, 3), ("en_decoder.up_trans.trans", 177, 8),
+             ("en_decoder.local_trans", 60, 1), ("en_encoder.local_trans", 60, 5), ("en_decoder.local_trans", 45, 2),
+             ("en_decoder.up_trans.trans", 100, 1), ("en_decoder.up_trans.trans", 128, 4), ("en_decoder.local_trans", 1, 2),
+             ("en_decoder.up_trans.trans", 192, 2), ("en_decoder.local_trans", 17, 7)]
+    for block, t, bsz in cases:
+        x = _rand((bsz, t, 128), 900 + t + bsz)
+        coop = [G.op_block(ctx, "l3ac_op_local_trans", block, x.cuda(), (bsz, t, 128)).cpu() for _ in range(3)]
+        ctx.set_option("trans_coop", 0)
+        try:
+            single = G.op_block(ctx, "l3ac_op_local_trans", block, x.cuda(), (bsz, t, 128)).cpu()
+        finally:
+            ctx.set_option("trans_coop", 1)
+        assert torch.isfinite(single).all()
+        for i, c in enumerate(coop):
+            assert torch.equal(c, single), f"{block} T={t} B={bsz}: cooperative launch {i} differs from the one-workgroup form"
+    # a clip alone (cooperative) == the same clip inside a batch the cooperative form does not take (one workgroup per clip)
+    for block, t in (("en_decoder.up_trans.trans", 180), ("en_decoder.local_trans", 60)):
+        x = _rand((40, t, 128), 950 + t)
+        big = G.op_block(ctx, "l3ac_op_local_trans", block, x.cuda(), (40, t, 128)).cpu()
+        for i in (0, 17, 39):
+            alone = G.op_block(ctx, "l3ac_op_local_trans", block, x[i:i + 1].cuda(), (1, t, 128)).cpu()
+            assert torch.equal(alone[0], big[i])
+    # many launches back to back, other work in between, then under uneven load: a long kernel on another stream while the
+    # cooperative workgroups exchange their partials
+    block, t = "en_decoder.up_trans.trans", 180
+    x = _rand((2, t, 128), 999)
+    want = G.op_block(ctx, "l3ac_op_local_trans", block, x.cuda(), (2, t, 128)).cpu()
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device="cuda")
+    for i in range(20):
+        with torch.cuda.stream(side):
+            (a @ a).sum()
+        got = G.op_block(ctx, "l3ac_op_local_trans", block, x.cuda(), (2, t, 128)).cpu()
+        assert torch.equal(got, want), f"launch {i}"
+    torch.cuda.synchronize()
+
+
 # ---------------------------------------------------------------------------------------------------
 def test_fsq_known_answers_and_exactness():
     kat = np.load(GOLDEN / "fsq_kat.npz")

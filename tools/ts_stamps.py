@@ -13,7 +13,7 @@ import l3ac_amd
 from l3ac_amd import _capi
 
 PHASES = ["prologue", "LayerNorm 1", "q k v products", "attention", "out projection", "residual + LayerNorm 2", "FF-in products", "GEGLU",
-          "FF-out products", "residual"]
+          "FF-out products", "residual", "coop: partial stored", "coop: arrive + wait", "coop: partials read + added"]
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 codec = l3ac_amd.get_model("1kbps", synthetic_seed=0)
