@@ -209,8 +209,9 @@ typedef float f32x4a __attribute__((ext_vector_type(4)));
 //   first  result: lanes 0-31 = row 16 h + i,     columns 32 u .. 32 u + 31; lanes 32-63 = row 16 h + 8 + i,  same columns
 //   second result: lanes 0-31 = row 16 h + 4 + i, columns 32 u .. 32 u + 31; lanes 32-63 = row 16 h + 12 + i, same columns
 // i.e. whole 128-B lines per half wave, and the lane's column (hence its bias / snake / GRN parameters) is 32 u + (lane & 31) for both.
-template <int RG>
-__device__ __forceinline__ void gemm_epilogue16(const GemmArgs& p, f32x4a (&acc)[RG][8], int64_t m0, int n0, int wave, int lane) {
+// NT column tiles of 16 (8: the whole 128-column block; 2: one 32-column slice, n0 = its first column — not with EPI_GEGLU)
+template <int RG, int NT = 8>
+__device__ __forceinline__ void gemm_epilogue16(const GemmArgs& p, f32x4a (&acc)[RG][NT], int64_t m0, int n0, int wave, int lane) {
     const int c32 = lane & 31, hi = lane >> 5;
     const int64_t mw = m0 + 16 * RG * wave + 8 * hi;  // + 16 h + i (first result), + 16 h + 4 + i (second)
     // (inline asm: with __builtin_amdgcn_permlane16_swap hipcc 7.2 folded the four swaps of a tile pair into one — every row of a
@@ -221,7 +222,7 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmArgs& p, f32x4a (&acc)
         lo = a;
         up = b;
     };
-    if (p.epi == EPI_GEGLU) {
+    if constexpr (NT == 8) if (p.epi == EPI_GEGLU) {
         // 32-column tiles come in (value, gate) pairs u = 0, 2 with u + 1; output column j = n0 / 2 + 16 u + c32
 #pragma unroll
         for (int u = 0; u < 4; u += 2) {
@@ -243,7 +244,7 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmArgs& p, f32x4a (&acc)
         return;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NT / 2; ++u) {
         const int n = n0 + 32 * u + c32;
         const bool n_ok = n < p.n;
         const int nc = n_ok ? n : 0;
@@ -533,6 +534,109 @@ __device__ __forceinline__ void gemm_split_body16(const GemmArgs& p, const int g
 #endif
 }
 
+// ---- a single clip's products (a streaming chunk: 60-180 rows): column SLICES ------------------------------------------------------
+// gemm_split_kernel_few_blocks gives 180 x 512 x 2048 (the second 1x1 conv of a C = 512 ConvUnit) twelve blocks, each streaming its
+// 128-column block of W — 1.5 MB — through one CU at the ~30 GB/s a lone workgroup draws: 66 us, and every k tile of 12 MFMAs per wave
+// waits on it.  Here a block owns 64 rows x 32 COLUMNS (column tiles 2 c, 2 c + 1 of the 128-column block): four times the blocks,
+// each copying only its 32 rows of every plane of the W tile (3 x 2 KB, into the same LDS layout), with W and A requested FOUR k
+// tiles ahead through four register sets — the loop is pure latency.  Same k order, same six plane products per accumulator in the
+// same order as every other form of this GEMM: same bits (the batch-invariance tests compare them).
+template <bool KTAIL>
+__global__ __launch_bounds__(THREADS, 2) void gemm_split_kernel_slices(const GemmArgs p) {
+    constexpr int AHEAD = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_split[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ln = lane & 15, lg = lane >> 4;
+    const int n_slices = (p.n + 31) / 32;
+    const int64_t m0 = (int64_t)(blockIdx.x / (unsigned)n_slices) * 64;
+    const int slice = (int)(blockIdx.x % (unsigned)n_slices);
+    const int n0 = 32 * slice, c = slice & 3;           // c: which 32 rows of the 128-row W tile
+    const int n_tiles = (p.k + BK - 1) / BK;
+    const int last = n_tiles - 1;
+    const int64_t row = m0 + 16 * wave + ln;
+    const float* const a_row = p.a + (row < p.m ? row : 0) * p.lda + 8 * lg;   // rows past the edge: row 0, never stored
+    // this thread's 16-B chunks of the slice's rows: chunk q = tid + 256 j < 384 -> plane q / 128, byte (q % 128) * 16 of the 2 KB
+    const unsigned char* const w_tile0 = p.w_img + (int64_t)(n0 / BN) * n_tiles * W_TILE + c * (32 * 64);
+    const int q1 = tid + 256;
+    const bool has1 = q1 < 384;
+    const int off0 = (tid / 128) * W_PLANE + (tid % 128) * 16, off1 = (q1 / 128) * W_PLANE + (q1 % 128) * 16;
+    float4 a_pre[AHEAD][2];
+    u32x4 w_reg[AHEAD][2];
+    auto load_a = [&](int kt, float4 (&dst)[2]) __attribute__((always_inline)) {
+        int o = kt * BK;
+        if (KTAIL) {
+            const int kmax = p.k - 8 - 8 * lg;
+            o = o < kmax ? o : kmax;
+        }
+        dst[0] = *reinterpret_cast<const float4*>(a_row + o);
+        dst[1] = *reinterpret_cast<const float4*>(a_row + o + 4);
+    };
+    auto load_w = [&](int kt, u32x4 (&dst)[2]) __attribute__((always_inline)) {
+        const unsigned char* t = w_tile0 + (int64_t)kt * W_TILE;
+        dst[0] = *reinterpret_cast<const u32x4*>(t + off0);
+        dst[1] = *reinterpret_cast<const u32x4*>(t + (has1 ? off1 : off0));
+    };
+    auto store_w = [&](int buf, const u32x4 (&src)[2]) __attribute__((always_inline)) {
+        unsigned char* base = smem_split + buf * W_TILE + c * (32 * 64);
+        *reinterpret_cast<u32x4*>(base + off0) = src[0];
+        if (has1) *reinterpret_cast<u32x4*>(base + off1) = src[1];
+    };
+    auto read_b = [&](const unsigned char* ws, int t, bf16x8 (&b)[3]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int pl = 2; pl >= 0; --pl) b[pl] = *reinterpret_cast<const bf16x8*>(ws + pl * W_PLANE + tile_off(16 * t + ln, lg));
+    };
+    f32x4a acc[1][2] = {{f32x4a{0.f, 0.f, 0.f, 0.f}, f32x4a{0.f, 0.f, 0.f, 0.f}}};
+#pragma unroll
+    for (int j = 0; j < AHEAD; ++j) {
+        load_a(j < last ? j : last, a_pre[j]);
+        load_w(j < last ? j : last, w_reg[j]);
+    }
+    store_w(0, w_reg[0]);
+    load_w(AHEAD < last ? AHEAD : last, w_reg[0]);
+    __syncthreads();
+    // step kt: LDS buffer kt & 1 holds W tile kt; register set (kt + 1) % AHEAD holds tile kt + 1 (stored here into the other buffer
+    // and refilled with tile kt + 1 + AHEAD); A set kt % AHEAD holds tile kt (split here, refilled with tile kt + AHEAD)
+    auto step = [&](int kt, auto set_) __attribute__((always_inline)) {
+        constexpr int set = decltype(set_)::value, nxt = (set + 1) % AHEAD;
+        const int buf = kt & 1;
+        u32x4 af[3];
+        {
+            unsigned x0, x1, x2, y0, y1, y2, z0, z1, z2, u0, u1, u2;
+            split2(a_pre[set][0].x, a_pre[set][0].y, x0, x1, x2);
+            split2(a_pre[set][0].z, a_pre[set][0].w, y0, y1, y2);
+            split2(a_pre[set][1].x, a_pre[set][1].y, z0, z1, z2);
+            split2(a_pre[set][1].z, a_pre[set][1].w, u0, u1, u2);
+            af[0] = u32x4{x0, y0, z0, u0};
+            af[1] = u32x4{x1, y1, z1, u1};
+            af[2] = u32x4{x2, y2, z2, u2};
+        }
+        load_a(kt + AHEAD < last ? kt + AHEAD : last, a_pre[set]);
+        store_w(buf ^ 1, w_reg[nxt]);                                        // tile kt + 1
+        load_w(kt + 1 + AHEAD < last ? kt + 1 + AHEAD : last, w_reg[nxt]);
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned char* ws = smem_split + buf * W_TILE;
+        bf16x8 bq[2][3];
+        read_b(ws, 2 * c, bq[0]);
+        read_b(ws, 2 * c + 1, bq[1]);
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                acc[0][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[PA[q]]), bq[u][PB[q]], acc[0][u], 0, 0, 0);
+        __syncthreads();
+    };
+    for (int kt = 0; kt < n_tiles; kt += AHEAD) {
+        step(kt, std::integral_constant<int, 0>{});
+        if (kt + 1 < n_tiles) step(kt + 1, std::integral_constant<int, 1>{});
+        if (kt + 2 < n_tiles) step(kt + 2, std::integral_constant<int, 2>{});
+        if (kt + 3 < n_tiles) step(kt + 3, std::integral_constant<int, 3>{});
+    }
+    gemm_epilogue16<1, 2>(p, acc, m0, n0, wave, lane);
+}
+
 // SHAPE: 16 = v_mfma_f32_16x16x32_bf16 (default); 32 = v_mfma_f32_32x32x16_bf16 (L3AC_SPLIT_MFMA=32).
 // (The 16x16x32 body is written for RG row groups of 16 per wave; RG = 4, i.e. 256-row blocks at two per CU, halves the LDS reads
 // and the W traffic per MFMA and was measured: +3 % on the K = 2048 shapes, -17 % on the K = 512 ones, whose epilogue it doubles.)
@@ -636,12 +740,23 @@ int launch_gemm_split(hipStream_t s, const GemmArgs& g) {
     }();
     const bool tail = g.k % BK != 0;
     const int cus = l3ac_device_cu_count();
+    static const bool slices_on = [] {  // L3AC_SPLIT_SLICES=0: the 64 x 128 blocks for a single clip's products too (A/B runs; same bits)
+        const char* e = std::getenv("L3AC_SPLIT_SLICES");
+        return !(e && std::atoi(e) == 0);
+    }();
     if (conv) {  // (whole k tiles: no tail; the 16x16x32 form only)
         if (blocks <= cus)
             hipLaunchKernelGGL(gemm_split_conv_kernel_few_blocks, dim3((unsigned)(ceil_div64(g.m, BM / 2) * ceil_div64(g.n, BN))), dim3(THREADS),
                                2 * W_TILE, s, g, gp);
         else
             hipLaunchKernelGGL(gemm_split_conv_kernel, dim3((unsigned)blocks), dim3(THREADS), 2 * W_TILE, s, g, gp);
+    } else if (!shape32 && g.epi != EPI_GEGLU && ceil_div64(g.m, BM / 2) * ceil_div64(g.n, BN) <= cus / 4 && slices_on) {
+        // a single clip: column slices (64 rows x 32 columns per block)
+        const unsigned grid = (unsigned)(ceil_div64(g.m, 64) * ceil_div64(g.n, 32));
+        if (tail)
+            hipLaunchKernelGGL((gemm_split_kernel_slices<true>), dim3(grid), dim3(THREADS), 2 * W_TILE, s, g);
+        else
+            hipLaunchKernelGGL((gemm_split_kernel_slices<false>), dim3(grid), dim3(THREADS), 2 * W_TILE, s, g);
     } else if (!shape32 && blocks <= cus) {
         const unsigned few = (unsigned)(ceil_div64(g.m, BM / 2) * ceil_div64(g.n, BN));
         if (tail)

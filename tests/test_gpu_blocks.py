@@ -84,6 +84,23 @@ def test_gemm_split_accuracy():
         assert es.pow(2).mean().sqrt().item() <= 1.05 * ef.pow(2).mean().sqrt().item() + 1e-9
 
 
+def test_gemm_split_forms_return_the_same_bits():
+    """The bf16x3 GEMM has three launch forms by grid size — 128 x 128 blocks, 64 x 128 blocks with W two k tiles ahead (few blocks),
+    64 x 32 column slices with W and A four k tiles ahead (a single clip's rows) — and a clip's results must not depend on the batch
+    it arrives in: the same rows through a large call and through calls of 180 / 60 / 1 rows, bit for bit (also k % 32 != 0, n not a
+    multiple of 128 or 32)."""
+    g = torch.Generator().manual_seed(41)
+    for n, k in ((512, 2048), (2048, 512), (256, 512), (192, 96), (200, 40), (128 * 3, 1032)):
+        m_big = 128 * 2 * (256 // max(1, n // 128) + 1)   # more 128 x 128 blocks than the chip has CUs
+        a = torch.randn(m_big, k, generator=g)
+        w = torch.randn(n, k, generator=g) * 0.1
+        b = torch.randn(n, generator=g)
+        big = G.gemm_split(a.cuda(), w.cuda(), b.cuda()).cpu()
+        for rows in (180, 60, 1, 400):
+            small = G.gemm_split(a[:rows].contiguous().cuda(), w.cuda(), b.cuda()).cpu()
+            assert torch.equal(small, big[:rows]), f"n={n} k={k}: {rows} rows alone differ from the same rows of a {m_big}-row call"
+
+
 def test_gemm_split_cancellation_and_underflow():
     """Adversarial operands for the bf16x3 split GEMM, with an ABSOLUTE bound per output: |err| <= 2^-20 * sum|a.w|.  (2^-23 was
     asked for; measured on these K = 1024 shapes the k-ordered fp32 MFMA chain itself — the kernel the split route replaces —
