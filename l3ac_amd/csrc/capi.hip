@@ -295,7 +295,7 @@ int l3ac_vq_argmin(const float* queries, int64_t n, const float* codebook, int32
 // ---- per-block parity entry points --------------------------------------------------------------------
 int l3ac_op_first_block(l3ac_ctx* ctx, const float* audio, int32_t batch, int32_t samples, float* y, void* stream) {
     L3AC_ENTER_WS(ctx, stream);
-    return launch_first_block((hipStream_t)stream, ctx->first, audio, samples, batch, samples, samples, y, ctx->gemm_split);
+    return launch_first_block((hipStream_t)stream, ctx->first, audio, samples, batch, samples, samples, y);
 }
 
 // (h: 4C floats per row, or the wide ConvUnit front end's planes of whole 32-frame tiles when that is more)

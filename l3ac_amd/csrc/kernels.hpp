@@ -119,7 +119,7 @@ struct FirstBlockW {
     int d0;
 };
 int launch_first_block(hipStream_t s, const FirstBlockW& w, const float* audio, int64_t audio_stride, int batch,
-                       int samples, int frames, float* y, bool split);  // split: 1x1 convs on the bf16 matrix cores (bf16x3)
+                       int samples, int frames, float* y);
 
 // EnhanceBlock helpers (tconv/__init__.py:30-44)
 struct EnhanceW {

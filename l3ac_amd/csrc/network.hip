@@ -866,7 +866,7 @@ static inline void swap_bufs(float** a, float** b) {
 int run_encoder(l3ac_ctx* ctx, hipStream_t s, const float* audio, int64_t audio_stride, int batch, int samples,
                 int frames, float** cur, float** alt) {
     const l3ac_config& c = ctx->cfg;
-    L3AC_TRY(launch_first_block(s, ctx->first, audio, audio_stride, batch, samples, frames, *cur, ctx->gemm_split));
+    L3AC_TRY(launch_first_block(s, ctx->first, audio, audio_stride, batch, samples, frames, *cur));
     int f = frames;
     for (int i = 0; i < c.n_enc; ++i) {
         L3AC_TRY(run_conv_units(ctx, s, ctx->enc_units[i], cur, alt, batch, f));
