@@ -93,34 +93,43 @@ __device__ __forceinline__ int rowmap(int r, int hh) { return (r & 3) + 8 * (r >
 // passed pre-biased by +3072 when N = 6 so that the offsets fit the signed 13-bit field), a wave-uniform 64-bit base in SGPRs
 // and one loop-invariant 32-bit lane offset: no vector address arithmetic per piece (guide 5.7: M0 is written in the statement
 // that uses it; the copies are invisible to hipcc's s_waitcnt bookkeeping and are counted by hand).
-template <int N>
+// NT: non-temporal policy on the copies (aux = nt).  For a stream that ONE workgroup per XCD or so reads once from beyond L2 (the
+// half-tile form: a single clip) the copies land sooner (guide, price list 'nt-weights'); never for the batch form, whose 256
+// workgroups re-read the image from L2 in step.
+template <int N, bool NT = false>
 __device__ __forceinline__ void dma_slot_quarter(const unsigned char* base, unsigned lane_off, unsigned lds_dst) {
     static_assert(N == 3 || N == 6, "3 KB or 6 KB per wave");
     unsigned keep;
+#define L3AC_DMA3(POL)                                                     \
+    asm volatile(                                                          \
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"             \
+        "global_load_lds_dwordx4 %1, %2" POL "\n\t"                        \
+        "global_load_lds_dwordx4 %1, %2 offset:1024" POL "\n\t"            \
+        "global_load_lds_dwordx4 %1, %2 offset:2048" POL "\n\t"            \
+        "s_mov_b32 m0, %0"                                                 \
+        : "=&s"(keep)                                                      \
+        : "v"(lane_off), "s"(base), "s"(lds_dst)                           \
+        : "memory")
+#define L3AC_DMA6(POL)                                                     \
+    asm volatile(                                                          \
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"             \
+        "global_load_lds_dwordx4 %1, %2 offset:-3072" POL "\n\t"           \
+        "global_load_lds_dwordx4 %1, %2 offset:-2048" POL "\n\t"           \
+        "global_load_lds_dwordx4 %1, %2 offset:-1024" POL "\n\t"           \
+        "global_load_lds_dwordx4 %1, %2" POL "\n\t"                        \
+        "global_load_lds_dwordx4 %1, %2 offset:1024" POL "\n\t"            \
+        "global_load_lds_dwordx4 %1, %2 offset:2048" POL "\n\t"            \
+        "s_mov_b32 m0, %0"                                                 \
+        : "=&s"(keep)                                                      \
+        : "v"(lane_off), "s"(base + 3072), "s"(lds_dst + 3072u)            \
+        : "memory")
     if constexpr (N == 3) {
-        asm volatile(
-            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-            "global_load_lds_dwordx4 %1, %2\n\t"
-            "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-            "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(keep)
-            : "v"(lane_off), "s"(base), "s"(lds_dst)
-            : "memory");
+        if constexpr (NT) L3AC_DMA3(" nt"); else L3AC_DMA3("");
     } else {
-        asm volatile(
-            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-            "global_load_lds_dwordx4 %1, %2 offset:-3072\n\t"
-            "global_load_lds_dwordx4 %1, %2 offset:-2048\n\t"
-            "global_load_lds_dwordx4 %1, %2 offset:-1024\n\t"
-            "global_load_lds_dwordx4 %1, %2\n\t"
-            "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-            "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(keep)
-            : "v"(lane_off), "s"(base + 3072), "s"(lds_dst + 3072u)
-            : "memory");
+        if constexpr (NT) L3AC_DMA6(" nt"); else L3AC_DMA6("");
     }
+#undef L3AC_DMA3
+#undef L3AC_DMA6
 }
 
 template <int N, class F, int I = 0>
@@ -229,10 +238,20 @@ __device__ __forceinline__ f32x4_t mfma_plane(const bf16x8 (&a)[3], const bf16x8
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[IA[M]], b[IB[M]], acc, 0, 0, 0);
 }
 
-template <int C>
+// FH: frame halves (16 frames each) a wave owns.  2: the 32-frame tiles described above.  1 (round 4): HALF tiles, for grids that leave
+// most of the chip idle — a single clip (the streaming chunk) is 29 tiles at C = 256, eight workgroups, and each wave's tile is 82 us
+// of MFMAs on its one SIMD however fast the weights arrive.  With 16 frames per wave there are twice the waves, every weight piece
+// meets one column group instead of two, and the activation has only its "frame half 0" stream (beside the second product of the
+// previous hidden tile).  Per element the same products in the same order: the same bits as FH = 2 (tested).
+#ifndef L3AC_WIDE_HALF_NT
+#define L3AC_WIDE_HALF_NT 0  // 1: the half-tile form's weight copies non-temporal — measured: no gain (86 vs 83 us at C = 256, 51 vs 52 at C = 192)
+#endif
+template <int C, int FH = 2>
 __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW w, const unsigned char* __restrict__ planes,
                                                               const float* __restrict__ x, float* __restrict__ y, const int64_t rows) {
     using G = WGeo<C>;
+    static_assert(FH == 1 || FH == 2, "one or two frame halves per wave");
+    constexpr int GPP = 6 * FH;  // MFMA gaps per weight piece
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_wide[];
     unsigned char* ring = smem_wide + G::OFF_RING;
     float* Pt = reinterpret_cast<float*>(smem_wide + G::OFF_P);
@@ -262,7 +281,7 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
     int dma_slot = 0;  // next slot of the stream to fetch (wave-uniform)
     auto issue = [&](int ring_pos) __attribute__((always_inline)) {
 #ifndef L3AC_WIDE_NODMA  // (timing experiments only)
-        dma_slot_quarter<G::DMA_N>(src_wave + (int64_t)dma_slot * G::SLOT, lane_off, ring_lds + (unsigned)(ring_pos * G::SLOT) + (unsigned)(G::SLOT / 4) * (unsigned)wave);
+        dma_slot_quarter<G::DMA_N, (FH == 1) && L3AC_WIDE_HALF_NT>(src_wave + (int64_t)dma_slot * G::SLOT, lane_off, ring_lds + (unsigned)(ring_pos * G::SLOT) + (unsigned)(G::SLOT / 4) * (unsigned)wave);
 #endif
         dma_slot = dma_slot + 1 == G::TOTAL ? 0 : dma_slot + 1;
     };
@@ -291,7 +310,7 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
     for (int i = tid; i < C; i += 256) B2s[i] = w.b2[i];
     __syncthreads();  // (plain loads above: hipcc drains them here, the DMA pieces with them)
 
-    const int64_t n_tiles = (rows + 31) / 32;
+    const int64_t n_tiles = (FH == 2 ? 1 : 2) * ((rows + 31) / 32);  // work units: 32-frame tiles, or their 16-frame halves
     const int64_t tile_stride = (int64_t)gridDim.x * 4;
 #ifndef L3AC_WIDE_NO_STAGGER
     // Passes run in lock step across the chip, so every workgroup would fetch its operand planes and store its tile at the
@@ -314,37 +333,42 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
     (void)pass_no;
     for (int64_t base = (int64_t)blockIdx.x * 4; base < n_tiles; base += tile_stride, ++pass_no) {
         WIDE_STAMP(0);
-        const int64_t tile = base + wave;              // this wave's 32 rows (beyond the last tile: its results are not stored)
-        const int64_t row0 = tile * 32;
+        const int64_t tile = base + wave;              // this wave's unit (beyond the last one: its results are not stored)
+        const int64_t row0 = tile * (16 * FH);
         const bool tile_ok = tile < n_tiles;
+        const int64_t tile32 = FH == 2 ? tile : tile >> 1;  // the 32-frame tile of the operand-plane image
+        const int fsel = FH == 2 ? 0 : (int)(tile & 1);     // FH = 1: which frame half of it
 
         // ---- LayerNorm(dw_conv7(x)) of this tile, already split and in fragment order (dwconv_ln_split_kernel): k step s,
         //      plane p is one 1-KB block, 16 B per lane
-        bf16x8 ap[G::NS1][3];
+        // (block s = 2 b + fh of the image: k block b, frame half fh; FH = 1 keeps the blocks of its own half: ap[b])
+        bf16x8 ap[G::NS1 / (3 - FH)][3];
         {
-            const unsigned char* src = planes + (tile_ok ? tile : 0) * (int64_t)(G::NS1 * 3072) + 16 * lane;
+            const unsigned char* src = planes + (tile_ok ? tile32 : 0) * (int64_t)(G::NS1 * 3072) + 16 * lane + (FH == 1 ? fsel * 3072 : 0);
 #pragma unroll
-            for (int s = 0; s < G::NS1; ++s)
+            for (int s = 0; s < G::NS1 / (3 - FH); ++s)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) ap[s][pl] = *reinterpret_cast<const bf16x8*>(src + (s * 3 + pl) * 1024);
+                for (int pl = 0; pl < 3; ++pl) ap[s][pl] = *reinterpret_cast<const bf16x8*>(src + ((FH == 1 ? 2 * s : s) * 3 + pl) * 1024);
         }
 
         // At C = 256 the 192 operand registers, the 160 accumulators and the activation's working set exceed the 256 arch VGPRs:
         // left alone hipcc parks part of ap in AGPRs and copies it back (4 v_accvgpr_read per MFMA) inside the loop.  An MFMA
         // reads its B operand from an AGPR just as well: the last k steps are moved there for good, once per pass.
+        if constexpr (FH == 2) {
 #pragma unroll
-        for (int s = G::AP_AGPR_FROM; s < G::NS1; ++s)
+            for (int s = G::AP_AGPR_FROM; s < G::NS1; ++s)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) asm volatile("" : "+a"(ap[s][pl]));
+                for (int pl = 0; pl < 3; ++pl) asm volatile("" : "+a"(ap[s][pl]));
+        }
 
         WIDE_STAMP(1);
         // ---- output accumulators start at the pw_conv2 bias: yacc[rt][fh][i] = y[channel 16 rt + 4 lg + i][frame 16 fh + ln]
-        f32x4_t yacc[G::RT][2];
+        f32x4_t yacc[G::RT][FH];
 #pragma unroll
         for (int rt = 0; rt < G::RT; ++rt) {
             const f32x4_t b2v = *reinterpret_cast<const f32x4_t*>(B2s + 16 * rt + 4 * lg);
-            yacc[rt][0] = b2v;
-            yacc[rt][1] = b2v;
+#pragma unroll
+            for (int fh = 0; fh < FH; ++fh) yacc[rt][fh] = b2v;
         }
 
         // the slot at ring position 0 (and the one after it) must have landed: first pass = the prologue's copies,
@@ -388,7 +412,7 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
         // frame half HALF = hidden half P >> 1, register pair P & 1 of accumulator tile 2 (P >> 1) + HALF
         auto act_gap = [&](auto gap_, auto half_, const XTile& xa, const float* tab) __attribute__((always_inline)) {
             constexpr int GAP = decltype(gap_)::value, HALF = decltype(half_)::value;
-            constexpr int TOTAL_ST = 4 * ACT_STAGES, GAPS = 12 * G::KS * G::NA;
+            constexpr int TOTAL_ST = 4 * ACT_STAGES, GAPS = GPP * G::KS * G::NA;
             constexpr int LO = GAP * TOTAL_ST / GAPS, HI = (GAP + 1) * TOTAL_ST / GAPS;
             static_for<HI - LO>([&](auto k_) {
                 constexpr int ST = LO + decltype(k_)::value, P = ST / ACT_STAGES, T = ST % ACT_STAGES;
@@ -409,24 +433,25 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
                              const bf16x8 (&xb)[2][3], const XTile& xa, const float* tab) __attribute__((always_inline)) {
             constexpr int PHASE = decltype(phase_)::value, POS = decltype(pos_)::value, NEXT = decltype(next_)::value;
             constexpr int I = decltype(i_)::value, ACT = decltype(act_)::value;
-            static_for<12 * G::KS>([&](auto g_) {
-                constexpr int g = decltype(g_)::value, pc = g / 12, fh = (g % 12) / 6, m = g % 6;
+            static_for<GPP * G::KS>([&](auto g_) {
+                constexpr int g = decltype(g_)::value, pc = g / GPP, fh = (g % GPP) / 6, m = g % 6;
                 constexpr int piece = G::KS * I + pc;
                 if constexpr (PHASE == 0)
-                    acc.q[2 * (piece & 1) + fh] = mfma_plane<m>(fb[pc & 1], ap[2 * (piece >> 1) + fh], acc.q[2 * (piece & 1) + fh]);
+                    acc.q[2 * (piece & 1) + fh] = mfma_plane<m>(fb[pc & 1], ap[FH == 2 ? 2 * (piece >> 1) + fh : (piece >> 1)], acc.q[2 * (piece & 1) + fh]);
                 else
                     yacc[piece][fh] = mfma_plane<m>(fb[pc & 1], xb[fh], yacc[piece][fh]);
                 // the next piece's planes in the order 0, 1, 2: its first MFMA takes plane 2 of the weights, the YOUNGEST read, so the one
                 // s_waitcnt in front of it covers all three (LDS returns in order) instead of one wait per plane
-                if constexpr (g % 12 == 0 || g % 12 == 3 || g % 12 == 6) {
-                    constexpr int pl = (g % 12) / 3;
+                constexpr int FSTEP = FH == 2 ? 3 : 2;  // gaps between the three fragment reads of the next piece
+                if constexpr ((g % GPP) % FSTEP == 0 && (g % GPP) / FSTEP < 3) {
+                    constexpr int pl = (g % GPP) / FSTEP;
                     if constexpr (pc + 1 < G::KS)
                         fb[(pc + 1) & 1][pl] = frag1(POS, pc + 1, pl);
                     else if constexpr (NEXT >= 0)
                         fb[0][pl] = frag1(NEXT, 0, pl);
                 }
                 if constexpr (g == 0) issue(issue_pos);
-                if constexpr (ACT >= 0) act_gap(std::integral_constant<int, 12 * G::KS * I + g>{}, std::integral_constant<int, ACT>{}, xa, tab);
+                if constexpr (ACT >= 0) act_gap(std::integral_constant<int, GPP * G::KS * I + g>{}, std::integral_constant<int, ACT>{}, xa, tab);
 #ifndef L3AC_WIDE_WALL_EVERY
 #define L3AC_WIDE_WALL_EVERY 3  // a wall after every gap (or every second) sends hipcc's register allocation over the edge at C = 256
 #endif
@@ -451,7 +476,7 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
         };
         auto make_xb = [&](bf16x8 (&xb)[2][3]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int fh = 0; fh < 2; ++fh)
+            for (int fh = 0; fh < FH; ++fh)
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
                     xb[fh][pl] = __builtin_bit_cast(bf16x8, u32x4{xbp[fh][pl][0], xbp[fh][pl][1], xbp[fh][pl][2], xbp[fh][pl][3]});
@@ -485,7 +510,7 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
             static_for<G::NA>([&](auto i_) {
                 constexpr int i = decltype(i_)::value;
                 slot_step(std::integral_constant<int, 0>{}, std::integral_constant<int, G::NA + i>{},
-                          std::integral_constant<int, (G::NA + i + 1) % G::NSTEP>{}, i_, std::integral_constant<int, 1>{},
+                          std::integral_constant<int, (G::NA + i + 1) % G::NSTEP>{}, i_, std::integral_constant<int, FH == 2 ? 1 : -1>{},
                           (G::NA + i + G::PF) % G::NSTEP, xnext, xb, xacc, tab_a);
             });
             // ---- B: second product of tile nt (slots 0 .. NA-1) beside frame half 0 of tile nt+1's activation ---------------
@@ -507,21 +532,23 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
         //      their registers hold the 8 x C/32 row pieces while the last second product runs (fetched tile by tile inside the
         //      store loop they cost 8 serial memory latencies: 21 k of a pass's 263 k cycles)
         const int er = lane >> 3, es = lane & 7;  // row within a group of 8, 16-B slot
-        float4 xres[G::CT][4];
+        float4 xres[G::CT][2 * FH];
 #pragma unroll
         for (int ct = 0; ct < G::CT; ++ct)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 2 * FH; ++i) {
                 const int64_t rr = row0 + 8 * i + er;
                 const bool ok = tile_ok && rr < rows;
                 xres[ct][i] = *reinterpret_cast<const float4*>(x + (ok ? rr : 0) * C + 32 * ct + 4 * es);
             }
         // ---- last hidden tile: frame half 1 of its activation alone, second product from slots NA .. 2NA-1 ------------------
-        static_for<4 * ACT_STAGES>([&](auto st_) {
-            constexpr int ST = decltype(st_)::value, P = ST / ACT_STAGES, T = ST % ACT_STAGES, Q = 2 * (P >> 1) + 1, E = 2 * (P & 1);
-            act_stage<T>(ast[P], tab_lane + 128 * (G::NT - 1) + 64 * (P >> 1) + 8 * (P & 1), xacc.q[Q][E], xacc.q[Q][E + 1], xbp[1][0][P],
-                         xbp[1][1][P], xbp[1][2][P]);
-        });
+        if constexpr (FH == 2) {
+            static_for<4 * ACT_STAGES>([&](auto st_) {
+                constexpr int ST = decltype(st_)::value, P = ST / ACT_STAGES, T = ST % ACT_STAGES, Q = 2 * (P >> 1) + 1, E = 2 * (P & 1);
+                act_stage<T>(ast[P], tab_lane + 128 * (G::NT - 1) + 64 * (P >> 1) + 8 * (P & 1), xacc.q[Q][E], xacc.q[Q][E + 1], xbp[1][0][P],
+                             xbp[1][1][P], xbp[1][2][P]);
+            });
+        }
         make_xb(xb);
         static_for<G::NA>([&](auto i_) {
             constexpr int i = decltype(i_)::value;
@@ -546,7 +573,7 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
 #pragma unroll
                 for (int rtl = 0; rtl < 2; ++rtl)
 #pragma unroll
-                    for (int fh = 0; fh < 2; ++fh) {
+                    for (int fh = 0; fh < FH; ++fh) {
                         const int fr = 16 * fh + ln;
                         const f32x4_t v = yacc[2 * ct + rtl][fh];
                         *reinterpret_cast<float4*>(tb + 128 * fr + 16 * ((4 * rtl + lg) ^ ((fr ^ (fr >> 3)) & 7))) = make_float4(v.x, v.y, v.z, v.w);
@@ -555,7 +582,7 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < 2 * FH; ++i) {
                     const int r = 8 * i + er;
                     const int64_t rr = row0 + r;
                     const float4 v = *reinterpret_cast<const float4*>(tb + 128 * r + 16 * (es ^ ((r ^ (r >> 3)) & 7)));
@@ -664,7 +691,9 @@ int launch_wide(hipStream_t s, const ConvUnitW& w, const float* x, float* y, uns
     using G = WGeo<C>;
     static PerDeviceOnce configured;
     if (configured.first()) {
-        L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_unit_wide_kernel<C>),
+        L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_unit_wide_kernel<C, 2>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+        L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_unit_wide_kernel<C, 1>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
         configured.done();
     }
@@ -676,9 +705,18 @@ int launch_wide(hipStream_t s, const ConvUnitW& w, const float* x, float* y, uns
     }
     const int64_t tiles = ceil_div64(rows, 32);
     int64_t blocks = ceil_div64(tiles, 4);
+    static const bool half_on = [] {  // L3AC_WIDE_HALF=0: 32-frame tiles for small grids too (A/B runs; same bits)
+        const char* e = std::getenv("L3AC_WIDE_HALF");
+        return !(e && std::atoi(e) == 0);
+    }();
+    const bool half = half_on && 2 * blocks <= l3ac_device_cu_count();  // half tiles while twice the workgroups still fit one pass
+    if (half) blocks = ceil_div64(2 * tiles, 4);
     if (blocks > 256) blocks = 256;
     ProfScope prof(s, name, (double)rows * (16.0 * C * C), (double)rows * 14.0 * C);
-    hipLaunchKernelGGL((conv_unit_wide_kernel<C>), dim3((unsigned)blocks), dim3(256), G::LDS, s, w, planes, x, y, rows);
+    if (half)
+        hipLaunchKernelGGL((conv_unit_wide_kernel<C, 1>), dim3((unsigned)blocks), dim3(256), G::LDS, s, w, planes, x, y, rows);
+    else
+        hipLaunchKernelGGL((conv_unit_wide_kernel<C, 2>), dim3((unsigned)blocks), dim3(256), G::LDS, s, w, planes, x, y, rows);
     L3AC_LAUNCH_CHECK();
     return L3AC_OK;
 }

@@ -274,6 +274,16 @@ def test_conv_units_wide_fused(full):
         ref = O.conv_unit(w, block, x)
         got = G.op_block(codec.network.context(), "l3ac_op_conv_unit", block, G.to_frames(x), (b, t, c))
         _close(f"{block} B={b} T={t}", G.from_frames(got), ref, atol=5e-5, rtol=5e-5)
+    # the two tile forms of the kernel — 32 frames per wave, and 16 frames per wave for grids that leave most of the chip idle (a
+    # single clip: the streaming chunk) — return the same bits: the first clips of a large batch against the same clips run alone
+    for block, c, t, b_big in (("decoder.blocks.4.1.module", 256, 900, 40), ("encoder.blocks.7.0.module", 192, 180, 200),
+                               ("decoder.blocks.4.0.module", 256, 901, 40), ("encoder.blocks.7.1.module", 192, 37, 300)):
+        x = _rand((b_big, c, t), 400 + c + t)
+        xf = G.to_frames(x)
+        big = G.op_block(codec.network.context(), "l3ac_op_conv_unit", block, xf, (b_big, t, c))
+        for b_small in (1, 3):
+            small = G.op_block(codec.network.context(), "l3ac_op_conv_unit", block, xf[:b_small].contiguous(), (b_small, t, c))
+            assert torch.equal(small, big[:b_small]), f"{block} T={t}: {b_small} clip(s) alone differ from the same clips of a batch of {b_big}"
     # C = 128 (no shipped model has such a stage; the reference's default geometry does): 2 ring slots per product
     codec128 = l3ac_amd.get_model(GOLDEN / "refdefault.toml", synthetic_seed=5)
     codec128.network.to(device="cuda").eval()
