@@ -705,18 +705,36 @@ int launch_wide(hipStream_t s, const ConvUnitW& w, const float* x, float* y, uns
     }
     const int64_t tiles = ceil_div64(rows, 32);
     int64_t blocks = ceil_div64(tiles, 4);
-    static const bool half_on = [] {  // L3AC_WIDE_HALF=0: 32-frame tiles for small grids too (A/B runs; same bits)
-        const char* e = std::getenv("L3AC_WIDE_HALF");
-        return !(e && std::atoi(e) == 0);
+    static const int half_mode = [] {  // L3AC_WIDE_HALF: 0 = 32-frame tiles only, 1 = half tiles for small grids, 2 (default) = also for
+        const char* e = std::getenv("L3AC_WIDE_HALF");  // the last, mostly empty pass of a large grid (A/B runs; same bits)
+        return e ? std::atoi(e) : 2;
     }();
-    const bool half = half_on && 2 * blocks <= l3ac_device_cu_count();  // half tiles while twice the workgroups still fit one pass
-    if (half) blocks = ceil_div64(2 * tiles, 4);
-    if (blocks > 256) blocks = 256;
+    const int cus = l3ac_device_cu_count();
+    const bool half = half_mode >= 1 && 2 * blocks <= cus;  // half tiles while twice the workgroups still fit one pass
     ProfScope prof(s, name, (double)rows * (16.0 * C * C), (double)rows * 14.0 * C);
-    if (half)
+    if (half) {
+        blocks = ceil_div64(2 * tiles, 4);
         hipLaunchKernelGGL((conv_unit_wide_kernel<C, 1>), dim3((unsigned)blocks), dim3(256), G::LDS, s, w, planes, x, y, rows);
-    else
-        hipLaunchKernelGGL((conv_unit_wide_kernel<C, 2>), dim3((unsigned)blocks), dim3(256), G::LDS, s, w, planes, x, y, rows);
+    } else {
+        // A large grid runs ceil(tiles / (4 x 256)) passes in lock step and the last one may be nearly empty (256 x 900 frames at
+        // C = 256: 7 200 tiles = 7 full passes + 32 tiles — an eighth pass for 0.4 % of the work).  When the remainder fits one pass
+        // of HALF tiles, it runs as a second launch of the 16-frame form (about 0.65 of a full pass) over the last rows; tiles are
+        // 32 consecutive global rows, so the split is a pointer offset.
+        const int64_t per_pass = 4LL * 256;
+        const int64_t full = tiles / per_pass * per_pass, rest = tiles - full;
+        // (Not for a SMALL remainder: with exactly full passes no workgroup has the slack the staggered start above lives on, and at
+        // 7 passes + 32 tiles the main launch lost more (3.03 -> 3.08 ms for the three C = 256 units) than the eighth pass costs;
+        // 1 pass + 416 tiles, the C = 192 units: 0.34 -> 0.30 ms.)
+        const bool tail = half_mode >= 2 && full > 0 && 8 * rest >= per_pass && 2 * rest <= per_pass;
+        const int64_t main_rows = tail ? full * 32 : rows;
+        if (blocks > 256) blocks = 256;
+        hipLaunchKernelGGL((conv_unit_wide_kernel<C, 2>), dim3((unsigned)blocks), dim3(256), G::LDS, s, w, planes, x, y, main_rows);
+        if (tail) {
+            L3AC_LAUNCH_CHECK();
+            hipLaunchKernelGGL((conv_unit_wide_kernel<C, 1>), dim3((unsigned)ceil_div64(2 * rest, 4)), dim3(256), G::LDS, s, w,
+                               planes + full * (int64_t)(G::NS1 * 3072), x + full * 32 * C, y + full * 32 * C, rows - full * 32);
+        }
+    }
     L3AC_LAUNCH_CHECK();
     return L3AC_OK;
 }
