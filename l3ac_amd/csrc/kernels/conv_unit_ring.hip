@@ -485,6 +485,14 @@ int launch_conv_unit_ring(hipStream_t s, const ConvUnitW& w, const float* x, flo
     // the vector work (VALU active 0.46 of the cycles at C = 96, 0.74 at C = 48) hides under the products (matrix pipe 0.38 / 0.37),
     // and at C <= 48 the vector work — 20 instructions of activation and 5.5 of operand split per hidden element — is the larger
     // of the two: these widths are bound by vector issue, not by the matrix pipe.
+    // Small grids (a single clip: the streaming chunk): at most one wave per SIMD of the chip — workgroups of FOUR waves, one per CU,
+    // so that every wave has its SIMD to itself (at 8 x 2 or 16 x 1 the few workgroups of a clip stack their waves four deep on a
+    // dozen CUs while the rest of the chip idles: C = 96, 2 700 frames: 42 us).  Variant 9 forces it (tests: same bits).
+    const int64_t tiles16 = (int64_t)batch * ((frames + 15) / 16);
+    if (variant == 9 || (variant == 0 && tiles16 <= 4LL * l3ac_device_cu_count())) {
+        if (w.c == 96) return launch_ring<RGeo<96, 4, 3, 3, 4, false>, 96>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<96>");
+        if (w.c == 48) return launch_ring<RGeo<48, 4, 1, 0, 0, true>, 48>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<48>");
+    }
     switch (w.c) {
         case 24:
             if (variant == 1) return launch_ring<RGeo<24, 6, 2, 0, 0, true>, 24>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<24>");

@@ -757,7 +757,12 @@ int run_up(l3ac_ctx* ctx, hipStream_t s, const UpW& w, const float* x, float* tm
 // EnhanceBlock + UpLayer of one decoder stage: the gate is applied inside the up conv's A staging (no pass of its own).
 // x is left untouched; tmp holds the conv output at the input rate.
 int run_enhance_up(l3ac_ctx* ctx, hipStream_t s, const EnhW& e, const UpW& w, float* x, float* tmp, float* y, int batch, int frames) {
-    if (w.cin % 16 != 0 || e.c != w.cin) {  // geometry the gated GEMM does not cover: separate passes
+    // separate passes (gate as a row kernel, in place; then the up layer) where the gated GEMM does not cover the geometry — and where
+    // the 1x1 conv is wide enough for the bf16x3 route (512 -> 256: the gated fp32-MFMA GEMM ran it at 81 TFLOP/s, 0.173 ms per step
+    // and 41 us for a single clip; a memory-bound gate pass + the split GEMM take 0.10 ms / 16 us).  The choice depends on the
+    // weight's shape and the context's route only, never on the batch.
+    const bool wide_up = ctx->img(w.w) != nullptr && gemm_split_eligible(w.cout, w.cin);
+    if (w.cin % 16 != 0 || e.c != w.cin || wide_up) {
         L3AC_TRY(run_enhance(ctx, s, e, x, x, batch, frames));
         return run_up(ctx, s, w, x, tmp, y, batch, frames);
     }

@@ -236,7 +236,7 @@ def test_conv_units_narrow_ring_and_split_forms(full):
         assert d < 5e-5
         # the kernel's other geometries (other waves x workgroups, 32 frames per wave, fragments read one piece ahead) evaluate the
         # same operations in the same order per frame: identical results
-        for geometry in (1, 5, 8):
+        for geometry in (1, 5, 8, 9):  # 9: the small-grid geometry (four waves per workgroup) whatever the size
             ctx.set_option("narrow_ring", 2)
             ctx.set_option("ring_geometry", geometry)
             try:
