@@ -389,7 +389,7 @@ def main():
         value = world * b * samples * args.steps / elapsed
         gflop_clip = algorithmic_gflop_per_clip_second(mc) * args.seconds
         if dry:
-            kernels, shapes, total_ms, roof = [], [], 0.0, None
+            kernels, shapes, total_ms, roof, runner_up = [], [], 0.0, None, None
         else:
             # ---- per-kernel roofline: one extra, untimed step with HIP events around every launch ----------
             with _capi.profile() as prof:
@@ -398,6 +398,12 @@ def main():
             total_ms = sum(e["ms_total"] for e in kernels)
             roof = roofline_of(kernels[0], total_ms)
             attach_traffic(roof, args.profiles_dir, f"{args.config} b{b} s{samples} {args.gemm}")
+            # the two largest kernels are within 1 % of each other (gemm_split: 14 launches of 8 shapes; conv_unit_wide<256>: 3
+            # launches): the runner-up's roofline is printed too, so that the line does not flip its story with the box
+            runner_up = None
+            if len(kernels) > 1:
+                runner_up = roofline_of(kernels[1], total_ms)
+                attach_traffic(runner_up, args.profiles_dir, f"{args.config} b{b} s{samples} {args.gemm}")
         out = {
             "metric": "audio samples/sec encode+decode, 1kbps@16kHz, batch 256; indices bit-exact" if not dry else
                       "DRY RUN ON CPU (gloo ranks, stand-in codec): plumbing check of the N-rank bench path, not a measurement",
@@ -419,6 +425,7 @@ def main():
                        "batch_per_gpu": b, "samples_per_clip": samples, "weights": "seeded synthetic (seed 0)",
                        "hipgraph": bool(args.graph)},
             "roofline": roof,
+            "roofline_runner_up": runner_up,
             "e2e": {"algorithmic_gflop_per_step": gflop_clip * b,
                     "achieved_tflops": gflop_clip * b * world / (ms_per_step * 1e-3) / 1e3,
                     "frac_of_f32_mfma_peak": gflop_clip * b / (ms_per_step * 1e-3) / 1e3 / PEAK_F32_TFLOPS,
