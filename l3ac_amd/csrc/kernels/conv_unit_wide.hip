@@ -243,6 +243,13 @@ __device__ __forceinline__ f32x4_t mfma_plane(const bf16x8 (&a)[3], const bf16x8
 // of MFMAs on its one SIMD however fast the weights arrive.  With 16 frames per wave there are twice the waves, every weight piece
 // meets one column group instead of two, and the activation has only its "frame half 0" stream (beside the second product of the
 // previous hidden tile).  Per element the same products in the same order: the same bits as FH = 2 (tested).
+// L3AC_WIDE_NT: non-temporal policy on the main kernel's STREAMED data — bit 0 the operand planes, bit 1 the residual rows, bit 2 the
+// output rows — so that they do not evict the weight image from L2 (PMC: the C = 256 unit fetched 1.96 x its algorithmic bytes, the
+// excess being ~250 re-fetches of the 3.1 MB image per launch).  Measured (profiles/r04/wide_nt.md, two interleaved rounds on one
+// box): all three on, the three C = 256 units 3.16-3.21 -> 3.06-3.07 ms, the next unit's front end 0.47 -> 0.44, the step - 1.7 %.
+#ifndef L3AC_WIDE_NT
+#define L3AC_WIDE_NT 7
+#endif
 #ifndef L3AC_WIDE_HALF_NT
 #define L3AC_WIDE_HALF_NT 0  // 1: the half-tile form's weight copies non-temporal — measured: no gain (86 vs 83 us at C = 256, 51 vs 52 at C = 192)
 #endif
@@ -348,7 +355,10 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
 #pragma unroll
             for (int s = 0; s < G::NS1 / (3 - FH); ++s)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) ap[s][pl] = *reinterpret_cast<const bf16x8*>(src + ((FH == 1 ? 2 * s : s) * 3 + pl) * 1024);
+                for (int pl = 0; pl < 3; ++pl) {
+                    const bf16x8* q = reinterpret_cast<const bf16x8*>(src + ((FH == 1 ? 2 * s : s) * 3 + pl) * 1024);
+                    ap[s][pl] = (L3AC_WIDE_NT & 1) ? __builtin_nontemporal_load(q) : *q;
+                }
         }
 
         // At C = 256 the 192 operand registers, the 160 accumulators and the activation's working set exceed the 256 arch VGPRs:
@@ -539,7 +549,12 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
             for (int i = 0; i < 2 * FH; ++i) {
                 const int64_t rr = row0 + 8 * i + er;
                 const bool ok = tile_ok && rr < rows;
-                xres[ct][i] = *reinterpret_cast<const float4*>(x + (ok ? rr : 0) * C + 32 * ct + 4 * es);
+                {
+                    typedef float f4nt __attribute__((ext_vector_type(4)));
+                    const f4nt* q = reinterpret_cast<const f4nt*>(x + (ok ? rr : 0) * C + 32 * ct + 4 * es);
+                    const f4nt v = (L3AC_WIDE_NT & 2) ? __builtin_nontemporal_load(q) : *q;
+                    xres[ct][i] = make_float4(v.x, v.y, v.z, v.w);
+                }
             }
         // ---- last hidden tile: frame half 1 of its activation alone, second product from slots NA .. 2NA-1 ------------------
         if constexpr (FH == 2) {
@@ -586,9 +601,12 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
                     const int r = 8 * i + er;
                     const int64_t rr = row0 + r;
                     const float4 v = *reinterpret_cast<const float4*>(tb + 128 * r + 16 * (es ^ ((r ^ (r >> 3)) & 7)));
-                    if (tile_ok && rr < rows)
-                        *reinterpret_cast<float4*>(y + rr * C + 32 * ct + 4 * es) =
-                            make_float4(xres[ct][i].x + v.x, xres[ct][i].y + v.y, xres[ct][i].z + v.z, xres[ct][i].w + v.w);
+                    if (tile_ok && rr < rows) {
+                        typedef float f4nt __attribute__((ext_vector_type(4)));
+                        const f4nt o = {xres[ct][i].x + v.x, xres[ct][i].y + v.y, xres[ct][i].z + v.z, xres[ct][i].w + v.w};
+                        if (L3AC_WIDE_NT & 4) __builtin_nontemporal_store(o, reinterpret_cast<f4nt*>(y + rr * C + 32 * ct + 4 * es));
+                        else *reinterpret_cast<f4nt*>(y + rr * C + 32 * ct + 4 * es) = o;
+                    }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
