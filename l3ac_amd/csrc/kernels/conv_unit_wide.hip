@@ -700,6 +700,7 @@ __global__ __launch_bounds__(256) void dwconv_ln_split_kernel(const ConvUnitW w,
     }
     __syncthreads();
     unsigned char* out = planes + tile * (int64_t)IMG;
+    // (plain stores: the planes are the main kernel's next read; non-temporal ones cost the front end 3 %: profiles/r04/wide_nt.md)
     for (int o = 16 * threadIdx.x; o < IMG; o += 16 * 256) *reinterpret_cast<u32x4*>(out + o) = *reinterpret_cast<const u32x4*>(img + o);
 }
 

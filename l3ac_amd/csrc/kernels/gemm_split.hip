@@ -202,6 +202,16 @@ __device__ __forceinline__ void gemm_split_body32(const GemmArgs& p, const int g
 //                    swizzle are the 32x32 kernel's (any 64 lanes of this pattern touch 64 distinct 16-B slots of one KB).
 //   D:               acc[h][t][i] = c[row 16 h + 4 (lane >> 4) + i][column 16 t + (lane & 15)].
 typedef float f32x4a __attribute__((ext_vector_type(4)));
+// L3AC_GEMM_NT: the bf16x3 GEMMs' output stores non-temporal (bias / residual / snake epilogues): the streamed-out C tile does not
+// push the A panel and the W tiles, which the column blocks of the same XCD re-read, out of L2.  Measured (profiles/r04/wide_nt.md):
+// the step's 14 launches 3.05-3.07 -> 2.99 ms in both of two interleaved rounds (the consumer of the hidden tensor included).
+#ifndef L3AC_GEMM_NT
+#define L3AC_GEMM_NT 1
+#endif
+__device__ __forceinline__ void c_store(float* p, float v) {
+    if (L3AC_GEMM_NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
 
 // Epilogue of the 16x16 accumulator layout.  Stored as they are, the tiles give 64-B row segments (16 lanes x 4 B) — measured: 29-42 k
 // cycles per block, a quarter to a half of a block's life, ten times the 32x32 layout's epilogue.  v_permlane16_swap_b32 exchanges the
@@ -284,8 +294,8 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmArgs& p, f32x4a (&acc)
                             continue;
                         }
 #endif
-                        if (m < p.m) p.c[m * p.ldc + n] = o.x;
-                        if (m + 1 < p.m) p.c[(m + 1) * p.ldc + n] = o.y;
+                        if (m < p.m) c_store(p.c + m * p.ldc + n, o.x);
+                        if (m + 1 < p.m) c_store(p.c + (m + 1) * p.ldc + n, o.y);
                     }
                 continue;
             }
@@ -297,7 +307,7 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmArgs& p, f32x4a (&acc)
                     if (m >= p.m) continue;
                     float v = (half ? up[i] : lo[i]) + bias;
                     if (p.epi == EPI_BIAS_RES) v = p.res[m * p.ldres + n] + v;
-                    p.c[m * p.ldc + n] = v;
+                    c_store(p.c + m * p.ldc + n, v);
                 }
         }
     }
