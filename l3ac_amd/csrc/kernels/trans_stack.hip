@@ -380,7 +380,10 @@ void trans_stack_kernel(const TransStackArgs p) {
         if (tid == 0) {
             __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned want = (unsigned)TS_KS * (unsigned)(coop_phase + 1);
-            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(2);
+            // (bounded: were the six workgroups of a clip ever not co-resident — a CU mask, a debugger holding CUs — the launch ends
+            // with wrong numbers after some seconds instead of hanging the device)
+            for (unsigned spins = 0; __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && spins < (1u << 25); ++spins)
+                __builtin_amdgcn_s_sleep(2);
         }
         __builtin_amdgcn_s_barrier();                      // the poll has matched: all six partials of this phase are in memory
         TS_STAMP(11);  // arrival + wait for the other five
