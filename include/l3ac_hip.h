@@ -247,10 +247,10 @@ int l3ac_ctx_set_gemm_split(l3ac_ctx* ctx, int32_t enable);
  * one (C = 48, 96), 2 = wherever it exists (C = 24 too).  Both evaluate the same operations; their results agree to rounding.
  * "ring_geometry" (diagnostics) runs conv_unit_ring_kernel in another geometry with the same results: 0 default, 1 other waves x
  * workgroups, 5 32 frames per wave, 8 fragments read one piece ahead.
- * "trans_coop" (default 1): batches of at most 8 clips — a streaming chunk is one — run every LocalTrans stack in the cooperative
+ * "trans_coop" (default 1): batches of at most 32 clips — a streaming chunk is one — run every LocalTrans stack in the cooperative
  * form of trans_stack_kernel (six co-resident workgroups per clip exchanging partial tiles through global memory); 0 keeps one
- * workgroup per clip.  Both forms return the same bits.  The cooperative form's workgroups wait for each other: it needs 48 free
- * CUs to make progress, which any other work on the device only delays.
+ * workgroup per clip.  Both forms return the same bits.  The cooperative form's six workgroups per clip wait for each other: they need
+ * six free CUs per clip to make progress, which any other work on the device only delays.
  * Unknown names return L3AC_EINVAL. */
 int l3ac_ctx_set_option(l3ac_ctx* ctx, const char* name, int32_t value);
 int32_t l3ac_ctx_get_gemm_split(const l3ac_ctx* ctx);

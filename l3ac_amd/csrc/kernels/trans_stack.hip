@@ -99,9 +99,10 @@ struct TransStackArgs {
     float* coop_x;
     unsigned* coop_cnt;
     int batch;
+    int coop_slots;            // clip slots of this launch: the batch rounded up to a multiple of 8 (grid = TS_KS * coop_slots)
 };
 constexpr int TS_KS = 6;                                    // workgroups per clip of the cooperative form (= heads)
-constexpr int TS_COOP_CLIPS = 8;                            // clip slots: blocks b and b + 8 are dealt to the same XCD (speed only)
+constexpr int TS_COOP_CLIPS = 32;                           // clip slots (a multiple of 8: blocks b and b + 8 are dealt to the same XCD — speed only)
 constexpr int64_t TS_COOP_SLAB_FLOATS = 2LL * TS_KS * 192 * TS_DIM;
 constexpr int64_t TS_COOP_X_FLOATS = (int64_t)TS_KS * 192 * TS_DIM;
 
@@ -143,10 +144,10 @@ void trans_stack_kernel(const TransStackArgs p) {
     constexpr bool COOP = KS > 1;
     static_assert(KS == 1 || KS == TS_HEADS, "one workgroup per clip, or one per head");
     using L = TsLds<MAXW>;
-    // cooperative form: block = part * TS_COOP_CLIPS + clip slot (the KS workgroups of a clip are 8 blocks apart: one XCD under the
-    // observed round-robin placement); slots beyond the batch have nothing to do
-    const int clip = COOP ? (int)(blockIdx.x % TS_COOP_CLIPS) : (int)blockIdx.x;
-    const int part = COOP ? (int)(blockIdx.x / TS_COOP_CLIPS) : 0;
+    // cooperative form: block = part * coop_slots + clip slot, coop_slots a multiple of 8 (the KS workgroups of a clip are then a
+    // multiple of 8 blocks apart: one XCD under the observed round-robin placement); slots beyond the batch have nothing to do
+    const int clip = COOP ? (int)(blockIdx.x % (unsigned)p.coop_slots) : (int)blockIdx.x;
+    const int part = COOP ? (int)(blockIdx.x / (unsigned)p.coop_slots) : 0;
     if (COOP && clip >= p.batch) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_ts[];
     const int tid = threadIdx.x;
@@ -651,7 +652,7 @@ template <int MAXW>
 static void launch_ts(hipStream_t s, bool coop, int batch, int waves, int n_layers, const TransStackArgs& a) {
     const unsigned threads = 64 * (waves + (TsLds<MAXW>::LOADER ? TsLds<MAXW>::NDW : 0));  // (+ the loader waves)
     if (coop)
-        hipLaunchKernelGGL((trans_stack_kernel<MAXW, TS_KS>), dim3(TS_KS * TS_COOP_CLIPS), dim3(threads), TsLds<MAXW>::bytes(n_layers), s, a);
+        hipLaunchKernelGGL((trans_stack_kernel<MAXW, TS_KS>), dim3(TS_KS * a.coop_slots), dim3(threads), TsLds<MAXW>::bytes(n_layers), s, a);
     else
         hipLaunchKernelGGL((trans_stack_kernel<MAXW, 1>), dim3((unsigned)batch), dim3(threads), TsLds<MAXW>::bytes(n_layers), s, a);
 }
@@ -675,11 +676,11 @@ int launch_trans_stack(hipStream_t s, const LocalTransW& w, float* x, int batch,
     }
     int waves = 2 * (int)ceil_div64(frames, 32);  // even: every key tile a wave reads in pairs has been written by some wave
     if (waves < 4) waves = 4;                      // (the 4-wave instantiation adds its loader wave at the launch)
-    // the cooperative form needs its TS_KS workgroups per clip co-resident (they wait for each other): 48 workgroups of one per CU
+    // the cooperative form needs its TS_KS workgroups per clip co-resident (they wait for each other): 192 workgroups of one per CU
     const bool use_coop = coop != nullptr && batch <= TS_COOP_CLIPS && l3ac_device_cu_count() >= TS_KS * TS_COOP_CLIPS;
     TransStackArgs a{};
     a.x = x; a.frames = frames; a.n_layers = n_layers; a.img = w.stack_img; a.ln = w.stack_ln; a.bias_table = w.bias_table;
-    a.table_stride = 2 * w.window; a.scale = scale; a.batch = batch;
+    a.table_stride = 2 * w.window; a.scale = scale; a.batch = batch; a.coop_slots = (batch + 7) / 8 * 8;
     if (use_coop) {
         a.coop_slab = reinterpret_cast<float*>(coop);
         a.coop_x = a.coop_slab + (int64_t)TS_COOP_CLIPS * TS_COOP_SLAB_FLOATS;

@@ -459,18 +459,19 @@ def test_local_trans_stack_kernel(full):
 
 
 def test_local_trans_stack_cooperative_form(full):
-    """The cooperative form of trans_stack_kernel (batches of at most 8 clips — a streaming chunk is one: six co-resident workgroups
+    """The cooperative form of trans_stack_kernel (batches of at most 32 clips — a streaming chunk is one: six co-resident workgroups
     per clip, one head / one pair of FeedForward chunks each, partial tiles exchanged through write-through slabs behind an arrival
     counter and added in a fixed order) must return the SAME BITS as the one-workgroup form, which sums its heads and chunk pairs in
     that order too: checked through the context option that switches the form off, for every wave-count instantiation (<= 64, <=
-    128, <= 192 frames), ragged lengths, 1 .. 8 clips, a single frame; against clips of a large batch (batch invariance across the
+    128, <= 192 frames), ragged lengths, 1 .. 32 clips, a single frame; against clips of a large batch (batch invariance across the
     two forms); and launch after launch on one context (the arrival counters are left zeroed by every launch)."""
     codec, mc, w = full
     ctx = codec.network.context()
     cases = [("en_encoder.down_trans.trans", 180, 1), ("en_decoder.up_trans.trans", 180, 3), ("en_decoder.up_trans.trans", 177, 8),
              ("en_decoder.local_trans", 60, 1), ("en_encoder.local_trans", 60, 5), ("en_decoder.local_trans", 45, 2),
              ("en_decoder.up_trans.trans", 100, 1), ("en_decoder.up_trans.trans", 128, 4), ("en_decoder.local_trans", 1, 2),
-             ("en_decoder.up_trans.trans", 192, 2), ("en_decoder.local_trans", 17, 7)]
+             ("en_decoder.up_trans.trans", 192, 2), ("en_decoder.local_trans", 17, 7), ("en_decoder.up_trans.trans", 180, 32),
+             ("en_decoder.local_trans", 60, 21)]
     for block, t, bsz in cases:
         x = _rand((bsz, t, 128), 900 + t + bsz)
         coop = [G.op_block(ctx, "l3ac_op_local_trans", block, x.cuda(), (bsz, t, 128)).cpu() for _ in range(3)]
