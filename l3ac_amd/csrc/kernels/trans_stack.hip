@@ -676,8 +676,8 @@ int launch_trans_stack(hipStream_t s, const LocalTransW& w, float* x, int batch,
     }
     int waves = 2 * (int)ceil_div64(frames, 32);  // even: every key tile a wave reads in pairs has been written by some wave
     if (waves < 4) waves = 4;                      // (the 4-wave instantiation adds its loader wave at the launch)
-    // the cooperative form needs its TS_KS workgroups per clip co-resident (they wait for each other): 192 workgroups of one per CU
-    const bool use_coop = coop != nullptr && batch <= TS_COOP_CLIPS && l3ac_device_cu_count() >= TS_KS * TS_COOP_CLIPS;
+    // the cooperative form needs its TS_KS workgroups per clip co-resident (they wait for each other), one workgroup per CU
+    const bool use_coop = coop != nullptr && batch <= TS_COOP_CLIPS && l3ac_device_cu_count() >= TS_KS * ((batch + 7) / 8 * 8);
     TransStackArgs a{};
     a.x = x; a.frames = frames; a.n_layers = n_layers; a.img = w.stack_img; a.ln = w.stack_ln; a.bias_table = w.bias_table;
     a.table_stride = 2 * w.window; a.scale = scale; a.batch = batch; a.coop_slots = (batch + 7) / 8 * 8;
