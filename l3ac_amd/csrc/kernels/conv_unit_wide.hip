@@ -253,12 +253,15 @@ __device__ __forceinline__ f32x4_t mfma_plane(const bf16x8 (&a)[3], const bf16x8
 #ifndef L3AC_WIDE_HALF_NT
 #define L3AC_WIDE_HALF_NT 0  // 1: the half-tile form's weight copies non-temporal — measured: no gain (86 vs 83 us at C = 256, 51 vs 52 at C = 192)
 #endif
-template <int C, int FH = 2>
+// tail_tiles (FHK = 2 only): the LAST tail_tiles 32-frame tiles are left out of the lock-step passes and run afterwards as half tiles on
+// the first workgroups — 256 x 900 frames at C = 256 are 7 full passes + 32 tiles, and an eighth pass for 0.4 % of the tiles cost 12 %
+// of the unit; as 64 half tiles on 16 workgroups it costs half a pass.
+template <int C, int FHK = 2>
 __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW w, const unsigned char* __restrict__ planes,
-                                                              const float* __restrict__ x, float* __restrict__ y, const int64_t rows) {
+                                                              const float* __restrict__ x, float* __restrict__ y, const int64_t rows,
+                                                              const int64_t tail_tiles) {
     using G = WGeo<C>;
-    static_assert(FH == 1 || FH == 2, "one or two frame halves per wave");
-    constexpr int GPP = 6 * FH;  // MFMA gaps per weight piece
+    static_assert(FHK == 1 || FHK == 2, "one or two frame halves per wave");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_wide[];
     unsigned char* ring = smem_wide + G::OFF_RING;
     float* Pt = reinterpret_cast<float*>(smem_wide + G::OFF_P);
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
     int dma_slot = 0;  // next slot of the stream to fetch (wave-uniform)
     auto issue = [&](int ring_pos) __attribute__((always_inline)) {
 #ifndef L3AC_WIDE_NODMA  // (timing experiments only)
-        dma_slot_quarter<G::DMA_N, (FH == 1) && L3AC_WIDE_HALF_NT>(src_wave + (int64_t)dma_slot * G::SLOT, lane_off, ring_lds + (unsigned)(ring_pos * G::SLOT) + (unsigned)(G::SLOT / 4) * (unsigned)wave);
+        dma_slot_quarter<G::DMA_N, (FHK == 1) && L3AC_WIDE_HALF_NT>(src_wave + (int64_t)dma_slot * G::SLOT, lane_off, ring_lds + (unsigned)(ring_pos * G::SLOT) + (unsigned)(G::SLOT / 4) * (unsigned)wave);
 #endif
         dma_slot = dma_slot + 1 == G::TOTAL ? 0 : dma_slot + 1;
     };
@@ -317,7 +320,8 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
     for (int i = tid; i < C; i += 256) B2s[i] = w.b2[i];
     __syncthreads();  // (plain loads above: hipcc drains them here, the DMA pieces with them)
 
-    const int64_t n_tiles = (FH == 2 ? 1 : 2) * ((rows + 31) / 32);  // work units: 32-frame tiles, or their 16-frame halves
+    const int64_t tiles32 = (rows + 31) / 32;
+    const int64_t n_tiles = FHK == 2 ? tiles32 - tail_tiles : 2 * tiles32;  // units of the lock-step passes: 32-frame tiles, or 16-frame halves
     const int64_t tile_stride = (int64_t)gridDim.x * 4;
 #ifndef L3AC_WIDE_NO_STAGGER
     // Passes run in lock step across the chip, so every workgroup would fetch its operand planes and store its tile at the
@@ -330,7 +334,11 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
         const int64_t max_passes = (wg_passes + gridDim.x - 1) / gridDim.x;
         const int64_t my_passes = (wg_passes - blockIdx.x + gridDim.x - 1) / gridDim.x;
         constexpr long long PASS_CYCLES = (long long)G::NT * G::NSTEP * (12 * G::KS) * 16 * 6 / 5 + 35000;
-        const long long delay = my_passes < max_passes ? (long long)((blockIdx.x >> 3) & 7) * (PASS_CYCLES * 9 / 80) : 0;
+        // (with a tail of half tiles the workgroups that do NOT run it have half a pass of slack)
+        const bool tail_slack = FHK == 2 && tail_tiles > 0 && (int64_t)blockIdx.x * 4 >= 2 * tail_tiles;
+        const long long delay = my_passes < max_passes ? (long long)((blockIdx.x >> 3) & 7) * (PASS_CYCLES * 9 / 80)
+                                : tail_slack        ? (long long)((blockIdx.x >> 3) & 7) * (PASS_CYCLES * 9 / 160)
+                                                    : 0;
         const long long t0 = (long long)__builtin_amdgcn_s_memtime();
         while ((long long)__builtin_amdgcn_s_memtime() - t0 < delay) __builtin_amdgcn_s_sleep(16);
     }
@@ -338,11 +346,13 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
     // every wave of the block runs the same number of passes (block barriers inside)
     int pass_no = 0;
     (void)pass_no;
-    for (int64_t base = (int64_t)blockIdx.x * 4; base < n_tiles; base += tile_stride, ++pass_no) {
+    // one unit of FH frame halves: `tile` counts units of 16 FH frames from row 0, units >= unit_limit are computed but not stored
+    auto run_unit = [&](auto fh_, const int64_t tile, const int64_t unit_limit) __attribute__((always_inline)) {
+        constexpr int FH = decltype(fh_)::value;
+        constexpr int GPP = 6 * FH;  // MFMA gaps per weight piece
         WIDE_STAMP(0);
-        const int64_t tile = base + wave;              // this wave's unit (beyond the last one: its results are not stored)
         const int64_t row0 = tile * (16 * FH);
-        const bool tile_ok = tile < n_tiles;
+        const bool tile_ok = tile < unit_limit;
         const int64_t tile32 = FH == 2 ? tile : tile >> 1;  // the 32-frame tile of the operand-plane image
         const int fsel = FH == 2 ? 0 : (int)(tile & 1);     // FH = 1: which frame half of it
 
@@ -612,6 +622,13 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
+    };
+    for (int64_t base = (int64_t)blockIdx.x * 4; base < n_tiles; base += tile_stride, ++pass_no)
+        run_unit(std::integral_constant<int, FHK>{}, base + wave, n_tiles);  // (every wave of the block runs the same number of passes)
+    if constexpr (FHK == 2) {
+        // the tail: half tiles 2 n_tiles .. 2 tiles32 - 1 (the weight stream continues where the last pass left it)
+        for (int64_t base = (int64_t)blockIdx.x * 4; base < 2 * tail_tiles; base += tile_stride, ++pass_no)
+            run_unit(std::integral_constant<int, 1>{}, 2 * n_tiles + base + wave, 2 * tiles32);
     }
     WIDE_STAMP(6);
     // leave no LDS-DMA in flight behind the workgroup
@@ -733,26 +750,16 @@ int launch_wide(hipStream_t s, const ConvUnitW& w, const float* x, float* y, uns
     ProfScope prof(s, name, (double)rows * (16.0 * C * C), (double)rows * 14.0 * C);
     if (half) {
         blocks = ceil_div64(2 * tiles, 4);
-        hipLaunchKernelGGL((conv_unit_wide_kernel<C, 1>), dim3((unsigned)blocks), dim3(256), G::LDS, s, w, planes, x, y, rows);
+        hipLaunchKernelGGL((conv_unit_wide_kernel<C, 1>), dim3((unsigned)blocks), dim3(256), G::LDS, s, w, planes, x, y, rows, (int64_t)0);
     } else {
-        // A large grid runs ceil(tiles / (4 x 256)) passes in lock step and the last one may be nearly empty (256 x 900 frames at
-        // C = 256: 7 200 tiles = 7 full passes + 32 tiles — an eighth pass for 0.4 % of the work).  When the remainder fits one pass
-        // of HALF tiles, it runs as a second launch of the 16-frame form (about 0.65 of a full pass) over the last rows; tiles are
-        // 32 consecutive global rows, so the split is a pointer offset.
+        // A large grid runs its tiles in lock-step passes of 4 x 256 and the last pass may be nearly empty (256 x 900 frames at C = 256:
+        // 7 200 tiles = 7 full passes + 32 tiles).  A remainder of at most half a pass is left out of the passes and run as HALF tiles
+        // by the first workgroups, inside the same launch (conv_unit_wide_kernel, tail_tiles).
         const int64_t per_pass = 4LL * 256;
         const int64_t full = tiles / per_pass * per_pass, rest = tiles - full;
-        // (Not for a SMALL remainder: with exactly full passes no workgroup has the slack the staggered start above lives on, and at
-        // 7 passes + 32 tiles the main launch lost more (3.03 -> 3.08 ms for the three C = 256 units) than the eighth pass costs;
-        // 1 pass + 416 tiles, the C = 192 units: 0.34 -> 0.30 ms.)
-        const bool tail = half_mode >= 2 && full > 0 && 8 * rest >= per_pass && 2 * rest <= per_pass;
-        const int64_t main_rows = tail ? full * 32 : rows;
+        const int64_t tail = (half_mode >= 2 && full > 0 && 2 * rest <= per_pass) ? rest : 0;
         if (blocks > 256) blocks = 256;
-        hipLaunchKernelGGL((conv_unit_wide_kernel<C, 2>), dim3((unsigned)blocks), dim3(256), G::LDS, s, w, planes, x, y, main_rows);
-        if (tail) {
-            L3AC_LAUNCH_CHECK();
-            hipLaunchKernelGGL((conv_unit_wide_kernel<C, 1>), dim3((unsigned)ceil_div64(2 * rest, 4)), dim3(256), G::LDS, s, w,
-                               planes + full * (int64_t)(G::NS1 * 3072), x + full * 32 * C, y + full * 32 * C, rows - full * 32);
-        }
+        hipLaunchKernelGGL((conv_unit_wide_kernel<C, 2>), dim3((unsigned)blocks), dim3(256), G::LDS, s, w, planes, x, y, rows, tail);
     }
     L3AC_LAUNCH_CHECK();
     return L3AC_OK;
