@@ -497,11 +497,16 @@ def test_local_trans_stack_cooperative_form(full):
     want = G.op_block(ctx, "l3ac_op_local_trans", block, x.cuda(), (2, t, 128)).cpu()
     side = torch.cuda.Stream()
     a = torch.randn(4096, 4096, device="cuda")
-    for i in range(20):
+    big = torch.empty(64 << 20, device="cuda")
+    xg = x.cuda()
+    for i in range(300):  # every word of every launch is compared: a stale partial shows as a different bit pattern
         with torch.cuda.stream(side):
-            (a @ a).sum()
-        got = G.op_block(ctx, "l3ac_op_local_trans", block, x.cuda(), (2, t, 128)).cpu()
-        assert torch.equal(got, want), f"launch {i}"
+            if i % 3 == 0:
+                (a @ a).sum()        # matrix-core load on the other CUs
+            elif i % 3 == 1:
+                big.mul_(1.0001)     # a 512 MB memory stream through every L2
+        got = G.op_block(ctx, "l3ac_op_local_trans", block, xg, (2, t, 128))
+        assert torch.equal(got.cpu(), want), f"launch {i}"
     torch.cuda.synchronize()
 
 
