@@ -39,6 +39,7 @@ SOURCES = [
     "kernels/conv_unit_ring.hip",
     "kernels/last_block.hip",
     "kernels/bitpack.hip",
+    "kernels/up_fused.hip",
 ]
 
 

@@ -1,0 +1,260 @@
+// Decoder up layer in ONE kernel (reference l3ac/tconv/__init__.py:35-44 + l3ac/modules.py:160-164):
+//
+//     x' = x + merge(instnorm(branches(x))) * x          EnhanceBlock gate (the branch signals and their statistics come from
+//                                                          enhance_branches / enhance_stats: they need the whole clip first)
+//     c  = Conv1d(Cin -> Cout, k = 1)(x')                  weight-normed, folded at load
+//     u  = Upsample(scale s, linear, align_corners=False)(c)
+//     y  = ChannelNorm(u)                                  channels_first: (u - mean_C) / sqrt(var_C + eps) * w + b
+//
+// What it replaces, for the NARROW up layers (256 -> 96, 96 -> 48, 48 -> 24): the gated fp32-MFMA GEMM (a small-N product that ran at
+// 2.1-3.4 TB/s of its own bytes: 0.15-0.18 ms each at 256 clips), the [frames][Cout] tensor it wrote, and row_kernel<LERP,CN> that
+// read it back — 0.86 ms of the step for 2 GB of algorithmic traffic.
+//
+// One WAVE owns 16 consecutive input frames of a clip.  The conv is "weights (A) x activations (B)" on v_mfma_f32_16x16x32_bf16 with
+// both operands as exact bf16x3 splits (ring_common.hpp: fp32 accuracy): lane (frame fl, k group g) loads the 8 channels
+// sigma(g, .) of ITS frame for each k step of 32, applies the gate in registers, splits, and multiplies against the weight pieces
+// resident in LDS; the result is in accumulator layout — channel 16 rt + 4 g + i of frame fl in register i of tile rt.  In that
+// layout the linear upsample needs the neighbouring FRAME = the neighbouring lane of the 16-lane row (two DPP row shifts per
+// register), and ChannelNorm's sums are RT x 4 registers plus the four k groups of a frame (permlane swaps): nothing goes through
+// LDS or memory between the conv and the store.  Output frames s i .. s i + s - 1 of input frame i interpolate between frames i - 1,
+// i, i + 1 only, so a wave stores the outputs of the 14 inner frames of its tile and tiles advance by 14 (12.5 % of the products and
+// of the L2-served loads are redundant; HBM traffic is the algorithmic 4 Cin B in + 4 s Cout B out per frame).
+// The arithmetic of gate, lerp and norm is row_kernel's, operation for operation.
+#include "../kernels.hpp"
+#include "../network.hpp"
+#include "device_math.hpp"
+#include "ring_common.hpp"
+
+#include <vector>
+
+namespace {
+
+constexpr int UF_WAVES = 16;  // one workgroup of 16 waves per CU (the 256 -> 96 weights are 144 KB of LDS)
+constexpr int UF_CORE = 14;   // frames of a 16-frame tile whose outputs the wave stores
+
+struct UpFusedArgs {
+    const float* x;
+    float* y;
+    int batch, frames, scale;
+    const unsigned char* img;  // RT x K1 pieces
+    const float* bias;         // [cout]
+    const float* nw;           // ChannelNorm affine [cout]
+    const float* nb;
+    float eps;
+    const float* yi;           // raw branch signals [batch][frames][4]
+    const float* stats;        // [batch][8] = mean[4], 1 / std[4]
+    const float* in_w;         // InstanceNorm affine [4]
+    const float* in_b;
+    const float* gate_w;       // merge conv [cin][4]
+    const float* gate_b;       // [cin]
+};
+
+template <int CIN, int COUT>
+struct UfGeo {
+    static constexpr int K1 = (CIN + 31) / 32, RT = (COUT + 15) / 16, CP = 16 * RT, CINP = 32 * K1;
+    static constexpr int OFF_W = 0;
+    static constexpr int OFF_PAR = RT * K1 * 3072;       // bias | nw | nb, CP floats each (zeros beyond cout)
+    static constexpr int OFF_GW = OFF_PAR + 3 * CP * 4;  // gate_w [CINP][4] | gate_b [CINP] (zeros beyond cin)
+    static constexpr int LDS = OFF_GW + CINP * 5 * 4;
+    static_assert(CIN % 16 == 0 && COUT % 8 == 0 && LDS <= 160 * 1024, "geometry");
+};
+
+// value of the lane one position down / up inside its 16-lane row (frame fl - 1 / fl + 1 of the same k group)
+__device__ __forceinline__ float row_prev(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false));  // row_shr:1
+}
+__device__ __forceinline__ float row_next(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, false));  // row_shl:1
+}
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(64 * UF_WAVES, UF_WAVES / 4) void up_fused_kernel(const UpFusedArgs p, const int tiles_per_clip, const int n_tiles) {
+    using G = UfGeo<CIN, COUT>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_uf[];
+    float* const par = reinterpret_cast<float*>(smem_uf + G::OFF_PAR);
+    float* const gws = reinterpret_cast<float*>(smem_uf + G::OFF_GW);
+    float* const gbs = gws + 4 * G::CINP;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < G::RT * G::K1 * 3072 / 16; i += 64 * UF_WAVES)
+        reinterpret_cast<u32x4*>(smem_uf)[i] = reinterpret_cast<const u32x4*>(p.img)[i];
+    for (int i = tid; i < G::CP; i += 64 * UF_WAVES) {
+        par[i] = i < COUT ? p.bias[i] : 0.f;
+        par[G::CP + i] = i < COUT ? p.nw[i] : 0.f;
+        par[2 * G::CP + i] = i < COUT ? p.nb[i] : 0.f;
+    }
+    for (int i = tid; i < G::CINP; i += 64 * UF_WAVES) {
+        const float4 w4 = i < CIN ? *reinterpret_cast<const float4*>(p.gate_w + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(gws + 4 * i) = w4;
+        gbs[i] = i < CIN ? p.gate_b[i] : 0.f;
+    }
+    __syncthreads();
+
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fl = lane & 15, lg = lane >> 4;
+    const int T = p.frames, S = p.scale;
+    const float rscale = (float)(1.0 / (double)S);
+    const float4 iw = *reinterpret_cast<const float4*>(p.in_w);
+    const float4 ib = *reinterpret_cast<const float4*>(p.in_b);
+    const unsigned char* const wl = smem_uf + 16 * lane;
+
+    for (int tile = blockIdx.x * UF_WAVES + wave; tile < n_tiles; tile += gridDim.x * UF_WAVES) {
+        const int b = tile / tiles_per_clip;
+        const int k = tile - b * tiles_per_clip;
+        const int f = UF_CORE * k - 1 + fl;          // this lane's input frame
+        const bool valid = f >= 0 && f < T;
+        const int fv = valid ? f : 0;
+        const float* const row = p.x + ((int64_t)b * T + fv) * CIN;
+        // ---- gate input: z = InstanceNorm(branch signals) of this frame (rows.hip, SRC_GATE) ----------------------------------------
+        float z0, z1, z2, z3;
+        {
+            const float4 yraw = *reinterpret_cast<const float4*>(p.yi + ((int64_t)b * T + fv) * 4);
+            const float4 mean = *reinterpret_cast<const float4*>(p.stats + (int64_t)b * 8);
+            const float4 istd = *reinterpret_cast<const float4*>(p.stats + (int64_t)b * 8 + 4);
+            z0 = (yraw.x - mean.x) * istd.x * iw.x + ib.x;
+            z1 = (yraw.y - mean.y) * istd.y * iw.y + ib.y;
+            z2 = (yraw.z - mean.z) * istd.z * iw.z + ib.z;
+            z3 = (yraw.w - mean.w) * istd.w * iw.w + ib.w;
+        }
+        // ---- c^T = W . x'^T + bias ---------------------------------------------------------------------------------------------------
+        f32x4_t acc[G::RT];
+#pragma unroll
+        for (int rt = 0; rt < G::RT; ++rt) acc[rt] = *reinterpret_cast<const f32x4_t*>(par + 16 * rt + 4 * lg);
+        auto gated = [&](const f32x4_t xv, const int c0) __attribute__((always_inline)) -> f32x4_t {  // x + (gate_b + gate_w . z) * x
+            f32x4_t o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float4 gw = *reinterpret_cast<const float4*>(gws + 4 * (c0 + e));
+                const float g = gbs[c0 + e] + gw.x * z0 + gw.y * z1 + gw.z * z2 + gw.w * z3;
+                o[e] = xv[e] + g * xv[e];
+            }
+            return o;
+        };
+#pragma unroll
+        for (int s = 0; s < G::K1; ++s) {
+            const int c_lo = 32 * s + 4 * lg, c_hi = c_lo + 16;
+            f32x4_t lo = f32x4_t{0.f, 0.f, 0.f, 0.f}, hi = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if (valid) lo = gated(*reinterpret_cast<const f32x4_t*>(row + c_lo), c_lo);   // (32 s + 15 < CIN for every k step: CIN % 16 == 0)
+            if (32 * s + 16 < CIN) {
+                if (valid) hi = gated(*reinterpret_cast<const f32x4_t*>(row + c_hi), c_hi);
+            }
+            bf16x8 bp[3];
+            planes_of(lo, hi, bp);
+#pragma unroll
+            for (int rt = 0; rt < G::RT; ++rt) {
+                bf16x8 wf[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) wf[pl] = *reinterpret_cast<const bf16x8*>(wl + (rt * G::K1 + s) * 3072 + 1024 * pl);
+                acc[rt] = mfma6(wf, bp, acc[rt]);
+            }
+        }
+        const bool core = fl >= 1 && fl <= UF_CORE && f < T;  // (f >= 0 for fl >= 1)
+        float* const yclip = p.y + (int64_t)b * T * S * COUT;
+        // ---- s output frames per input frame: lerp (ATen upsample_linear1d, rows.hip SRC_LERP), ChannelNorm, store -----------------
+#pragma unroll 1
+        for (int j = 0; j < S; ++j) {
+            const int d = S * f + j;
+            float src = __fsub_rn(__fmul_rn(rscale, (float)d + 0.5f), 0.5f);
+            src = src < 0.f ? 0.f : src;
+            const int i0 = (int)src;
+            const int i1 = i0 + (i0 + 1 < T ? 1 : 0);
+            float l1 = src - (float)i0;
+            l1 = fminf(fmaxf(l1, 0.f), 1.f);
+            const float l0 = 1.f - l1;
+            const bool p0 = i0 < f, n1 = i1 > f;  // i0 in {f - 1, f}, i1 in {f, f + 1} (i1 == i0 only at the clip's last frame)
+            f32x4_t v[G::RT];
+            float s1 = 0.f;
+#pragma unroll
+            for (int rt = 0; rt < G::RT; ++rt) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    // (the neighbouring frame's value = the neighbouring lane's, fetched where it is used: kept for all s output frames,
+                    // the two shifted copies of the accumulators cost the 256 -> 96 kernel 46 spilled registers)
+                    // the shifts themselves run in EVERY lane, outside any lane-dependent control flow: a DPP read from a lane the EXEC mask has
+                    // switched off returns 0, not that lane's register (the first build selected by branching and lost frame 0 at clip starts)
+                    const float pv = row_prev(acc[rt][i]), nx = row_next(acc[rt][i]);
+                    const float x0 = p0 ? pv : acc[rt][i];
+                    const float x1 = n1 ? nx : acc[rt][i];
+                    const float u = __fadd_rn(__fmul_rn(l0, x0), __fmul_rn(l1, x1));
+                    v[rt][i] = (16 * rt + 4 * lg + i < COUT) ? u : 0.f;
+                }
+                s1 += (v[rt][0] + v[rt][1]) + (v[rt][2] + v[rt][3]);
+            }
+            const float mean = rows_sum(s1) / (float)COUT;
+            float q = 0.f;
+#pragma unroll
+            for (int rt = 0; rt < G::RT; ++rt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float dv = v[rt][i] - mean;
+                    q += (16 * rt + 4 * lg + i < COUT) ? dv * dv : 0.f;
+                }
+            const float var = rows_sum(q) / (float)COUT;
+            const float rstd = 1.0f / sqrtf(var + p.eps);
+            if (core) {
+                float* const dst = yclip + (int64_t)d * COUT + 4 * lg;
+#pragma unroll
+                for (int rt = 0; rt < G::RT; ++rt) {
+                    if (16 * rt + 4 * lg < COUT) {
+                        const f32x4_t w = *reinterpret_cast<const f32x4_t*>(par + G::CP + 16 * rt + 4 * lg);
+                        const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(par + 2 * G::CP + 16 * rt + 4 * lg);
+                        f32x4_t o;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) o[i] = w[i] * ((v[rt][i] - mean) * rstd) + bb[i];
+                        *reinterpret_cast<f32x4_t*>(dst + 16 * rt) = o;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int CIN, int COUT>
+int launch_uf(hipStream_t s, const UpFusedArgs& a) {
+    using G = UfGeo<CIN, COUT>;
+    static PerDeviceOnce configured;
+    if (configured.first()) {
+        L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(up_fused_kernel<CIN, COUT>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+        configured.done();
+    }
+    const int tiles_per_clip = (a.frames + UF_CORE - 1) / UF_CORE;
+    const int64_t tiles = (int64_t)a.batch * tiles_per_clip;
+    L3AC_REQUIRE(tiles < ((int64_t)1 << 31) - 65536 && (int64_t)a.frames * a.scale < ((int64_t)1 << 30), "up_fused: too many tiles");
+    int64_t blocks = ceil_div64(tiles, UF_WAVES);
+    const int64_t cus = l3ac_device_cu_count();
+    if (blocks > cus) blocks = cus;
+    const double rows = (double)a.batch * a.frames;
+    char name[64];
+    std::snprintf(name, sizeof(name), "up_fused_kernel<%d,%d>", CIN, COUT);
+    ProfScope prof(s, name, rows * 2.0 * CIN * COUT, rows * 4.0 * (CIN + 4 + (double)a.scale * COUT));
+    hipLaunchKernelGGL((up_fused_kernel<CIN, COUT>), dim3((unsigned)blocks), dim3(64 * UF_WAVES), G::LDS, s, a, tiles_per_clip, (int)tiles);
+    L3AC_LAUNCH_CHECK();
+    return L3AC_OK;
+}
+
+}  // namespace
+
+bool up_fused_supported(int cin, int cout) { return (cin == 256 && cout == 96) || (cin == 96 && cout == 48) || (cin == 48 && cout == 24); }
+
+// the 1x1 conv's weight [cout][cin] as RT x K1 pieces (16 rows x 32 k, three bf16 planes; zeros beyond cout / cin)
+std::vector<unsigned char> up_fused_image(const float* w, int cin, int cout) {
+    std::vector<unsigned char> img;
+    const int k1 = (cin + 31) / 32, rt_n = (cout + 15) / 16;
+    img.reserve((size_t)rt_n * k1 * 3072);
+    for (int rt = 0; rt < rt_n; ++rt)
+        for (int s = 0; s < k1; ++s) ring_put_piece(img, w, cin, cout, cin, 16 * rt, 32 * s);
+    return img;
+}
+
+// EnhanceBlock gate + up layer; yi / stats: the branch signals and statistics of x (enhance_branches / enhance_stats)
+int launch_up_fused(hipStream_t s, const EnhW& e, const UpW& w, const float* x, const float* yi, const float* stats, float* y, int batch, int frames) {
+    L3AC_REQUIRE(w.fused_img && x && y && yi && stats && batch > 0 && frames > 0 && e.c == w.cin, "up_fused: bad arguments");
+    UpFusedArgs a{};
+    a.x = x; a.y = y; a.batch = batch; a.frames = frames; a.scale = w.scale; a.img = w.fused_img; a.bias = w.b; a.nw = w.nw; a.nb = w.nb; a.eps = 1e-8f;
+    a.yi = yi; a.stats = stats; a.in_w = e.in_w; a.in_b = e.in_b; a.gate_w = e.gate_w; a.gate_b = e.gate_b;
+    if (w.cin == 256 && w.cout == 96) return launch_uf<256, 96>(s, a);
+    if (w.cin == 96 && w.cout == 48) return launch_uf<96, 48>(s, a);
+    if (w.cin == 48 && w.cout == 24) return launch_uf<48, 24>(s, a);
+    l3ac_set_error("up_fused: %d -> %d not supported", w.cin, w.cout);
+    return L3AC_EINVAL;
+}

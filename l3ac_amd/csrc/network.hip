@@ -407,6 +407,10 @@ int network_build(l3ac_ctx* ctx, const l3ac_tensor* tensors, int n_tensors) {
                             b.extra_imgs.push_back({conv_unit_wide_image(b.host_of(u.w1), b.host_of(u.w2), u.c), &u.wide_img});
                         }
         }
+        if (b.err.empty()) {  // (ctx->dec_up was sized before the loop above: the targets stay valid)
+            for (UpW& u : ctx->dec_up)
+                if (up_fused_supported(u.cin, u.cout)) b.extra_imgs.push_back({up_fused_image(b.host_of(u.w), u.cin, u.cout), &u.fused_img});
+        }
         if (b.err.empty() && last_block_fused_supported(cl, 9)) {  // (ctx->legacy no longer reallocates: the targets stay valid)
             for (LegacyW& l : ctx->legacy) {
                 b.extra_imgs.push_back({legacy_w1_image(b.host_of(l.w1), cl), &l.w1_img});
@@ -754,6 +758,15 @@ int run_up(l3ac_ctx* ctx, hipStream_t s, const UpW& w, const float* x, float* tm
     return launch_rows(s, r);
 }
 
+// the one-kernel form of EnhanceBlock gate + up layer (kernels/up_fused.hip): bf16x3 route, the narrow stages' widths
+static bool use_up_fused(const l3ac_ctx* ctx, const UpW& w) {
+    static const bool off = [] {  // L3AC_UP_FUSED=0: gated GEMM + row kernel instead (A/B runs)
+        const char* ev = std::getenv("L3AC_UP_FUSED");
+        return ev && std::atoi(ev) == 0;
+    }();
+    return !off && ctx->gemm_split && w.fused_img != nullptr;
+}
+
 // EnhanceBlock + UpLayer of one decoder stage: the gate is applied inside the up conv's A staging (no pass of its own).
 // x is left untouched; tmp holds the conv output at the input rate.
 int run_enhance_up(l3ac_ctx* ctx, hipStream_t s, const EnhW& e, const UpW& w, float* x, float* tmp, float* y, int batch, int frames) {
@@ -769,6 +782,9 @@ int run_enhance_up(l3ac_ctx* ctx, hipStream_t s, const EnhW& e, const UpW& w, fl
     Workspace& ws = ctx->ws;
     L3AC_TRY(launch_enhance_branches(s, e.t, x, batch, frames, e.c, ws.yi));
     L3AC_TRY(launch_enhance_stats(s, ws.yi, batch, frames, ws.stats));
+    if (use_up_fused(ctx, w) && x != y)  // gate, conv, upsample and ChannelNorm in one kernel; it reads x while it writes y
+        return launch_up_fused(s, e, w, x, ws.yi, ws.stats, y, batch, frames);
+    L3AC_REQUIRE(tmp != nullptr, "enhance_up: scratch missing");
     GemmArgs g{};  // gate (tconv/__init__.py:35-44) + 1x1 conv (modules.py:161)
     g.a = x; g.lda = w.cin; g.w = w.w; g.ldw = w.cin; g.c = tmp; g.ldc = w.cout; g.m = (int64_t)batch * frames; g.n = w.cout; g.k = w.cin;
     g.bias = w.b; g.epi = EPI_BIAS;
@@ -925,7 +941,12 @@ int run_decoder(l3ac_ctx* ctx, hipStream_t s, int batch, int frames, float** cur
     int f = frames;
     for (int i = 0; i + 1 < c.n_dec; ++i) {
         L3AC_TRY(run_conv_units(ctx, s, ctx->dec_units[i], cur, alt, batch, f));
-        L3AC_TRY(run_enhance_up(ctx, s, ctx->dec_enh[i], ctx->dec_up[i], *cur, *alt, *cur, batch, f));
+        if (use_up_fused(ctx, ctx->dec_up[i])) {  // the one-kernel form cannot work in place: result in the other buffer
+            L3AC_TRY(run_enhance_up(ctx, s, ctx->dec_enh[i], ctx->dec_up[i], *cur, nullptr, *alt, batch, f));
+            swap_bufs(cur, alt);
+        } else {
+            L3AC_TRY(run_enhance_up(ctx, s, ctx->dec_enh[i], ctx->dec_up[i], *cur, *alt, *cur, batch, f));
+        }
         f *= c.decode_rates[i];
     }
     return run_last_block(ctx, s, *cur, audio, batch, f);

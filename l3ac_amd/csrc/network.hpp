@@ -35,6 +35,8 @@ struct EnhW {  // tconv/__init__.py:30-44
 struct UpW {  // modules.py:160-164
     int cin = 0, cout = 0, scale = 1;
     const float *w, *b, *nw, *nb;
+    // the 1x1 conv's weight as bf16x3 pieces for up_fused_kernel (kernels/up_fused.hip), null when the geometry is not the kernel's
+    const unsigned char* fused_img = nullptr;
 };
 struct LegacyW {  // modules.py:47-64
     int c = 0, dil = 1;
@@ -160,6 +162,10 @@ int64_t trans_stack_layer_image_bytes();
 int launch_trans_stack(hipStream_t s, const LocalTransW& w, float* x, int batch, int frames, float scale, void* coop = nullptr);
 size_t trans_stack_coop_bytes();
 int trans_stack_coop_max_batch();
+// EnhanceBlock gate + 1x1 conv + linear upsample + ChannelNorm of the narrow decoder stages in one kernel (kernels/up_fused.hip)
+bool up_fused_supported(int cin, int cout);
+std::vector<unsigned char> up_fused_image(const float* w, int cin, int cout);  // w [cout][cin]
+int launch_up_fused(hipStream_t s, const EnhW& e, const UpW& w, const float* x, const float* yi, const float* stats, float* y, int batch, int frames);
 // fused LegacyUnit / head (kernels/last_block.hip); x must not alias y
 bool last_block_fused_supported(int c, int max_dil);
 // host builders of the LegacyUnit weight images: w1 [c][7][c] (tap-major rows), w2 [c][c]

@@ -364,7 +364,13 @@ def test_enhance_and_up_layers(tiny, full):
     import torch.nn.functional as F
     for (codec, mc, w), cases in ((tiny, [("decoder.blocks.2", "decoder.blocks.3", 32, 16, 3, 41)]),
                                   (full, [("decoder.blocks.2", "decoder.blocks.3", 512, 256, 5, 180),
-                                          ("decoder.blocks.11", "decoder.blocks.12", 48, 24, 2, 700)])):
+                                          ("decoder.blocks.11", "decoder.blocks.12", 48, 24, 2, 700),
+                                          # up_fused_kernel (gate + conv + upsample + ChannelNorm in one kernel): every width it takes,
+                                          # lengths around its 14-frame tiles (1, 13, 14, 15, 29 frames) and a long clip
+                                          ("decoder.blocks.5", "decoder.blocks.6", 256, 96, 3, 900), ("decoder.blocks.8", "decoder.blocks.9", 96, 48, 3, 2700),
+                                          ("decoder.blocks.5", "decoder.blocks.6", 256, 96, 3, 29), ("decoder.blocks.8", "decoder.blocks.9", 96, 48, 3, 15),
+                                          ("decoder.blocks.11", "decoder.blocks.12", 48, 24, 2, 14), ("decoder.blocks.11", "decoder.blocks.12", 48, 24, 2, 13),
+                                          ("decoder.blocks.8", "decoder.blocks.9", 96, 48, 3, 2)])):
         for eb, ub, ci, co, s, t in cases:
             x = _rand((2, ci, t), 50 + ci)
             ref = O.enhance_block(w, eb, x)
