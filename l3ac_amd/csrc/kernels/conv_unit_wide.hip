@@ -1,4 +1,4 @@
-// ConvUnit of the WIDE stages (C = 128 / 192 / 256) with the hidden tensor kept in registers, both channel contractions on the
+// ConvUnit of the WIDE stages (C = 128 / 192 / 256; round 4: also C = 96, see WGeo::WG_PER_CU / FRONT) with the hidden tensor kept in registers, both channel contractions on the
 // bf16 matrix cores at fp32 accuracy ("bf16x3", split_bf16.hpp); reference l3ac/modules.py:10-41 + Residual
 // (l3ac/xtract/nn/layers.py:59-62):
 //
@@ -34,6 +34,7 @@
 #include "../kernels.hpp"
 #include "../network.hpp"
 #include "device_math.hpp"
+#include "ring_common.hpp"
 #include "split_bf16.hpp"
 
 #include <vector>
@@ -48,12 +49,23 @@ struct WGeo {
     static constexpr int CT = C / 32;       // output tiles of 32 channels (epilogue)
     static constexpr int RT = C / 16;       // output row tiles of 16 channels (second product)
     static constexpr int KQ = C / 8;        // channel quads per lane half
-    static constexpr int KS = C >= 256 ? 8 : 4;  // pieces (weight fragments of 3 planes x 1 KB = 12 MFMAs) per ring slot: the step barrier, the
-                                                 // DMA statement and the counted wait come once per slot, so fewer, larger slots where the ring
-                                                 // still holds four of them (a multiple of 4: every wave copies whole 1-KB blocks)
+    static constexpr int KS = C >= 256 ? 8 : C % 64 == 0 ? 4 : 3;  // pieces (weight fragments of 3 planes x 1 KB = 12 MFMAs) per ring slot: the
+                                                 // step barrier, the DMA statement and the counted wait come once per slot, so fewer, larger slots
+                                                 // where the ring still holds four of them.  Every copying wave moves whole 1-KB blocks, 3 or 6 of
+                                                 // them: all four waves when KS is a multiple of 4; C = 96 (six pieces per product) has slots of
+                                                 // three pieces = 9 KB, copied by the first three waves
     static constexpr int SLOT = KS * 3 * 1024;
     static constexpr int NA = NS1 / KS;     // slots of one W1 tile == slots of one W2 tile
-    static constexpr int DMA_N = SLOT / 4096;  // 1-KB LDS-DMA instructions per wave and slot
+    static constexpr int DMA_N = KS == 8 ? 6 : 3;  // 1-KB LDS-DMA instructions per copying wave and slot
+    static constexpr int COPY_WAVES = SLOT / (DMA_N * 1024);
+    // workgroups per CU.  C = 96 has 3.4 vector instructions per MFMA where two hide behind one: with ONE wave per SIMD the hidden-tile loop
+    // ran at 32 cycles per MFMA (stamps: 4.6 k cycles per hidden tile against 2.3 k of products).  A SIMD issues vector instructions of TWO
+    // waves at 1.8 x the rate of one (tools/probes issue_probe2), and the second workgroup's products run under the first one's activation
+    static constexpr int WG_PER_CU = C <= 96 ? 2 : 1;
+    // the front end (depth-wise conv + LayerNorm + split) inside the main kernel's pass prologue instead of dwconv_ln_split_kernel: with two
+    // workgroups per CU the other workgroup's loop covers its loads, and at C = 96 the separate kernel's 10 C bytes per frame through HBM
+    // cost half of what the main kernel does (0.68 against 1.12 ms at 256 clips)
+    static constexpr bool FRONT = WG_PER_CU == 2;
     static constexpr int HALF_POS = 49152 / SLOT;  // ring positions per opaque LDS base (fragment offsets must fit 16 bits)
     static constexpr int NSTEP = 2 * NA;    // slots per hidden-tile iteration == ring size
     static constexpr int PF = NSTEP - 1;    // slots in flight
@@ -70,13 +82,13 @@ struct WGeo {
     static constexpr int OFF_RING = OFF_B2 + C * 4;
     static constexpr int OFF_TB = OFF_RING + RING;            // epilogue transposition buffers: 2 x 4 KB per wave
     static constexpr int LDS = OFF_TB + 4 * 8192;
-    static_assert(C % 64 == 0 && NS1 % KS == 0 && KS % 4 == 0 && NSTEP <= 2 * HALF_POS, "bad geometry");
+    static_assert(C % 32 == 0 && NS1 % KS == 0 && NS1 % 2 == 0 && SLOT % (DMA_N * 1024) == 0 && COPY_WAVES <= 4 && NSTEP <= 2 * HALF_POS, "bad geometry");
     static_assert(PF >= 3 && WAIT <= 63, "ring too small / vmcnt field too narrow");
     static_assert(LDS <= 160 * 1024, "LDS budget exceeded");
 };
 
 #ifdef L3AC_WIDE_STAMPS  // diagnostic build (tools/wide_stamps.py): s_memtime at the phase boundaries of every pass of wave 0
-__device__ unsigned long long g_wide_stamps[256 * 16 * 8];
+__device__ unsigned long long g_wide_stamps[512 * 16 * 8];
 #define WIDE_STAMP(slot)                                                                                      \
     do {                                                                                                      \
         if (lane == 0 && wave == 0 && pass_no < 16)                                                           \
@@ -231,11 +243,155 @@ __device__ __forceinline__ void act_stage(ActPair& a, const float* tab, float h0
 // one of the six plane products of a fragment pair, in mfma_split's order (split_bf16.hpp), on v_mfma_f32_16x16x32_bf16: D[16 x 16]
 // += A[16 x 32] B[32 x 16]; A: lane (row = lane & 15, k group = lane >> 4) holds 8 k values; B: lane (column = lane & 15, k group);
 // D: lane (column = lane & 15), registers = rows 4 (lane >> 4) .. + 3.  (Why this shape: DESIGN.md 3.1, 'MFMA shape'.)
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
 template <int M>
 __device__ __forceinline__ f32x4_t mfma_plane(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4_t acc) {
     constexpr int IA[6] = {2, 1, 0, 1, 0, 0}, IB[6] = {0, 1, 2, 0, 1, 0};
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[IA[M]], b[IB[M]], acc, 0, 0, 0);
+}
+
+// The front end inside the main kernel (WGeo::FRONT): LayerNorm(dw_conv7(x)) of this wave's frames, computed directly in the B-operand
+// layout — lane (frame n = lane & 15, k group g = lane >> 4) owns channels 32 b + 8 g .. + 7 of its frame for every k block b, so the
+// conv is 7 taps x 2 x 16 B of the lane's own channel run per block (rows of a neighbouring clip are the conv's zero padding, as in
+// dwconv_ln_split_kernel), the LayerNorm sums are C/4 registers plus the four k groups of the frame (rows_sum, a fixed order: the same
+// bits for a clip alone and inside any batch), and the split planes are the operand registers themselves.
+// one output channel of the depth-wise conv for 16 consecutive frames held one per lane of a 16-lane row: acc += sum over taps of
+// w[tap] * x[frame + tap - 3].  A neighbouring frame is a neighbouring LANE (DPP row shift); the three frames beyond either end of the row
+// come from the registers that hold the previous / next 16 frames (lanes 13..15 of `prev`, lanes 0..2 of `next`) by the complementary shift,
+// written only into the bank of the boundary lanes.  A DPP lane whose source lies outside the row is switched off (no bound_ctrl), so each
+// lane executes exactly its seven fused multiply-adds, in tap order: the same bits as the per-tap loads of the general path below.
+// (s_nop: a vector write of a DPP source needs two wait states before the DPP read, and hipcc does not see into the statement.)
+__device__ __forceinline__ float dw_taps_dpp(float acc, float own, float prev, float next, const float (&w)[7]) {
+    asm("s_nop 1\n\t"
+        "v_fmac_f32_dpp %0, %1, %4 row_shr:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %2, %4 row_shl:13 row_mask:0xf bank_mask:0x1\n\t"
+        "v_fmac_f32_dpp %0, %1, %5 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %2, %5 row_shl:14 row_mask:0xf bank_mask:0x1\n\t"
+        "v_fmac_f32_dpp %0, %1, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %2, %6 row_shl:15 row_mask:0xf bank_mask:0x1\n\t"
+        "v_fmac_f32 %0, %1, %7\n\t"
+        "v_fmac_f32_dpp %0, %1, %8 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %3, %8 row_shr:15 row_mask:0xf bank_mask:0x8\n\t"
+        "v_fmac_f32_dpp %0, %1, %9 row_shl:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %3, %9 row_shr:14 row_mask:0xf bank_mask:0x8\n\t"
+        "v_fmac_f32_dpp %0, %1, %10 row_shl:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %3, %10 row_shr:13 row_mask:0xf bank_mask:0x8"
+        : "+v"(acc)
+        : "v"(own), "v"(prev), "v"(next), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]));
+    return acc;
+}
+
+// The front end inside the main kernel (WGeo::FRONT): LayerNorm(dw_conv7(x)) of this wave's frames, computed directly in the B-operand
+// layout — lane (frame n = lane & 15, k group g = lane >> 4) owns channels 32 b + 8 g .. + 7 of its frame for every k block b.  The
+// LayerNorm sums are C/4 registers plus the four k groups of the frame (rows_sum, a fixed order: the same bits for a clip alone and inside
+// any batch), and the split planes are the operand registers themselves.  The conv has two forms with the same bits per frame:
+//   general   7 taps x 2 x 16 B of the lane's own channel run per block, rows of a neighbouring clip being the conv's zero padding (as in
+//             dwconv_ln_split_kernel): 28 loads per block and frame half;
+//   interior  (wave-uniform test: the tile and three frames either side lie inside one clip — all but ~1 % of the tiles of a 2700-frame
+//             clip) every row is loaded ONCE and the taps are lane shifts (dw_taps_dpp): 8 row loads per block instead of 28.
+template <int C, int FH, int N>
+__device__ __forceinline__ void wide_front(const ConvUnitW& w, const float* __restrict__ x, const int64_t rows, const int frames, const int64_t row0,
+                                           const bool tile_ok, const int ln, const int lg, bf16x8 (&ap)[N][3]) {
+    constexpr int KB = C / 32;
+    static_assert(N == (FH == 2 ? 2 * KB : KB), "operand planes of FH frame halves");
+    float cv[FH][KB][8];
+    bool interior = false;
+    if (tile_ok && row0 >= 16 && row0 + 16 * FH + 16 <= rows) {  // (the halo loads read whole 16-frame groups either side)
+        const int t0 = (int)(row0 % frames);
+        interior = t0 >= 3 && t0 + 16 * FH + 3 <= frames;
+    }
+    if (__builtin_amdgcn_readfirstlane((int)interior)) {
+#pragma unroll
+        for (int b = 0; b < KB; ++b) {
+            const int c0 = 32 * b + 8 * lg;
+            const float* px = x + (row0 - 16 + ln) * C + c0;  // frame group -1: its lanes 13..15 are the left halo
+            f32x4_t grp[FH + 2][2];
+#pragma unroll
+            for (int gi = 0; gi < FH + 2; ++gi)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) grp[gi][h] = *reinterpret_cast<const f32x4_t*>(px + (int64_t)gi * 16 * C + 4 * h);
+            f32x4_t wt[7][2], bs[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                bs[h] = *reinterpret_cast<const f32x4_t*>(w.dw_b + c0 + 4 * h);
+#pragma unroll
+                for (int tap = 0; tap < 7; ++tap) wt[tap][h] = *reinterpret_cast<const f32x4_t*>(w.dw_w + tap * C + c0 + 4 * h);
+            }
+#pragma unroll
+            for (int fh = 0; fh < FH; ++fh)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float wv[7] = {wt[0][h][e], wt[1][h][e], wt[2][h][e], wt[3][h][e], wt[4][h][e], wt[5][h][e], wt[6][h][e]};
+                        cv[fh][b][4 * h + e] = dw_taps_dpp(bs[h][e], grp[fh + 1][h][e], grp[fh][h][e], grp[fh + 2][h][e], wv);
+                    }
+#ifdef L3AC_FRONT_SB
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+    } else {
+#pragma unroll
+        for (int fh = 0; fh < FH; ++fh) {
+            const int64_t r = row0 + 16 * fh + ln;
+            const bool ok = tile_ok && r < rows;
+            const int64_t rc = ok ? r : 0;
+            const int t = (int)(rc % frames);
+#pragma unroll
+            for (int b = 0; b < KB; ++b) {
+                const int c0 = 32 * b + 8 * lg;
+                f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(w.dw_b + c0), a1 = *reinterpret_cast<const f32x4_t*>(w.dw_b + c0 + 4);
+#pragma unroll
+                for (int tap = 0; tap < 7; ++tap) {
+                    const int tt = t + tap - 3;
+                    const bool in_clip = ok && tt >= 0 && tt < frames;
+                    const float* px = x + (rc + (in_clip ? tap - 3 : 0)) * C + c0;
+                    const f32x4_t x0 = *reinterpret_cast<const f32x4_t*>(px), x1 = *reinterpret_cast<const f32x4_t*>(px + 4);
+                    const f32x4_t w0 = *reinterpret_cast<const f32x4_t*>(w.dw_w + tap * C + c0), w1 = *reinterpret_cast<const f32x4_t*>(w.dw_w + tap * C + c0 + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        a0[e] = fmaf(in_clip ? x0[e] : 0.f, w0[e], a0[e]);
+                        a1[e] = fmaf(in_clip ? x1[e] : 0.f, w1[e], a1[e]);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) cv[fh][b][e] = a0[e], cv[fh][b][4 + e] = a1[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int fh = 0; fh < FH; ++fh) {
+        const bool ok = tile_ok && row0 + 16 * fh + ln < rows;
+        float s1 = 0.f;
+#pragma unroll
+        for (int b = 0; b < KB; ++b)
+            s1 += ((cv[fh][b][0] + cv[fh][b][1]) + (cv[fh][b][2] + cv[fh][b][3])) + ((cv[fh][b][4] + cv[fh][b][5]) + (cv[fh][b][6] + cv[fh][b][7]));
+        const float mean = rows_sum(s1) / (float)C;
+        float s2 = 0.f;
+#pragma unroll
+        for (int b = 0; b < KB; ++b)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                cv[fh][b][e] -= mean;
+                s2 = fmaf(cv[fh][b][e], cv[fh][b][e], s2);
+            }
+        const float rstd = 1.0f / sqrtf(rows_sum(s2) / (float)C + 1e-8f);
+#pragma unroll
+        for (int b = 0; b < KB; ++b) {
+            const int c0 = 32 * b + 8 * lg;
+            float o[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4_t lw = *reinterpret_cast<const f32x4_t*>(w.ln_w + c0 + 4 * h), lb = *reinterpret_cast<const f32x4_t*>(w.ln_b + c0 + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[4 * h + e] = ok ? cv[fh][b][4 * h + e] * rstd * lw[e] + lb[e] : 0.f;  // frames past the end: zeros
+            }
+            unsigned p[3][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) split2(o[2 * j], o[2 * j + 1], p[0][j], p[1][j], p[2][j]);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) ap[FH == 2 ? 2 * b + fh : b][pl] = __builtin_bit_cast(bf16x8, u32x4{p[pl][0], p[pl][1], p[pl][2], p[pl][3]});
+        }
+    }
 }
 
 // FH: frame halves (16 frames each) a wave owns.  2: the 32-frame tiles described above.  1 (round 4): HALF tiles, for grids that leave
@@ -257,9 +413,9 @@ __device__ __forceinline__ f32x4_t mfma_plane(const bf16x8 (&a)[3], const bf16x8
 // the first workgroups — 256 x 900 frames at C = 256 are 7 full passes + 32 tiles, and an eighth pass for 0.4 % of the tiles cost 12 %
 // of the unit; as 64 half tiles on 16 workgroups it costs half a pass.
 template <int C, int FHK = 2>
-__global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW w, const unsigned char* __restrict__ planes,
+__global__ __launch_bounds__(256, WGeo<C>::WG_PER_CU) void conv_unit_wide_kernel(const ConvUnitW w, const unsigned char* __restrict__ planes,
                                                               const float* __restrict__ x, float* __restrict__ y, const int64_t rows,
-                                                              const int64_t tail_tiles) {
+                                                              const int64_t tail_tiles, const int frames) {
     using G = WGeo<C>;
     static_assert(FHK == 1 || FHK == 2, "one or two frame halves per wave");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_wide[];
@@ -284,14 +440,15 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
     const int ring_hi = opaque(G::OFF_RING + 16 * lane + G::HALF_POS * G::SLOT);
     static_assert((G::HALF_POS - 1) * G::SLOT + (G::KS - 1) * 3072 + 2 * 1024 + 1024 < 65536, "fragment offsets must fit the ds_read immediate");
 
-    // ---- the weight stream: this wave copies bytes [3072 wave, 3072 wave + 3072) of every slot ------------------
+    // ---- the weight stream: copying wave v moves bytes [1024 DMA_N v, 1024 DMA_N (v + 1)) of every slot ------------------
     const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)ring;
-    const unsigned char* const src_wave = w.wide_img + (G::SLOT / 4) * wave;  // wave-uniform
+    const unsigned char* const src_wave = w.wide_img + (G::DMA_N * 1024) * wave;  // wave-uniform
     const unsigned lane_off = 16u * (unsigned)lane;
     int dma_slot = 0;  // next slot of the stream to fetch (wave-uniform)
     auto issue = [&](int ring_pos) __attribute__((always_inline)) {
 #ifndef L3AC_WIDE_NODMA  // (timing experiments only)
-        dma_slot_quarter<G::DMA_N, (FHK == 1) && L3AC_WIDE_HALF_NT>(src_wave + (int64_t)dma_slot * G::SLOT, lane_off, ring_lds + (unsigned)(ring_pos * G::SLOT) + (unsigned)(G::SLOT / 4) * (unsigned)wave);
+        if (G::COPY_WAVES == 4 || wave < G::COPY_WAVES)  // (a wave without copies meets the same counted waits with nothing outstanding)
+            dma_slot_quarter<G::DMA_N, (FHK == 1) && L3AC_WIDE_HALF_NT>(src_wave + (int64_t)dma_slot * G::SLOT, lane_off, ring_lds + (unsigned)(ring_pos * G::SLOT) + (unsigned)(G::DMA_N * 1024) * (unsigned)wave);
 #endif
         dma_slot = dma_slot + 1 == G::TOTAL ? 0 : dma_slot + 1;
     };
@@ -360,7 +517,9 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
         //      plane p is one 1-KB block, 16 B per lane
         // (block s = 2 b + fh of the image: k block b, frame half fh; FH = 1 keeps the blocks of its own half: ap[b])
         bf16x8 ap[G::NS1 / (3 - FH)][3];
-        {
+        if constexpr (G::FRONT) {
+            wide_front<C, FH>(w, x, rows, frames, row0, tile_ok, ln, lg, ap);
+        } else {
             const unsigned char* src = planes + (tile_ok ? tile32 : 0) * (int64_t)(G::NS1 * 3072) + 16 * lane + (FH == 1 ? fsel * 3072 : 0);
 #pragma unroll
             for (int s = 0; s < G::NS1 / (3 - FH); ++s)
@@ -456,19 +615,20 @@ __global__ __launch_bounds__(256, 1) void conv_unit_wide_kernel(const ConvUnitW 
             static_for<GPP * G::KS>([&](auto g_) {
                 constexpr int g = decltype(g_)::value, pc = g / GPP, fh = (g % GPP) / 6, m = g % 6;
                 constexpr int piece = G::KS * I + pc;
+                // (the fragment double buffer alternates with the PIECE, not with its position in the slot: slots of three pieces)
                 if constexpr (PHASE == 0)
-                    acc.q[2 * (piece & 1) + fh] = mfma_plane<m>(fb[pc & 1], ap[FH == 2 ? 2 * (piece >> 1) + fh : (piece >> 1)], acc.q[2 * (piece & 1) + fh]);
+                    acc.q[2 * (piece & 1) + fh] = mfma_plane<m>(fb[piece & 1], ap[FH == 2 ? 2 * (piece >> 1) + fh : (piece >> 1)], acc.q[2 * (piece & 1) + fh]);
                 else
-                    yacc[piece][fh] = mfma_plane<m>(fb[pc & 1], xb[fh], yacc[piece][fh]);
+                    yacc[piece][fh] = mfma_plane<m>(fb[piece & 1], xb[fh], yacc[piece][fh]);
                 // the next piece's planes in the order 0, 1, 2: its first MFMA takes plane 2 of the weights, the YOUNGEST read, so the one
                 // s_waitcnt in front of it covers all three (LDS returns in order) instead of one wait per plane
                 constexpr int FSTEP = FH == 2 ? 3 : 2;  // gaps between the three fragment reads of the next piece
                 if constexpr ((g % GPP) % FSTEP == 0 && (g % GPP) / FSTEP < 3) {
                     constexpr int pl = (g % GPP) / FSTEP;
                     if constexpr (pc + 1 < G::KS)
-                        fb[(pc + 1) & 1][pl] = frag1(POS, pc + 1, pl);
+                        fb[(piece + 1) & 1][pl] = frag1(POS, pc + 1, pl);
                     else if constexpr (NEXT >= 0)
-                        fb[0][pl] = frag1(NEXT, 0, pl);
+                        fb[(piece + 1) & 1][pl] = frag1(NEXT, 0, pl);  // (a product has an even number of pieces: the next one starts at fb[0] again)
                 }
                 if constexpr (g == 0) issue(issue_pos);
                 if constexpr (ACT >= 0) act_gap(std::integral_constant<int, GPP * G::KS * I + g>{}, std::integral_constant<int, ACT>{}, xa, tab);
@@ -733,7 +893,7 @@ int launch_wide(hipStream_t s, const ConvUnitW& w, const float* x, float* y, uns
                                            hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
         configured.done();
     }
-    {
+    if constexpr (!G::FRONT) {
         ProfScope prof(s, name_front, (double)rows * 30.0 * C, (double)rows * 10.0 * C);
         constexpr int IMG = (C / 16) * 3072;
         hipLaunchKernelGGL((dwconv_ln_split_kernel<C>), dim3((unsigned)ceil_div64(rows, 32)), dim3(256), IMG, s, w, x, planes, rows, frames);
@@ -746,20 +906,20 @@ int launch_wide(hipStream_t s, const ConvUnitW& w, const float* x, float* y, uns
         return e ? std::atoi(e) : 2;
     }();
     const int cus = l3ac_device_cu_count();
-    const bool half = half_mode >= 1 && 2 * blocks <= cus;  // half tiles while twice the workgroups still fit one pass
-    ProfScope prof(s, name, (double)rows * (16.0 * C * C), (double)rows * 14.0 * C);
+    const bool half = half_mode >= 1 && 2 * blocks <= (int64_t)cus * G::WG_PER_CU;  // half tiles while twice the workgroups still fit one pass
+    ProfScope prof(s, name, (double)rows * (16.0 * C * C + (G::FRONT ? 30.0 * C : 0.0)), (double)rows * (G::FRONT ? 8.0 : 14.0) * C);
     if (half) {
         blocks = ceil_div64(2 * tiles, 4);
-        hipLaunchKernelGGL((conv_unit_wide_kernel<C, 1>), dim3((unsigned)blocks), dim3(256), G::LDS, s, w, planes, x, y, rows, (int64_t)0);
+        hipLaunchKernelGGL((conv_unit_wide_kernel<C, 1>), dim3((unsigned)blocks), dim3(256), G::LDS, s, w, planes, x, y, rows, (int64_t)0, frames);
     } else {
         // A large grid runs its tiles in lock-step passes of 4 x 256 and the last pass may be nearly empty (256 x 900 frames at C = 256:
         // 7 200 tiles = 7 full passes + 32 tiles).  A remainder of at most half a pass is left out of the passes and run as HALF tiles
         // by the first workgroups, inside the same launch (conv_unit_wide_kernel, tail_tiles).
-        const int64_t per_pass = 4LL * 256;
+        const int64_t per_pass = 4LL * 256 * G::WG_PER_CU;
         const int64_t full = tiles / per_pass * per_pass, rest = tiles - full;
         const int64_t tail = (half_mode >= 2 && full > 0 && 2 * rest <= per_pass) ? rest : 0;
-        if (blocks > 256) blocks = 256;
-        hipLaunchKernelGGL((conv_unit_wide_kernel<C, 2>), dim3((unsigned)blocks), dim3(256), G::LDS, s, w, planes, x, y, rows, tail);
+        if (blocks > 256 * G::WG_PER_CU) blocks = 256 * G::WG_PER_CU;
+        hipLaunchKernelGGL((conv_unit_wide_kernel<C, 2>), dim3((unsigned)blocks), dim3(256), G::LDS, s, w, planes, x, y, rows, tail, frames);
     }
     L3AC_LAUNCH_CHECK();
     return L3AC_OK;
@@ -773,7 +933,7 @@ extern "C" int l3ac_debug_wide_stamps(unsigned long long* out, int n) {  // diag
 }
 #endif
 
-bool conv_unit_wide_supported(int c) { return c == 128 || c == 192 || c == 256; }
+bool conv_unit_wide_supported(int c) { return c == 96 || c == 128 || c == 192 || c == 256; }
 // scratch the pair of kernels needs: the split LayerNorm output of `rows` frames (whole 32-frame tiles), 6 bytes per element
 size_t conv_unit_wide_scratch_bytes(int c, int64_t rows) { return (size_t)ceil_div64(rows, 32) * 32 * (size_t)c * 6; }
 
@@ -786,6 +946,7 @@ int launch_conv_unit_wide(hipStream_t s, const ConvUnitW& w, const float* x, flo
                  planes_bytes, conv_unit_wide_scratch_bytes(w.c, rows), w.c, (long long)rows);
     L3AC_REQUIRE(ceil_div64(rows, 4) < ((int64_t)1 << 31), "conv_unit_wide: too many rows");
     switch (w.c) {
+        case 96: return launch_wide<96>(s, w, x, y, planes, rows, frames, "conv_unit_wide_kernel<96>", "dwconv_ln_split_kernel<96>");
         case 128: return launch_wide<128>(s, w, x, y, planes, rows, frames, "conv_unit_wide_kernel<128>", "dwconv_ln_split_kernel<128>");
         case 192: return launch_wide<192>(s, w, x, y, planes, rows, frames, "conv_unit_wide_kernel<192>", "dwconv_ln_split_kernel<192>");
         case 256: return launch_wide<256>(s, w, x, y, planes, rows, frames, "conv_unit_wide_kernel<256>", "dwconv_ln_split_kernel<256>");

@@ -403,6 +403,8 @@ int network_build(l3ac_ctx* ctx, const l3ac_tensor* tensors, int n_tensors) {
                             b.extra_imgs.push_back({conv_unit_w2_image(b.host_of(u.w2), u.c), &u.w2_img});
                             if (conv_unit_ring_supported(u.c))
                                 b.extra_imgs.push_back({conv_unit_ring_image(b.host_of(u.w1), b.host_of(u.w2), u.c), &u.ring_img});
+                            if (conv_unit_wide_supported(u.c))  // C = 96: both forms (use_wide)
+                                b.extra_imgs.push_back({conv_unit_wide_image(b.host_of(u.w1), b.host_of(u.w2), u.c), &u.wide_img});
                         } else if (conv_unit_wide_supported(u.c)) {
                             b.extra_imgs.push_back({conv_unit_wide_image(b.host_of(u.w1), b.host_of(u.w2), u.c), &u.wide_img});
                         }
@@ -617,6 +619,13 @@ static bool use_wide(const l3ac_ctx* ctx, const ConvUnitW& w) {
         const char* e = std::getenv("L3AC_WIDE_FUSED");
         return e && std::atoi(e) == 0;
     }();
+    // C = 96 has both fused forms: the register-resident one (round 4) unless L3AC_WIDE_NARROW=0 selects conv_unit_ring_kernel<96>
+    // (A/B runs; one choice per process, so a clip alone and inside a batch always take the same form)
+    static const bool narrow_off = [] {
+        const char* e = std::getenv("L3AC_WIDE_NARROW");
+        return e && std::atoi(e) == 0;
+    }();
+    if (narrow_off && conv_unit_fused_supported(w.c)) return false;
     return !off && !ctx->cfg.grn_exact && w.wide_img && ctx->gemm_split && conv_unit_wide_supported(w.c);
 }
 

@@ -262,14 +262,18 @@ def test_conv_units_narrow_ring_and_split_forms(full):
 
 
 def test_conv_units_wide_fused(full):
-    """conv_unit_wide_kernel (C = 192 / 256: hidden tensor in registers, weights streamed through the LDS ring) against the
+    """conv_unit_wide_kernel (C = 96 / 192 / 256: hidden tensor in registers, weights streamed through the LDS ring) against the
     oracle on shapes that exercise what the small cases above do not: clip boundaries inside a 32-row tile (frames % 32 != 0),
     a ragged last tile, one frame per clip, and enough rows for several passes per workgroup (the weight ring wraps around
     and is re-entered: 36 000 rows > 256 workgroups x 128 rows)."""
     codec, mc, w = full
     for block, c, b, t in (("decoder.blocks.4.1.module", 256, 3, 900), ("encoder.blocks.7.0.module", 192, 5, 180),
                            ("decoder.blocks.4.2.module", 256, 7, 1), ("encoder.blocks.7.1.module", 192, 2, 33),
-                           ("decoder.blocks.4.0.module", 256, 40, 900), ("encoder.blocks.7.1.module", 192, 200, 180)):
+                           ("decoder.blocks.4.0.module", 256, 40, 900), ("encoder.blocks.7.1.module", 192, 200, 180),
+                           # C = 96 (round 4): ring slots of three pieces copied by three of the four waves
+                           ("decoder.blocks.7.0.module", 96, 3, 2700), ("encoder.blocks.5.0.module", 96, 5, 534),
+                           ("decoder.blocks.7.1.module", 96, 7, 1), ("encoder.blocks.5.0.module", 96, 2, 33),
+                           ("decoder.blocks.7.1.module", 96, 16, 2700)):
         x = _rand((b, c, t), 200 + c + t)
         ref = O.conv_unit(w, block, x)
         got = G.op_block(codec.network.context(), "l3ac_op_conv_unit", block, G.to_frames(x), (b, t, c))
@@ -277,7 +281,8 @@ def test_conv_units_wide_fused(full):
     # the two tile forms of the kernel — 32 frames per wave, and 16 frames per wave for grids that leave most of the chip idle (a
     # single clip: the streaming chunk) — return the same bits: the first clips of a large batch against the same clips run alone
     for block, c, t, b_big in (("decoder.blocks.4.1.module", 256, 900, 40), ("encoder.blocks.7.0.module", 192, 180, 200),
-                               ("decoder.blocks.4.0.module", 256, 901, 40), ("encoder.blocks.7.1.module", 192, 37, 300)):
+                               ("decoder.blocks.4.0.module", 256, 901, 40), ("encoder.blocks.7.1.module", 192, 37, 300),
+                               ("decoder.blocks.7.0.module", 96, 2700, 14), ("encoder.blocks.5.0.module", 96, 535, 70)):
         x = _rand((b_big, c, t), 400 + c + t)
         xf = G.to_frames(x)
         big = G.op_block(codec.network.context(), "l3ac_op_conv_unit", block, xf, (b_big, t, c))

@@ -1,0 +1,13 @@
+# A/B of an environment switch on one box: tools/env_ab.sh <out.txt> <kernel-name-substring> <VAR> <value> [<value> ...]
+# BENCH_ARGS="--batch 1" etc. is passed on to bench.py
+# bench.py --pipeline-only per value, two interleaved rounds; prints the step and the kernels whose name contains the substring.
+out=$1; pat=$2; var=$3; shift 3
+mkdir -p "$(dirname "$out")"
+for round in 1 2; do
+for v in "$@"; do
+  env $var=$v timeout 200 python bench.py --pipeline-only --steps 20 --warmup 3 $BENCH_ARGS 2>/dev/null | python -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$var=$v', round(d['ms_per_step'],3), ' '.join('%s=%.4f' % (e['name'], e['ms']) for e in d['kernels'] if any(p in e['name'] for p in '$pat'.split(','))))
+"
+done; done 2>&1 | tee "$out"

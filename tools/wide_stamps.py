@@ -22,7 +22,7 @@ from l3ac_amd import _capi
 c = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 frames = int(sys.argv[3]) if len(sys.argv) > 3 else 900
-block = {256: "decoder.blocks.4.1.module", 192: "encoder.blocks.7.0.module"}[c]
+block = {256: "decoder.blocks.4.1.module", 192: "encoder.blocks.7.0.module", 96: "decoder.blocks.7.0.module"}[c]
 codec = l3ac_amd.get_model("1kbps", synthetic_seed=0)
 codec.network.to(device="cuda").eval()
 ctx = codec.network.context()
@@ -39,17 +39,18 @@ _capi.check(lib.l3ac_op_conv_unit(ctx.handle, block.encode(), x.data_ptr(), batc
 e1.record()
 torch.cuda.synchronize()
 print(f"C={c} rows={batch * frames}: {e0.elapsed_time(e1):.3f} ms")
-n = 256 * 16 * 8
+NB = 512
+n = NB * 16 * 8
 buf = np.zeros(n, dtype=np.uint64)
 fn = lib.l3ac_debug_wide_stamps
 fn.restype = C.c_int
 assert fn(buf.ctypes.data_as(C.c_void_p), n) == 0
-st = buf.reshape(256, 16, 8).astype(np.int64)
-passes = int(np.ceil(np.ceil(batch * frames / 32) / 4 / 256))
+st = buf.reshape(NB, 16, 8).astype(np.int64)
+passes = min(15, int(np.ceil(np.ceil(batch * frames / 32) / 4 / (512 if c <= 96 else 256))))
 names = ["plane loads", "entry barrier", "first product (tile 0)", "hidden-tile loop", "last tile", "residual + store"]
 tot = []
 for p in range(passes):
-    blk = [b for b in range(256) if st[b, p, 0] > 0 and st[b, p, 5] > 0]
+    blk = [b for b in range(NB) if st[b, p, 0] > 0 and st[b, p, 5] > 0]
     d = np.array([[st[b, p, i + 1] - st[b, p, i] for i in range(5)] for b in blk])
     # the pass ends where the next one starts (stamp 0), or — last pass of a block — at the exit stamp, which the kernel
     # stores under the pass counter's final value
@@ -59,6 +60,6 @@ for p in range(passes):
     print(f"pass {p} ({len(blk)} blocks): " + " | ".join(f"{n_} {m / 1e3:.1f}k" for n_, m in zip(names, med)) + f" | total {sum(med) / 1e3:.1f}k cycles")
 tot = np.array(tot)
 print("share of a pass: " + ", ".join(f"{n_} {100 * v:.1f}%" for n_, v in zip(names, tot.sum(0) / tot.sum())))
-span = np.array([st[b, :, 6].max() - st[b, 0, 0] for b in range(256) if st[b, 0, 0] > 0])
+span = np.array([st[b, :, 6].max() - st[b, 0, 0] for b in range(NB) if st[b, 0, 0] > 0])
 print(f"kernel span per block: median {np.median(span) / 1e3:.0f}k cycles, max {span.max() / 1e3:.0f}k; "
       f"ideal MFMA-only: {passes * (4 * c // 32) * (c // 16 + c // 16) * 6 * 32 / 1e3:.0f}k")
