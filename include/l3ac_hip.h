@@ -251,6 +251,8 @@ int l3ac_ctx_set_gemm_split(l3ac_ctx* ctx, int32_t enable);
  * form of trans_stack_kernel (six co-resident workgroups per clip exchanging partial tiles through global memory); 0 keeps one
  * workgroup per clip.  Both forms return the same bits.  The cooperative form's six workgroups per clip wait for each other: they need
  * six free CUs per clip to make progress, which any other work on the device only delays.
+ * "wide_narrow" (default 1): the C = 96 ConvUnits on conv_unit_wide_kernel<96> (hidden tensor in registers, two workgroups per CU);
+ * 0 keeps conv_unit_ring_kernel<96>.  The two forms agree to rounding (not bit for bit).
  * Unknown names return L3AC_EINVAL. */
 int l3ac_ctx_set_option(l3ac_ctx* ctx, const char* name, int32_t value);
 int32_t l3ac_ctx_get_gemm_split(const l3ac_ctx* ctx);

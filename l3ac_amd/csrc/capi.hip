@@ -132,6 +132,8 @@ int l3ac_create(const l3ac_config* cfg, const l3ac_tensor* tensors, int32_t n_te
         if (e) ctx->narrow_ring = std::atoi(e);
         e = std::getenv("L3AC_RING_VARIANT");
         if (e) ctx->ring_geometry = std::atoi(e);
+        e = std::getenv("L3AC_WIDE_NARROW");
+        if (e) ctx->wide_narrow = std::atoi(e) != 0;
     }
     DeviceGuard guard(device);
     int rc = guard.ok ? network_build(ctx, tensors, n_tensors) : L3AC_EHIP;
@@ -541,8 +543,9 @@ int l3ac_ctx_set_option(l3ac_ctx* ctx, const char* name, int32_t value) {
     else if (n == "narrow_ring") ctx->narrow_ring = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "ring_geometry") ctx->ring_geometry = value;
     else if (n == "trans_coop") ctx->trans_coop_enabled = value != 0;
+    else if (n == "wide_narrow") ctx->wide_narrow = value != 0;
     else {
-        l3ac_set_error("set_option: unknown option '%s' (gemm_split, head_pretanh, narrow_ring, ring_geometry, trans_coop)", name);
+        l3ac_set_error("set_option: unknown option '%s' (gemm_split, head_pretanh, narrow_ring, ring_geometry, trans_coop, wide_narrow)", name);
         return L3AC_EINVAL;
     }
     return L3AC_OK;

@@ -619,13 +619,9 @@ static bool use_wide(const l3ac_ctx* ctx, const ConvUnitW& w) {
         const char* e = std::getenv("L3AC_WIDE_FUSED");
         return e && std::atoi(e) == 0;
     }();
-    // C = 96 has both fused forms: the register-resident one (round 4) unless L3AC_WIDE_NARROW=0 selects conv_unit_ring_kernel<96>
-    // (A/B runs; one choice per process, so a clip alone and inside a batch always take the same form)
-    static const bool narrow_off = [] {
-        const char* e = std::getenv("L3AC_WIDE_NARROW");
-        return e && std::atoi(e) == 0;
-    }();
-    if (narrow_off && conv_unit_fused_supported(w.c)) return false;
+    // C = 96 has both fused forms: the register-resident one (round 4) unless the context option "wide_narrow" (env L3AC_WIDE_NARROW)
+    // is 0, which keeps conv_unit_ring_kernel<96>
+    if (!ctx->wide_narrow && conv_unit_fused_supported(w.c)) return false;
     return !off && !ctx->cfg.grn_exact && w.wide_img && ctx->gemm_split && conv_unit_wide_supported(w.c);
 }
 

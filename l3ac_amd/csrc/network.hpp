@@ -84,6 +84,10 @@ struct l3ac_ctx {
     // which fused kernel takes the narrow ConvUnits (C <= 96) on the split route: conv_unit_ring_kernel (16 frames per wave, LDS-DMA
     // weight ring) or conv_unit_split_kernel (32 frames per wave, chunk barriers); l3ac_ctx_set_option(ctx, "narrow_ring", 0 / 1)
     int narrow_ring = 1;  // 0: conv_unit_split_kernel everywhere, 1: the ring kernel where it is faster (C = 48, 96), 2: wherever it exists
+    // C = 96 has both fused forms: 1 (default) conv_unit_wide_kernel<96> (round 4), 0 conv_unit_ring_kernel<96> (rounds 2-3); option
+    // "wide_narrow" / env L3AC_WIDE_NARROW.  The forms agree to rounding, not bit for bit: switch it per context, not between the calls
+    // whose results are compared bit for bit (a clip alone / inside a batch).
+    int wide_narrow = 1;
     int ring_geometry = 0;  // diagnostics (option "ring_geometry" / env L3AC_RING_VARIANT): another geometry of conv_unit_ring_kernel, same results
     const unsigned char* img(const float* w) const {  // null on the exact route: launch_gemm then takes the fp32 kernel
         if (!gemm_split) return nullptr;

@@ -217,6 +217,16 @@ def test_conv_units_narrow_ring_and_split_forms(full):
     rounding noise."""
     codec, mc, w = full
     ctx = codec.network.context()
+    # C = 96 runs on conv_unit_wide_kernel<96> since round 4 (test_conv_units_wide_fused); "wide_narrow" = 0 keeps the two narrow forms
+    # reachable, and this test compares all three
+    ctx.set_option("wide_narrow", 0)
+    try:
+        _narrow_forms(ctx, w)
+    finally:
+        ctx.set_option("wide_narrow", 1)
+
+
+def _narrow_forms(ctx, w):
     cases = (("encoder.blocks.1.0.module", 24, 3, 1), ("encoder.blocks.1.0.module", 24, 2, 47), ("encoder.blocks.1.0.module", 24, 40, 16200),
              ("encoder.blocks.3.0.module", 48, 5, 15), ("decoder.blocks.10.0.module", 48, 3, 8100), ("decoder.blocks.10.0.module", 48, 300, 97),
              ("encoder.blocks.5.0.module", 96, 7, 17), ("decoder.blocks.7.0.module", 96, 2, 2700), ("decoder.blocks.7.1.module", 96, 130, 333))
@@ -234,6 +244,16 @@ def test_conv_units_narrow_ring_and_split_forms(full):
         d = float((outs["ring"] - outs["split"]).abs().max())
         print(f"[ring vs split {block} B={b} T={t}] max difference {d:.3e}")
         assert d < 5e-5
+        if c == 96:
+            ctx.set_option("wide_narrow", 1)
+            try:
+                wide = G.from_frames(G.op_block(ctx, "l3ac_op_conv_unit", block, G.to_frames(x), (b, t, c)))
+            finally:
+                ctx.set_option("wide_narrow", 0)
+            _close(f"wide {block} B={b} T={t}", wide[:2], ref, atol=5e-5, rtol=5e-5)
+            d = float((wide - outs["ring"]).abs().max())
+            print(f"[wide vs ring {block} B={b} T={t}] max difference {d:.3e}")
+            assert d < 5e-5
         # the kernel's other geometries (other waves x workgroups, 32 frames per wave, fragments read one piece ahead) evaluate the
         # same operations in the same order per frame: identical results
         for geometry in (1, 5, 8, 9):  # 9: the small-grid geometry (four waves per workgroup) whatever the size
@@ -249,16 +269,20 @@ def test_conv_units_narrow_ring_and_split_forms(full):
     x = _rand((2, c, 1000), 4242)
     ref64 = O.conv_unit({k: v.double() for k, v in w.items() if k.startswith(block)}, block, x.double())
     errs = {}
-    for name, ring in (("ring", 2), ("split", 0)):
+    for name, ring, wide_on in (("ring", 2, 0), ("split", 0, 0), ("wide", 1, 1)):
         ctx.set_option("narrow_ring", ring)
+        ctx.set_option("wide_narrow", wide_on)
         try:
             got = G.from_frames(G.op_block(ctx, "l3ac_op_conv_unit", block, G.to_frames(x), (2, 1000, c))).double()
         finally:
             ctx.set_option("narrow_ring", 1)
+            ctx.set_option("wide_narrow", 0)
         e = (got - ref64).abs()
         errs[name] = (float(e.max()), float(e.pow(2).mean().sqrt()))
-    print(f"[narrow forms vs fp64] ring max {errs['ring'][0]:.3e} rms {errs['ring'][1]:.3e} | split max {errs['split'][0]:.3e} rms {errs['split'][1]:.3e}")
+    print(f"[C = 96 forms vs fp64] ring max {errs['ring'][0]:.3e} rms {errs['ring'][1]:.3e} | split max {errs['split'][0]:.3e} rms {errs['split'][1]:.3e}"
+          f" | wide max {errs['wide'][0]:.3e} rms {errs['wide'][1]:.3e}")
     assert errs["ring"][1] <= 1.5 * errs["split"][1] + 1e-9
+    assert errs["wide"][1] <= 1.5 * errs["split"][1] + 1e-9
 
 
 def test_conv_units_wide_fused(full):
@@ -726,6 +750,7 @@ def test_context_options_by_name(full):
         ctx.set_option("gemm_split", 1)
     block, c, b, t = "decoder.blocks.7.0.module", 96, 3, 333
     x = _rand((b, c, t), 77)
+    ctx.set_option("wide_narrow", 0)  # (C = 96 on the narrow kernels, as before round 4)
     ref = G.from_frames(G.op_block(ctx, "l3ac_op_conv_unit", block, G.to_frames(x), (b, t, c)))
     try:
         ctx.set_option("narrow_ring", 99)     # clamped to 2: still the ring kernel at this width
@@ -734,4 +759,5 @@ def test_context_options_by_name(full):
     finally:
         ctx.set_option("narrow_ring", 1)
         ctx.set_option("ring_geometry", 0)
+        ctx.set_option("wide_narrow", 1)
     assert torch.equal(got, ref)
