@@ -295,9 +295,9 @@ __device__ __forceinline__ void wide_front(const ConvUnitW& w, const float* __re
     static_assert(N == (FH == 2 ? 2 * KB : KB), "operand planes of FH frame halves");
     float cv[FH][KB][8];
     bool interior = false;
-    if (tile_ok && row0 >= 16 && row0 + 16 * FH + 16 <= rows) {  // (the halo loads read whole 16-frame groups either side)
+    if (tile_ok) {
         const int t0 = (int)(row0 % frames);
-        interior = t0 >= 3 && t0 + 16 * FH + 3 <= frames;
+        interior = t0 >= 3 && t0 + 16 * FH + 3 <= frames;  // (inside one clip, hence inside the tensor)
     }
     if (__builtin_amdgcn_readfirstlane((int)interior)) {
 #pragma unroll
@@ -306,9 +306,13 @@ __device__ __forceinline__ void wide_front(const ConvUnitW& w, const float* __re
             const float* px = x + (row0 - 16 + ln) * C + c0;  // frame group -1: its lanes 13..15 are the left halo
             f32x4_t grp[FH + 2][2];
 #pragma unroll
-            for (int gi = 0; gi < FH + 2; ++gi)
+            for (int gi = 0; gi < FH + 2; ++gi) {
+                // (of the groups either side only the three frames next to the tile are read — lanes 13..15 / 0..2: - 1.2 % of the kernel)
+                const bool wanted = gi == 0 ? ln >= 13 : gi == FH + 1 ? ln <= 2 : true;
 #pragma unroll
-                for (int h = 0; h < 2; ++h) grp[gi][h] = *reinterpret_cast<const f32x4_t*>(px + (int64_t)gi * 16 * C + 4 * h);
+                for (int h = 0; h < 2; ++h)
+                    grp[gi][h] = wanted ? *reinterpret_cast<const f32x4_t*>(px + (int64_t)gi * 16 * C + 4 * h) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+            }
             f32x4_t wt[7][2], bs[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
