@@ -26,6 +26,7 @@
 #include "../kernels.hpp"
 #include "../network.hpp"
 #include "device_math.hpp"
+#include "lane_sums.hpp"
 
 namespace {
 
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_unit_fused_kernel(const ConvU
             }
         }
         // ---- LayerNorm over the C channels of frame lj (two lanes hold one frame) -----------------------
-        s1 += __shfl_xor(s1, 32, 64);
+        s1 = halves_sum(s1);
         const float mean = s1 / (float)C;
         float s2 = 0.f;
 #pragma unroll
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_unit_fused_kernel(const ConvU
             const float d = a[i] - mean;
             s2 = fmaf(d, d, s2);
         }
-        s2 += __shfl_xor(s2, 32, 64);
+        s2 = halves_sum(s2);
         const float rstd = 1.0f / sqrtf(s2 / (float)C + 1e-8f);
         const bool frame_ok = tile_ok && t0 + lj < frames;
 #pragma unroll

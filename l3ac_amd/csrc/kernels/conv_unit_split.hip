@@ -21,6 +21,7 @@
 #include "../kernels.hpp"
 #include "../network.hpp"
 #include "device_math.hpp"
+#include "lane_sums.hpp"
 #include "split_bf16.hpp"
 
 #include <vector>
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv_unit_split_kernel(const Co
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        s1 += __shfl_xor(s1, 32, 64);
+        s1 = halves_sum(s1);
         const float mean = s1 / (float)C;
         float s2 = 0.f;
 #pragma unroll
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv_unit_split_kernel(const Co
             const float d = a[i] - mean;
             s2 = fmaf(d, d, s2);
         }
-        s2 += __shfl_xor(s2, 32, 64);
+        s2 = halves_sum(s2);
         const float rstd = 1.0f / sqrtf(s2 / (float)C + 1e-8f);
         const bool frame_ok = tile_ok && t0 + lj < frames;
         // ---- LayerNorm affine, then split: k step s of lane half lh = a[8s .. 8s+7] = channels split_sigma(s, lh, j) ----

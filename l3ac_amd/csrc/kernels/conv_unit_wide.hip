@@ -859,14 +859,10 @@ __global__ __launch_bounds__(256) void dwconv_ln_split_kernel(const ConvUnitW w,
                 acc.w = fmaf(xv.w, dww[tap].w, acc.w);
             }
         }
-        float s1 = (acc.x + acc.y) + (acc.z + acc.w);  // idle lanes contribute exact zeros
-#pragma unroll
-        for (int m = 1; m < 64; m <<= 1) s1 += __shfl_xor(s1, m, 64);
+        const float s1 = wave_sum((acc.x + acc.y) + (acc.z + acc.w));  // idle lanes contribute exact zeros
         const float mean = s1 / (float)C;
         const float dx = acc.x - mean, dy = acc.y - mean, dz = acc.z - mean, dw_ = acc.w - mean;
-        float s2 = ok ? fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, dw_ * dw_))) : 0.f;
-#pragma unroll
-        for (int m = 1; m < 64; m <<= 1) s2 += __shfl_xor(s2, m, 64);
+        const float s2 = wave_sum(ok ? fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, dw_ * dw_))) : 0.f);
         const float rstd = 1.0f / sqrtf(s2 / (float)C + 1e-8f);
         unsigned p[3][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}};  // frames past the end: zeros
         if (ok) {

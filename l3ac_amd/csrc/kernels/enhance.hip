@@ -10,6 +10,7 @@
 // Output head (l3ac/modules.py:192-194): weight-normed Conv1d(c -> 1, k7, pad 3) -> tanh on the snake-activated
 // last feature map.
 #include "../kernels.hpp"
+#include "lane_sums.hpp"
 
 namespace {
 
@@ -89,12 +90,7 @@ __global__ __launch_bounds__(1024) void enhance_stats_kernel(const float* __rest
     const int b = blockIdx.x;
     const float4* src = reinterpret_cast<const float4*>(yi) + (int64_t)b * frames;
     auto block_sum = [&](float4 v) -> float4 {
-        for (int mask = 32; mask > 0; mask >>= 1) {
-            v.x += __shfl_xor(v.x, mask, 64);
-            v.y += __shfl_xor(v.y, mask, 64);
-            v.z += __shfl_xor(v.z, mask, 64);
-            v.w += __shfl_xor(v.w, mask, 64);
-        }
+        v = make_float4(wave_sum(v.x), wave_sum(v.y), wave_sum(v.z), wave_sum(v.w));
         __syncthreads();
         if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
         __syncthreads();

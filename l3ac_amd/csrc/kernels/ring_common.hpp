@@ -11,6 +11,7 @@
 #include <type_traits>
 #include <vector>
 
+#include "lane_sums.hpp"
 #include "split_bf16.hpp"
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -36,35 +37,6 @@ __device__ __forceinline__ void planes_of(const f32x4_t& lo, const f32x4_t& hi, 
     split2(hi[2], hi[3], p[0][3], p[1][3], p[2][3]);
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) out[pl] = __builtin_bit_cast(bf16x8, u32x4{p[pl][0], p[pl][1], p[pl][2], p[pl][3]});
-}
-
-// Reductions over the four 16-lane rows of a wave (the four k groups that share a column of an accumulator tile) without the LDS
-// crossbar: v_permlane16_swap exchanges the odd rows of one register with the even rows of another, v_permlane32_swap the upper
-// half of one with the lower half of another; applied to two copies of x they leave (x[l & ~16], x[l | 16]) resp. (x[l & ~32],
-// x[l | 32]) in every lane.  A ds_bpermute round trip (what __shfl_xor(x, 16 / 32) compiles to) is ~100+ cycles of latency on the
-// critical path of a softmax step; these are two vector instructions.  Inline asm as in gemm_split.hip (hipcc 7.2 folds repeated
-// builtin swaps); the s_nop covers the VALU-write -> permlane-read hazard.
-__device__ __forceinline__ void row_pair16(float x, float& lo, float& hi) {
-    lo = x, hi = x;
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 0" : "+v"(lo), "+v"(hi));
-}
-__device__ __forceinline__ void row_pair32(float x, float& lo, float& hi) {
-    lo = x, hi = x;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0" : "+v"(lo), "+v"(hi));
-}
-__device__ __forceinline__ float rows_sum(float x) {  // sum over lanes l, l ^ 16, l ^ 32, l ^ 48: the same bits in all four
-    float a, b;
-    row_pair16(x, a, b);
-    x = a + b;
-    row_pair32(x, a, b);
-    return a + b;
-}
-__device__ __forceinline__ float rows_max(float x) {
-    float a, b;
-    row_pair16(x, a, b);
-    x = fmaxf(a, b);
-    row_pair32(x, a, b);
-    return fmaxf(a, b);
 }
 
 // this wave's quarter (3 KB) of one ring slot: three 1-KB LDS-DMA pieces, lane l copying 16 B (as conv_unit_wide.hip)

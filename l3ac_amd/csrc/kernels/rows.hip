@@ -14,6 +14,7 @@
 // registers with a butterfly over the group.
 #include "../kernels.hpp"
 #include "device_math.hpp"
+#include "lane_sums.hpp"
 
 namespace {
 
@@ -24,10 +25,7 @@ constexpr int MAX_CH = 2;  // chunks per lane
 // the xor butterfly; other sizes (6 / 12 lanes for 24 / 48 / 96 channels: five or ten rows per wave instead of padding
 // every group to 8 / 16 lanes) a segmented shift-down reduction followed by a broadcast from the group's first lane.
 __device__ __forceinline__ float group_sum(float v, int lpr, int pos) {
-    if ((lpr & (lpr - 1)) == 0) {
-        for (int mask = lpr >> 1; mask > 0; mask >>= 1) v += __shfl_xor(v, mask, 64);
-        return v;
-    }
+    if ((lpr & (lpr - 1)) == 0) return lanes_sum(v, lpr);  // (DPP / permlane adds instead of ds_bpermute round trips: lane_sums.hpp)
     for (int d = 1; d < lpr; d <<= 1) {
         const float o = __shfl_down(v, d, 64);
         v += pos + d < lpr ? o : 0.f;

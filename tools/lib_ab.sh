@@ -9,6 +9,6 @@ for t in "$@"; do
   L3AC_LIB_PATH=$lib timeout 200 python bench.py --pipeline-only --steps 20 --warmup 3 $BENCH_ARGS 2>/dev/null | python -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('$t', round(d['ms_per_step'],3), ' '.join('%s=%.4f' % (e['name'], e['ms']) for e in d['kernels'] if '$pat' in e['name']))
+print('$t', round(d['ms_per_step'],3), ' '.join('%s=%.4f' % (e['name'], e['ms']) for e in d['kernels'] if any(p in e['name'] for p in '$pat'.split(','))))
 "
 done; done 2>&1 | tee "$out"
