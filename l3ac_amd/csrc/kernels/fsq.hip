@@ -17,6 +17,7 @@
 #include <atomic>
 
 #include "../kernels.hpp"
+#include "lane_sums.hpp"
 
 namespace {
 
@@ -102,6 +103,9 @@ __device__ __forceinline__ int64_t fsq_group_at(int64_t it, int64_t b, int64_t G
     return g < n_groups ? g : n_groups;
 }
 
+#ifndef L3AC_FSQ_DPP_SUM
+#define L3AC_FSQ_DPP_SUM 1  // A/B builds: 0 = the latents' lane sums by __shfl_xor butterflies
+#endif
 template <int D, int NV>
 __global__ __launch_bounds__(THREADS) void fsq_kernel(const FsqDev p, const int lpt) {
     const int feat = p.feat;
@@ -182,7 +186,11 @@ __global__ __launch_bounds__(THREADS) void fsq_kernel(const FsqDev p, const int 
                         s = fmaf(xv[v].x, wv.x, s); s = fmaf(xv[v].y, wv.y, s);
                         s = fmaf(xv[v].z, wv.z, s); s = fmaf(xv[v].w, wv.w, s);
                     }
+#if L3AC_FSQ_DPP_SUM
+                    s = lanes_sum(s, lpt);  // (DPP adds instead of log2(lpt) ds_bpermute round trips per latent: lane_sums.hpp)
+#else
                     for (int mask = lpt >> 1; mask > 0; mask >>= 1) s += __shfl_xor(s, mask, 64);
+#endif
                     lat[d] = s + (p.b_in ? p.b_in[d] : 0.f);
                 }
             } else {
