@@ -253,6 +253,8 @@ int l3ac_ctx_set_gemm_split(l3ac_ctx* ctx, int32_t enable);
  * six free CUs per clip to make progress, which any other work on the device only delays.
  * "wide_narrow" (default 1): the C = 96 ConvUnits on conv_unit_wide_kernel<96> (hidden tensor in registers, two workgroups per CU);
  * 0 keeps conv_unit_ring_kernel<96>.  The two forms agree to rounding (not bit for bit).
+ * "down_fused" (default 0): the encoder down layers 24 -> 48 and 48 -> 96 (Conv1d(k = stride) + ChannelNorm) in one kernel on the
+ * bf16x3 route instead of an fp32-MFMA GEMM + row kernel: faster, equally accurate, a different rounding of those layers.
  * Unknown names return L3AC_EINVAL. */
 int l3ac_ctx_set_option(l3ac_ctx* ctx, const char* name, int32_t value);
 int32_t l3ac_ctx_get_gemm_split(const l3ac_ctx* ctx);

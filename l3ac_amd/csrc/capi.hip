@@ -134,6 +134,8 @@ int l3ac_create(const l3ac_config* cfg, const l3ac_tensor* tensors, int32_t n_te
         if (e) ctx->ring_geometry = std::atoi(e);
         e = std::getenv("L3AC_WIDE_NARROW");
         if (e) ctx->wide_narrow = std::atoi(e) != 0;
+        e = std::getenv("L3AC_DOWN_FUSED");
+        if (e) ctx->down_fused = std::atoi(e) != 0;
     }
     DeviceGuard guard(device);
     int rc = guard.ok ? network_build(ctx, tensors, n_tensors) : L3AC_EHIP;
@@ -544,8 +546,9 @@ int l3ac_ctx_set_option(l3ac_ctx* ctx, const char* name, int32_t value) {
     else if (n == "ring_geometry") ctx->ring_geometry = value;
     else if (n == "trans_coop") ctx->trans_coop_enabled = value != 0;
     else if (n == "wide_narrow") ctx->wide_narrow = value != 0;
+    else if (n == "down_fused") ctx->down_fused = value != 0;
     else {
-        l3ac_set_error("set_option: unknown option '%s' (gemm_split, head_pretanh, narrow_ring, ring_geometry, trans_coop, wide_narrow)", name);
+        l3ac_set_error("set_option: unknown option '%s' (gemm_split, head_pretanh, narrow_ring, ring_geometry, trans_coop, wide_narrow, down_fused)", name);
         return L3AC_EINVAL;
     }
     return L3AC_OK;

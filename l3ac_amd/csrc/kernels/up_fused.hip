@@ -67,9 +67,13 @@ __device__ __forceinline__ float row_next(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, false));  // row_shl:1
 }
 
-template <int CIN, int COUT>
+// DOWN (round 4): the same kernel as an encoder DOWN layer (reference l3ac/modules.py:96-99): Conv1d(k = stride) — a frame-major patch of
+// `stride` frames is one contiguous row of CIN = stride x cin values — followed by ChannelNorm; no gate, no upsample, no halo (a wave stores
+// all 16 frames of its tile).  It replaces a small-N fp32-MFMA GEMM, the tensor it wrote and row_kernel<PLAIN,CN>.
+template <int CIN, int COUT, bool DOWN>
 __global__ __launch_bounds__(64 * UF_WAVES, UF_WAVES / 4) void up_fused_kernel(const UpFusedArgs p, const int tiles_per_clip, const int n_tiles) {
     using G = UfGeo<CIN, COUT>;
+    constexpr int CORE = DOWN ? 16 : UF_CORE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_uf[];
     float* const par = reinterpret_cast<float*>(smem_uf + G::OFF_PAR);
     float* const gws = reinterpret_cast<float*>(smem_uf + G::OFF_GW);
@@ -82,10 +86,12 @@ __global__ __launch_bounds__(64 * UF_WAVES, UF_WAVES / 4) void up_fused_kernel(c
         par[G::CP + i] = i < COUT ? p.nw[i] : 0.f;
         par[2 * G::CP + i] = i < COUT ? p.nb[i] : 0.f;
     }
-    for (int i = tid; i < G::CINP; i += 64 * UF_WAVES) {
-        const float4 w4 = i < CIN ? *reinterpret_cast<const float4*>(p.gate_w + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(gws + 4 * i) = w4;
-        gbs[i] = i < CIN ? p.gate_b[i] : 0.f;
+    if constexpr (!DOWN) {
+        for (int i = tid; i < G::CINP; i += 64 * UF_WAVES) {
+            const float4 w4 = i < CIN ? *reinterpret_cast<const float4*>(p.gate_w + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(gws + 4 * i) = w4;
+            gbs[i] = i < CIN ? p.gate_b[i] : 0.f;
+        }
     }
     __syncthreads();
 
@@ -94,20 +100,23 @@ __global__ __launch_bounds__(64 * UF_WAVES, UF_WAVES / 4) void up_fused_kernel(c
     const int fl = lane & 15, lg = lane >> 4;
     const int T = p.frames, S = p.scale;
     const float rscale = (float)(1.0 / (double)S);
-    const float4 iw = *reinterpret_cast<const float4*>(p.in_w);
-    const float4 ib = *reinterpret_cast<const float4*>(p.in_b);
+    float4 iw = make_float4(0.f, 0.f, 0.f, 0.f), ib = iw;
+    if constexpr (!DOWN) {
+        iw = *reinterpret_cast<const float4*>(p.in_w);
+        ib = *reinterpret_cast<const float4*>(p.in_b);
+    }
     const unsigned char* const wl = smem_uf + 16 * lane;
 
     for (int tile = blockIdx.x * UF_WAVES + wave; tile < n_tiles; tile += gridDim.x * UF_WAVES) {
         const int b = tile / tiles_per_clip;
         const int k = tile - b * tiles_per_clip;
-        const int f = UF_CORE * k - 1 + fl;          // this lane's input frame
+        const int f = CORE * k - (DOWN ? 0 : 1) + fl;  // this lane's input frame
         const bool valid = f >= 0 && f < T;
         const int fv = valid ? f : 0;
         const float* const row = p.x + ((int64_t)b * T + fv) * CIN;
         // ---- gate input: z = InstanceNorm(branch signals) of this frame (rows.hip, SRC_GATE) ----------------------------------------
-        float z0, z1, z2, z3;
-        {
+        float z0 = 0.f, z1 = 0.f, z2 = 0.f, z3 = 0.f;
+        if constexpr (!DOWN) {
             const float4 yraw = *reinterpret_cast<const float4*>(p.yi + ((int64_t)b * T + fv) * 4);
             const float4 mean = *reinterpret_cast<const float4*>(p.stats + (int64_t)b * 8);
             const float4 istd = *reinterpret_cast<const float4*>(p.stats + (int64_t)b * 8 + 4);
@@ -121,6 +130,7 @@ __global__ __launch_bounds__(64 * UF_WAVES, UF_WAVES / 4) void up_fused_kernel(c
 #pragma unroll
         for (int rt = 0; rt < G::RT; ++rt) acc[rt] = *reinterpret_cast<const f32x4_t*>(par + 16 * rt + 4 * lg);
         auto gated = [&](const f32x4_t xv, const int c0) __attribute__((always_inline)) -> f32x4_t {  // x + (gate_b + gate_w . z) * x
+            if constexpr (DOWN) return xv;
             f32x4_t o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -148,7 +158,7 @@ __global__ __launch_bounds__(64 * UF_WAVES, UF_WAVES / 4) void up_fused_kernel(c
                 acc[rt] = mfma6(wf, bp, acc[rt]);
             }
         }
-        const bool core = fl >= 1 && fl <= UF_CORE && f < T;  // (f >= 0 for fl >= 1)
+        const bool core = DOWN ? f < T : fl >= 1 && fl <= UF_CORE && f < T;  // (f >= 0 for fl >= 1)
         float* const yclip = p.y + (int64_t)b * T * S * COUT;
         // ---- s output frames per input frame: lerp (ATen upsample_linear1d, rows.hip SRC_LERP), ChannelNorm, store -----------------
 #pragma unroll 1
@@ -172,10 +182,13 @@ __global__ __launch_bounds__(64 * UF_WAVES, UF_WAVES / 4) void up_fused_kernel(c
                     // the two shifted copies of the accumulators cost the 256 -> 96 kernel 46 spilled registers)
                     // the shifts themselves run in EVERY lane, outside any lane-dependent control flow: a DPP read from a lane the EXEC mask has
                     // switched off returns 0, not that lane's register (the first build selected by branching and lost frame 0 at clip starts)
-                    const float pv = row_prev(acc[rt][i]), nx = row_next(acc[rt][i]);
-                    const float x0 = p0 ? pv : acc[rt][i];
-                    const float x1 = n1 ? nx : acc[rt][i];
-                    const float u = __fadd_rn(__fmul_rn(l0, x0), __fmul_rn(l1, x1));
+                    float u = acc[rt][i];
+                    if constexpr (!DOWN) {
+                        const float pv = row_prev(acc[rt][i]), nx = row_next(acc[rt][i]);
+                        const float x0 = p0 ? pv : acc[rt][i];
+                        const float x1 = n1 ? nx : acc[rt][i];
+                        u = __fadd_rn(__fmul_rn(l0, x0), __fmul_rn(l1, x1));
+                    }
                     v[rt][i] = (16 * rt + 4 * lg + i < COUT) ? u : 0.f;
                 }
                 s1 += (v[rt][0] + v[rt][1]) + (v[rt][2] + v[rt][3]);
@@ -209,15 +222,16 @@ __global__ __launch_bounds__(64 * UF_WAVES, UF_WAVES / 4) void up_fused_kernel(c
     }
 }
 
-template <int CIN, int COUT>
+template <int CIN, int COUT, bool DOWN = false>
 int launch_uf(hipStream_t s, const UpFusedArgs& a) {
     using G = UfGeo<CIN, COUT>;
     static PerDeviceOnce configured;
     if (configured.first()) {
-        L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(up_fused_kernel<CIN, COUT>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+        L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(up_fused_kernel<CIN, COUT, DOWN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
         configured.done();
     }
-    const int tiles_per_clip = (a.frames + UF_CORE - 1) / UF_CORE;
+    constexpr int CORE = DOWN ? 16 : UF_CORE;
+    const int tiles_per_clip = (a.frames + CORE - 1) / CORE;
     const int64_t tiles = (int64_t)a.batch * tiles_per_clip;
     L3AC_REQUIRE(tiles < ((int64_t)1 << 31) - 65536 && (int64_t)a.frames * a.scale < ((int64_t)1 << 30), "up_fused: too many tiles");
     int64_t blocks = ceil_div64(tiles, UF_WAVES);
@@ -225,9 +239,9 @@ int launch_uf(hipStream_t s, const UpFusedArgs& a) {
     if (blocks > cus) blocks = cus;
     const double rows = (double)a.batch * a.frames;
     char name[64];
-    std::snprintf(name, sizeof(name), "up_fused_kernel<%d,%d>", CIN, COUT);
-    ProfScope prof(s, name, rows * 2.0 * CIN * COUT, rows * 4.0 * (CIN + 4 + (double)a.scale * COUT));
-    hipLaunchKernelGGL((up_fused_kernel<CIN, COUT>), dim3((unsigned)blocks), dim3(64 * UF_WAVES), G::LDS, s, a, tiles_per_clip, (int)tiles);
+    std::snprintf(name, sizeof(name), DOWN ? "down_fused_kernel<%d,%d>" : "up_fused_kernel<%d,%d>", CIN, COUT);
+    ProfScope prof(s, name, rows * 2.0 * CIN * COUT, rows * 4.0 * (CIN + (DOWN ? 0 : 4) + (double)a.scale * COUT));
+    hipLaunchKernelGGL((up_fused_kernel<CIN, COUT, DOWN>), dim3((unsigned)blocks), dim3(64 * UF_WAVES), G::LDS, s, a, tiles_per_clip, (int)tiles);
     L3AC_LAUNCH_CHECK();
     return L3AC_OK;
 }
@@ -256,5 +270,23 @@ int launch_up_fused(hipStream_t s, const EnhW& e, const UpW& w, const float* x, 
     if (w.cin == 96 && w.cout == 48) return launch_uf<96, 48>(s, a);
     if (w.cin == 48 && w.cout == 24) return launch_uf<48, 24>(s, a);
     l3ac_set_error("up_fused: %d -> %d not supported", w.cin, w.cout);
+    return L3AC_EINVAL;
+}
+
+// ---- encoder down layers: Conv1d(k = stride) + ChannelNorm (up_fused_kernel<K, Cout, DOWN>) ---------------------------------------------
+bool down_fused_supported(int cin, int stride, int cout) {
+    const int k = cin * stride;
+    return (k == 144 && cout == 48) || (k == 240 && cout == 96) || (k == 192 && cout == 96);
+}
+// x [batch][frames_out * stride][cin] -> y [batch][frames_out][cout]; w.fused_img = up_fused_image(w.w, stride * cin, cout)
+int launch_down_fused(hipStream_t s, const DownW& w, const float* x, float* y, int batch, int frames_out) {
+    L3AC_REQUIRE(w.fused_img && w.nw && w.nb && x && y && x != y && batch > 0 && frames_out > 0, "down_fused: bad arguments");
+    UpFusedArgs a{};
+    a.x = x; a.y = y; a.batch = batch; a.frames = frames_out; a.scale = 1; a.img = w.fused_img; a.bias = w.b; a.nw = w.nw; a.nb = w.nb; a.eps = 1e-8f;
+    const int k = w.cin * w.stride;
+    if (k == 144 && w.cout == 48) return launch_uf<144, 48, true>(s, a);
+    if (k == 240 && w.cout == 96) return launch_uf<240, 96, true>(s, a);
+    if (k == 192 && w.cout == 96) return launch_uf<192, 96, true>(s, a);
+    l3ac_set_error("down_fused: %d x %d -> %d not supported", w.cin, w.stride, w.cout);
     return L3AC_EINVAL;
 }

@@ -22,6 +22,8 @@ struct ConvUnitW {  // modules.py:10-41
 struct DownW {  // modules.py:96-99 and local_trans.py:136: Conv1d(k = stride) [+ ChannelNorm]
     int cin = 0, cout = 0, stride = 1;
     const float *w, *b, *nw = nullptr, *nb = nullptr;
+    // the conv's weight [cout][stride * cin] as bf16x3 pieces for the DOWN form of up_fused_kernel, null when the geometry is not the kernel's
+    const unsigned char* fused_img = nullptr;
 };
 struct ConvK3W {  // modules.py:110, :150
     int cin = 0, cout = 0;
@@ -88,6 +90,11 @@ struct l3ac_ctx {
     // "wide_narrow" / env L3AC_WIDE_NARROW.  The forms agree to rounding, not bit for bit: switch it per context, not between the calls
     // whose results are compared bit for bit (a clip alone / inside a batch).
     int wide_narrow = 1;
+    // encoder down layers 24 -> 48 and 48 -> 96 (Conv1d(k = stride) + ChannelNorm) in one kernel on the bf16x3 route (the DOWN form of
+    // up_fused_kernel) instead of a small-N fp32-MFMA GEMM + row kernel: option "down_fused" / env L3AC_DOWN_FUSED.  Default 0: it is
+    // 0.12 ms faster at 256 clips and as accurate, but a different rounding of the encoder's first layers, and of the tokens compared
+    // with the oracle so far one (stress weights, 1.9e-6 of a rounding boundary) changes sides with it — DESIGN.md section 4.
+    int down_fused = 0;
     int ring_geometry = 0;  // diagnostics (option "ring_geometry" / env L3AC_RING_VARIANT): another geometry of conv_unit_ring_kernel, same results
     const unsigned char* img(const float* w) const {  // null on the exact route: launch_gemm then takes the fp32 kernel
         if (!gemm_split) return nullptr;
@@ -170,6 +177,9 @@ int trans_stack_coop_max_batch();
 bool up_fused_supported(int cin, int cout);
 std::vector<unsigned char> up_fused_image(const float* w, int cin, int cout);  // w [cout][cin]
 int launch_up_fused(hipStream_t s, const EnhW& e, const UpW& w, const float* x, const float* yi, const float* stats, float* y, int batch, int frames);
+// encoder down layer (Conv1d(k = stride) + ChannelNorm) in the same kernel's DOWN form
+bool down_fused_supported(int cin, int stride, int cout);
+int launch_down_fused(hipStream_t s, const DownW& w, const float* x, float* y, int batch, int frames_out);
 // fused LegacyUnit / head (kernels/last_block.hip); x must not alias y
 bool last_block_fused_supported(int c, int max_dil);
 // host builders of the LegacyUnit weight images: w1 [c][7][c] (tap-major rows), w2 [c][c]

@@ -373,13 +373,25 @@ def test_conv_units_wide_scratch_on_a_fresh_context():
 def test_down_and_k3_layers(tiny, full):
     import torch.nn.functional as F
     for (codec, mc, w), cases in ((tiny, [("encoder.blocks.2", 8, 16, 2, 66), ("encoder.blocks.4", 16, 24, 3, 66)]),
-                                  (full, [("encoder.blocks.2", 24, 48, 6, 600), ("encoder.blocks.6", 96, 192, 3, 90)])):
+                                  (full, [("encoder.blocks.2", 24, 48, 6, 600), ("encoder.blocks.6", 96, 192, 3, 90),
+                                          # the DOWN form of up_fused_kernel (conv + ChannelNorm in one kernel): both widths it takes at
+                                          # 1kbps, output lengths around its 16-frame tiles (1, 15, 16, 17, 33) and whole clips
+                                          ("encoder.blocks.4", 48, 96, 5, 5 * 33), ("encoder.blocks.4", 48, 96, 5, 2700),
+                                          ("encoder.blocks.2", 24, 48, 6, 6), ("encoder.blocks.2", 24, 48, 6, 6 * 15),
+                                          ("encoder.blocks.2", 24, 48, 6, 6 * 16), ("encoder.blocks.2", 24, 48, 6, 6 * 17),
+                                          ("encoder.blocks.2", 24, 48, 6, 16200)])):
         for block, ci, co, s, t in cases:
-            x = _rand((2, ci, t), 30 + ci)
+            x = _rand((2, ci, t), 30 + ci + t)
             ref = F.conv1d(x, w[f"{block}.0.weight"], w[f"{block}.0.bias"], stride=s)
             ref = O.channel_norm_first(ref, w[f"{block}.1.weight"], w[f"{block}.1.bias"])
-            got = G.op_block(codec.network.context(), "l3ac_op_down_layer", block, G.to_frames(x), (2, t // s, co))
-            _close(block, G.from_frames(got), ref)
+            ctx = codec.network.context()
+            for fused in (0, 1):  # option "down_fused": the GEMM + row kernel (default) and the one-kernel form where it exists
+                ctx.set_option("down_fused", fused)
+                try:
+                    got = G.op_block(ctx, "l3ac_op_down_layer", block, G.to_frames(x), (2, t // s, co))
+                finally:
+                    ctx.set_option("down_fused", 0)
+                _close(f"{block} T={t} down_fused={fused}", G.from_frames(got), ref)
     for (codec, mc, w), cases in ((tiny, [("encoder.blocks.6", 24, 16, 50), ("decoder.blocks.0", 16, 32, 50)]),
                                   (full, [("encoder.blocks.8", 192, 128, 180), ("decoder.blocks.0", 128, 512, 180)])):
         for block, ci, co, t in cases:

@@ -261,6 +261,37 @@ def test_index_agreement_full_batch(tag):
         codec.network.set_gemm_split(before)
 
 
+# option "down_fused" (default off): observed mismatches with the narrow encoder down layers in their one-kernel bf16x3 form
+OBSERVED_DOWN_FUSED_MISMATCHES = {"1kbps": 0, "stress_3kbps": 1}
+
+
+@pytest.mark.parametrize("tag", ["1kbps", "stress_3kbps"])
+def test_index_agreement_with_fused_down_layers(tag):
+    """The one-kernel form of the encoder down layers 24 -> 48 and 48 -> 96 (context option "down_fused", default off) is a different —
+    equally accurate — rounding of the encoder's first layers.  The index contract holds with it (single-level flips within TAU of a
+    rounding boundary only); what it costs is printed: on the stress weights the one decision that lies 1.9e-6 level units from its
+    boundary falls on the other side (the reason the option is off by default: every token compared so far is identical without it)."""
+    from tests.helpers import structured_audio
+    codec = _codec(tag, 0)
+    mc = codec.network.mc
+    w = W.folded_weights(codec.network.state_dicts())
+    audio = (torch.cat([seeded_audio(32, 16000, seed=11), structured_audio(2, 16000, seed=12)[0]]) if tag.startswith("stress")
+             else seeded_audio(64, 16000))
+    idx_ref, lat_ref = _oracle_indices(w, mc, audio)
+    ctx = codec.network.context()
+    _, plain = codec.encode_audio(audio.cuda())
+    ctx.set_option("down_fused", 1)
+    try:
+        _, ind = codec.encode_audio(audio.cuda())
+    finally:
+        ctx.set_option("down_fused", 0)
+    rep = index_agreement(ind["indices"].cpu().numpy(), idx_ref.numpy(), lat_ref.numpy(), mc.levels)
+    differ = int((ind["indices"] != plain["indices"]).sum())
+    print(f"[index agreement {tag} down_fused] {rep}; tokens that differ from the default form's: {differ}")
+    assert rep["single_step"] and rep["max_margin_of_mismatches"] < TAU
+    assert rep["mismatches"] <= OBSERVED_DOWN_FUSED_MISMATCHES[tag] + 1
+
+
 # observed on the MI355X with the stress profile (round 4; printed by the test): index mismatches per (config, route) and the
 # largest waveform error given identical indices
 OBSERVED_STRESS_MISMATCHES = {}
