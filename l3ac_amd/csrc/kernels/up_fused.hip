@@ -70,8 +70,11 @@ __device__ __forceinline__ float row_next(float v) {
 // DOWN (round 4): the same kernel as an encoder DOWN layer (reference l3ac/modules.py:96-99): Conv1d(k = stride) — a frame-major patch of
 // `stride` frames is one contiguous row of CIN = stride x cin values — followed by ChannelNorm; no gate, no upsample, no halo (a wave stores
 // all 16 frames of its tile).  It replaces a small-N fp32-MFMA GEMM, the tensor it wrote and row_kernel<PLAIN,CN>.
-template <int CIN, int COUT, bool DOWN>
-__global__ __launch_bounds__(64 * UF_WAVES, UF_WAVES / 4) void up_fused_kernel(const UpFusedArgs p, const int tiles_per_clip, const int n_tiles) {
+// WAVES: waves per workgroup — 16 (one workgroup per CU fills it), or 4 for grids of a few tiles (a single clip: 900 frames at 256 -> 96
+// are 65 tiles = five 16-wave workgroups on five CUs, each filling 144 KB of LDS first: 31 us; as 17 workgroups of four waves ~ a third).
+// A tile's arithmetic does not depend on it: the same bits.
+template <int CIN, int COUT, bool DOWN, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void up_fused_kernel(const UpFusedArgs p, const int tiles_per_clip, const int n_tiles) {
     using G = UfGeo<CIN, COUT>;
     constexpr int CORE = DOWN ? 16 : UF_CORE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_uf[];
@@ -79,15 +82,15 @@ __global__ __launch_bounds__(64 * UF_WAVES, UF_WAVES / 4) void up_fused_kernel(c
     float* const gws = reinterpret_cast<float*>(smem_uf + G::OFF_GW);
     float* const gbs = gws + 4 * G::CINP;
     const int tid = threadIdx.x;
-    for (int i = tid; i < G::RT * G::K1 * 3072 / 16; i += 64 * UF_WAVES)
+    for (int i = tid; i < G::RT * G::K1 * 3072 / 16; i += 64 * WAVES)
         reinterpret_cast<u32x4*>(smem_uf)[i] = reinterpret_cast<const u32x4*>(p.img)[i];
-    for (int i = tid; i < G::CP; i += 64 * UF_WAVES) {
+    for (int i = tid; i < G::CP; i += 64 * WAVES) {
         par[i] = i < COUT ? p.bias[i] : 0.f;
         par[G::CP + i] = i < COUT ? p.nw[i] : 0.f;
         par[2 * G::CP + i] = i < COUT ? p.nb[i] : 0.f;
     }
     if constexpr (!DOWN) {
-        for (int i = tid; i < G::CINP; i += 64 * UF_WAVES) {
+        for (int i = tid; i < G::CINP; i += 64 * WAVES) {
             const float4 w4 = i < CIN ? *reinterpret_cast<const float4*>(p.gate_w + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
             *reinterpret_cast<float4*>(gws + 4 * i) = w4;
             gbs[i] = i < CIN ? p.gate_b[i] : 0.f;
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(64 * UF_WAVES, UF_WAVES / 4) void up_fused_kernel(c
     }
     const unsigned char* const wl = smem_uf + 16 * lane;
 
-    for (int tile = blockIdx.x * UF_WAVES + wave; tile < n_tiles; tile += gridDim.x * UF_WAVES) {
+    for (int tile = blockIdx.x * WAVES + wave; tile < n_tiles; tile += gridDim.x * WAVES) {
         const int b = tile / tiles_per_clip;
         const int k = tile - b * tiles_per_clip;
         const int f = CORE * k - (DOWN ? 0 : 1) + fl;  // this lane's input frame
@@ -222,28 +225,39 @@ __global__ __launch_bounds__(64 * UF_WAVES, UF_WAVES / 4) void up_fused_kernel(c
     }
 }
 
-template <int CIN, int COUT, bool DOWN = false>
-int launch_uf(hipStream_t s, const UpFusedArgs& a) {
+template <int CIN, int COUT, bool DOWN, int WAVES>
+int launch_uf_waves(hipStream_t s, const UpFusedArgs& a, int tiles_per_clip, int64_t tiles) {
     using G = UfGeo<CIN, COUT>;
     static PerDeviceOnce configured;
     if (configured.first()) {
-        L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(up_fused_kernel<CIN, COUT, DOWN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+        L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(up_fused_kernel<CIN, COUT, DOWN, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
         configured.done();
     }
+    int64_t blocks = ceil_div64(tiles, WAVES);
+    const int64_t cus = l3ac_device_cu_count();
+    if (blocks > cus) blocks = cus;
+    hipLaunchKernelGGL((up_fused_kernel<CIN, COUT, DOWN, WAVES>), dim3((unsigned)blocks), dim3(64 * WAVES), G::LDS, s, a, tiles_per_clip, (int)tiles);
+    L3AC_LAUNCH_CHECK();
+    return L3AC_OK;
+}
+
+template <int CIN, int COUT, bool DOWN = false>
+int launch_uf(hipStream_t s, const UpFusedArgs& a) {
     constexpr int CORE = DOWN ? 16 : UF_CORE;
     const int tiles_per_clip = (a.frames + CORE - 1) / CORE;
     const int64_t tiles = (int64_t)a.batch * tiles_per_clip;
     L3AC_REQUIRE(tiles < ((int64_t)1 << 31) - 65536 && (int64_t)a.frames * a.scale < ((int64_t)1 << 30), "up_fused: too many tiles");
-    int64_t blocks = ceil_div64(tiles, UF_WAVES);
-    const int64_t cus = l3ac_device_cu_count();
-    if (blocks > cus) blocks = cus;
     const double rows = (double)a.batch * a.frames;
     char name[64];
     std::snprintf(name, sizeof(name), DOWN ? "down_fused_kernel<%d,%d>" : "up_fused_kernel<%d,%d>", CIN, COUT);
     ProfScope prof(s, name, rows * 2.0 * CIN * COUT, rows * 4.0 * (CIN + (DOWN ? 0 : 4) + (double)a.scale * COUT));
-    hipLaunchKernelGGL((up_fused_kernel<CIN, COUT, DOWN>), dim3((unsigned)blocks), dim3(64 * UF_WAVES), G::LDS, s, a, tiles_per_clip, (int)tiles);
-    L3AC_LAUNCH_CHECK();
-    return L3AC_OK;
+    static const int small_mode = [] {  // L3AC_UF_SMALL=0: 16-wave workgroups whatever the grid (A/B runs; same bits)
+        const char* e = std::getenv("L3AC_UF_SMALL");
+        return e ? std::atoi(e) : 1;
+    }();
+    // fewer 16-wave workgroups than half the CUs: four-wave workgroups spread the tiles over four times as many CUs
+    if (small_mode && 2 * ceil_div64(tiles, UF_WAVES) <= l3ac_device_cu_count()) return launch_uf_waves<CIN, COUT, DOWN, 4>(s, a, tiles_per_clip, tiles);
+    return launch_uf_waves<CIN, COUT, DOWN, UF_WAVES>(s, a, tiles_per_clip, tiles);
 }
 
 }  // namespace
