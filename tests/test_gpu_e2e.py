@@ -270,7 +270,7 @@ def test_index_agreement_with_fused_down_layers(tag):
     """The one-kernel form of the encoder down layers 24 -> 48 and 48 -> 96 (context option "down_fused", default off) is a different —
     equally accurate — rounding of the encoder's first layers.  The index contract holds with it (single-level flips within TAU of a
     rounding boundary only); what it costs is printed: on the stress weights the one decision that lies 1.9e-6 level units from its
-    boundary falls on the other side (the reason the option is off by default: every token compared so far is identical without it)."""
+    boundary falls on the other side (the reason the option is off by default: without it the only difference on record is an exact tie, 9.4e-9 from its boundary)."""
     from tests.helpers import structured_audio
     codec = _codec(tag, 0)
     mc = codec.network.mc
