@@ -103,6 +103,9 @@ __device__ __forceinline__ int64_t fsq_group_at(int64_t it, int64_t b, int64_t G
     return g < n_groups ? g : n_groups;
 }
 
+#ifndef L3AC_FSQ_DPP_BCAST
+#define L3AC_FSQ_DPP_BCAST 1  // A/B builds: 0 = level indices exchanged by __shfl (ds_bpermute)
+#endif
 #ifndef L3AC_FSQ_DPP_SUM
 #define L3AC_FSQ_DPP_SUM 1  // A/B builds: 0 = the latents' lane sums by __shfl_xor butterflies
 #endif
@@ -208,7 +211,28 @@ __global__ __launch_bounds__(THREADS) void fsq_kernel(const FsqDev p, const int 
                 li_mine = quantise(mine, sub < D ? sub : 0);
                 const int group_base = lane - sub;
 #pragma unroll
-                for (int d = 0; d < D; ++d) li[d] = __shfl(li_mine, group_base + d, 64);
+                for (int d = 0; d < D; ++d) {
+#if L3AC_FSQ_DPP_BCAST
+                    if (lpt == 8) {  // lane d of the token's eight: row_newbcast of lane d / 8 + d of the 16-lane row, chosen by the lane's half
+#define L3AC_BC(n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, li_mine), 0x150 + (n), 0xf, 0xf, false))
+                        float lo, hi;
+                        switch (d) {
+                            case 0: lo = L3AC_BC(0), hi = L3AC_BC(8); break;
+                            case 1: lo = L3AC_BC(1), hi = L3AC_BC(9); break;
+                            case 2: lo = L3AC_BC(2), hi = L3AC_BC(10); break;
+                            case 3: lo = L3AC_BC(3), hi = L3AC_BC(11); break;
+                            case 4: lo = L3AC_BC(4), hi = L3AC_BC(12); break;
+                            case 5: lo = L3AC_BC(5), hi = L3AC_BC(13); break;
+                            case 6: lo = L3AC_BC(6), hi = L3AC_BC(14); break;
+                            default: lo = L3AC_BC(7), hi = L3AC_BC(15); break;
+                        }
+#undef L3AC_BC
+                        li[d] = (lane & 8) ? hi : lo;
+                        continue;
+                    }
+#endif
+                    li[d] = __shfl(li_mine, group_base + d, 64);
+                }
             } else {
 #pragma unroll
                 for (int d = 0; d < D; ++d) li[d] = quantise(lat[d], d);
