@@ -471,10 +471,35 @@ def main():
         dist.destroy_process_group()
 
 
-def fsq_microbench(codec, dev, n_tokens=1 << 22):
+def _sysfs_clocks():
+    """Current shader / memory clock levels as sysfs prints them (the starred line of pp_dpm_sclk / pp_dpm_mclk of the first
+    amdgpu card that shows them): plain file reads, no HIP call.  None where the files are not readable."""
+    import glob
+    out = {}
+    for name in ("pp_dpm_sclk", "pp_dpm_mclk"):
+        out[name] = None
+        for f in sorted(glob.glob(f"/sys/class/drm/card*/device/{name}")):
+            try:
+                lines = open(f).read().splitlines()
+            except OSError:
+                continue
+            cur = [ln.strip() for ln in lines if ln.rstrip().endswith("*")]
+            if cur:
+                out[name] = cur[0]
+                break
+    return out
+
+
+def fsq_microbench(codec, dev, n_tokens=1 << 22, window=20, rounds=5, min_warm_s=0.5, max_warm_s=4.0):
     """HBM roofline of the closed-form FSQ kernel on its own: at batch 256 it moves 16 MB per launch (below launch
-    latency), so its fraction of the HBM peak is measured at 2^22 tokens (1 052 algorithmic bytes per token)."""
+    latency), so its fraction of the HBM peak is measured at 2^22 tokens (1 052 algorithmic bytes per token).
+
+    Protocol (the same on a box that has just been leased and on one that has run for minutes): launch windows of `window`
+    launches until two consecutive windows agree within 1 % and at least `min_warm_s` have passed (the clocks ramp from
+    idle for a few hundred ms); then `rounds` interleaved rounds of (kernel window, copy-ceiling window).  Every round is
+    printed; `achieved` is the MEDIAN round, `frac_of_copy_ceiling` the median of the per-round ratios."""
     import ctypes as C
+    import statistics
 
     from l3ac_amd import _capi, weights as W
     mc = codec.network.mc
@@ -492,35 +517,56 @@ def fsq_microbench(codec, dev, n_tokens=1 << 22):
                                                     wt["project_in.bias"].data_ptr(), wt["project_out.weight"].data_ptr(),
                                                     wt["project_out.bias"].data_ptr(), q.data_ptr(), idx.data_ptr(),
                                                     li.data_ptr(), None, s))
-    for _ in range(50):  # ~50 ms: lets the memory / fabric clocks ramp from idle before the timed launches
-        call()
+    with_copy = feat == 128 and d == 6  # the same grid and access pattern with no arithmetic: what this box's HBM gives that pattern
+    copy = lambda: _capi.check(lib.l3ac_fsq_copy_ceiling(x.data_ptr(), n_tokens, q.data_ptr(), idx.data_ptr(), li.data_ptr(), s))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 20
-    e0.record()
-    for _ in range(reps):
-        call()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
-    bytes_per_token = 4 * feat * 2 + 4 + 4 * d
-    gbs = n_tokens * bytes_per_token / ms / 1e6
-    out = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-           "tokens": n_tokens, "bytes_per_token": bytes_per_token, "ms": ms}
-    if feat == 128 and d == 6:  # the same grid and access pattern with no arithmetic: what this box's HBM gives that pattern
-        copy = lambda: _capi.check(lib.l3ac_fsq_copy_ceiling(x.data_ptr(), n_tokens, q.data_ptr(), idx.data_ptr(), li.data_ptr(), s))
-        for _ in range(10):
-            copy()
+
+    def timed(fn, lead=3):  # one window: ms per launch (the first `lead` launches after a change of kernel are not timed)
+        for _ in range(lead):
+            fn()
         e0.record()
-        for _ in range(reps):
-            copy()
+        for _ in range(window):
+            fn()
         e1.record()
         torch.cuda.synchronize()
-        cms = e0.elapsed_time(e1) / reps
-        cgbs = n_tokens * bytes_per_token / cms / 1e6
+        return e0.elapsed_time(e1) / window
+
+    clocks_before = _sysfs_clocks()
+    t0, prev, warm = time.perf_counter(), None, []
+    while True:
+        ms = timed(call)
+        warm.append(round(ms, 4))
+        waited = time.perf_counter() - t0
+        if (prev is not None and abs(ms - prev) <= 0.01 * prev and waited >= min_warm_s) or waited >= max_warm_s:
+            break
+        prev = ms
+    if with_copy:
+        timed(copy)
+    k_ms, c_ms = [], []
+    for _ in range(rounds):
+        k_ms.append(timed(call))
+        if with_copy:
+            c_ms.append(timed(copy))
+    bytes_per_token = 4 * feat * 2 + 4 + 4 * d
+    to_gbs = lambda ms: n_tokens * bytes_per_token / ms / 1e6
+    ms = statistics.median(k_ms)
+    gbs = to_gbs(ms)
+    out = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+           "tokens": n_tokens, "bytes_per_token": bytes_per_token, "ms": ms,
+           "protocol": f"windows of {window} launches until two agree within 1 % and >= {min_warm_s} s have passed, then {rounds} "
+                       "interleaved rounds of (kernel, copy ceiling), each window behind 3 untimed launches of its own kernel; achieved = median round",
+           "warmup_windows_ms": warm, "warmup_s": round(waited, 3),
+           "rounds_gbs": [round(to_gbs(v), 1) for v in k_ms],
+           "clocks_sysfs": {"before": clocks_before, "after": _sysfs_clocks()}}
+    if with_copy:
+        cms = statistics.median(c_ms)
+        cgbs = to_gbs(cms)
         out["copy_ceiling"] = {"achieved": cgbs, "unit": "GB/s", "frac_of_peak": cgbs / PEAK_HBM_GBS, "ms": cms,
+                               "rounds_gbs": [round(to_gbs(v), 1) for v in c_ms],
                                "what": "fsq_copy_ceiling_kernel: fsq_kernel's grid (3 workgroups per CU), token order and per-lane "
                                        "non-temporal loads / stores incl. the 4-B and 24-B side outputs, no arithmetic"}
-        out["frac_of_copy_ceiling"] = gbs / cgbs
+        out["frac_of_copy_ceiling"] = statistics.median([c / k for k, c in zip(k_ms, c_ms)])
+        out["frac_of_copy_ceiling_rounds"] = [round(c / k, 4) for k, c in zip(k_ms, c_ms)]
     return out
 
 

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define L3AC_ABI_VERSION 3
+#define L3AC_ABI_VERSION 4
 #define L3AC_MAX_STAGES 8
 #define L3AC_MAX_LEVELS 8
 
@@ -48,6 +48,8 @@ enum {
     L3AC_EWEIGHT = -2,   /* missing / mis-shaped weight tensor */
     L3AC_EHIP = -3,      /* HIP runtime error */
     L3AC_ENOMEM = -4,    /* workspace too small while stream capture forbids growing it */
+    L3AC_ECOOP = -5,     /* an EARLIER call's cooperative transformer launch timed out: that call's outputs are invalid
+                            (see l3ac_coop_timeout_count); reported once, by the next call on the context */
 };
 
 /* Network geometry: the [network_config] table of the reference's TOML files
@@ -98,6 +100,23 @@ int64_t l3ac_workspace_bytes(const l3ac_ctx* ctx);
  * per context and clamped into range instead of being decomposed into wrapped level indices.  This call synchronises the
  * device, writes the count since the last reset to *out and optionally resets it. */
 int l3ac_bad_index_count(l3ac_ctx* ctx, int32_t reset, int64_t* out);
+/* The cooperative form of the transformer kernel (option "trans_coop", below; reference l3ac/local_trans.py:42-48 — which cannot
+ * return silently wrong tokens) gives each clip of a small batch six workgroups that wait for each other's partial results.  If they
+ * are ever not co-resident (another PROCESS filling the device, a CU mask, a debugger) an arrival poll expires after
+ * "coop_timeout_ms" (default 250 ms; every workgroup then stops waiting, so the launch ends within about one time limit), the kernel
+ * counts it in host-visible memory and the outputs of that call are INVALID.  The host is told in two ways:
+ *   - the next encode / decode / op call on the context returns L3AC_ECOOP (once) before doing anything;
+ *   - this call synchronises the device and writes the number of expired polls since the last reset to *out.
+ * Either way the context then leaves the cooperative form (trans_coop = 0: same bits, one workgroup per clip) and its arrival
+ * counters are zeroed again, so the repeated call is correct.  Inside ONE process cooperative launches cannot starve each other:
+ * every context claims the CUs its launches need in a per-device registry and a launch that does not fit runs in the
+ * one-workgroup form.  Other processes sharing the device must set trans_coop = 0 (env L3AC_TRANS_COOP=0).
+ * A hipGraph captured from a context must not be replayed concurrently with itself or with other work of the same context
+ * (the slabs and counters are per context, like the workspace). */
+int l3ac_coop_timeout_count(l3ac_ctx* ctx, int32_t reset, int64_t* out);
+/* CUs of `device` that live contexts of this process have claimed for cooperative launches (the registry above); -1 for a bad
+ * ordinal.  No device call. */
+int32_t l3ac_coop_claimed_cus(int32_t device);
 /* Guard of the GRN fast path (layers.py:112-115; l3ac_config.grn_exact).  A context created with grn_exact = 1 evaluates
  * g / (g + 1e-8) per clip and keeps the smallest per-clip norm g = ||x||_2 any of its GRN layers has seen; this call
  * synchronises the device, writes that minimum to *out (+inf if no GRN has run) and optionally resets it.  The fast path
@@ -250,7 +269,9 @@ int l3ac_ctx_set_gemm_split(l3ac_ctx* ctx, int32_t enable);
  * "trans_coop" (default 1): batches of at most 32 clips — a streaming chunk is one — run every LocalTrans stack in the cooperative
  * form of trans_stack_kernel (six co-resident workgroups per clip exchanging partial tiles through global memory); 0 keeps one
  * workgroup per clip.  Both forms return the same bits.  The cooperative form's six workgroups per clip wait for each other: they need
- * six free CUs per clip to make progress, which any other work on the device only delays.
+ * six CUs per clip (claimed per context in a process-wide registry; a launch that does not fit runs in the one-workgroup form);
+ * failure reporting: l3ac_coop_timeout_count above.  "coop_timeout_ms" (default 250): the time limit of an arrival poll.
+ * "coop_test_fault" (test hook, default 0): j + 1 makes workgroup j of every clip withhold its first arrival.
  * "wide_narrow" (default 1): the C = 96 ConvUnits on conv_unit_wide_kernel<96> (hidden tensor in registers, two workgroups per CU);
  * 0 keeps conv_unit_ring_kernel<96>.  The two forms agree to rounding (not bit for bit).
  * "down_fused" (default 0): the encoder down layers 24 -> 48 and 48 -> 96 (Conv1d(k = stride) + ChannelNorm) in one kernel on the

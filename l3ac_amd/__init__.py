@@ -202,10 +202,21 @@ class L3AC:
             raise RuntimeError(f"{what} is on {t.device} but the network is on {self.network.device}")
         return ctx
 
+    @staticmethod
+    def _raise_on_coop_timeout(ctx, before: int, what: str):
+        lost = ctx.coop_timeout_count() - before  # (synchronises; the context has fallen back to the one-workgroup form by now)
+        if lost:
+            raise _capi.L3acError(
+                f"{what}: the cooperative transformer kernel lost {lost} arrival poll(s) to its time limit (its six workgroups per "
+                "clip were not co-resident: another process or a CU mask on the device?); this call's outputs are invalid. The "
+                "context now runs the one-workgroup form (same bits): repeat the call")
+
     @torch.no_grad()
-    def encode_audio(self, audio_data: torch.Tensor):
+    def encode_audio(self, audio_data: torch.Tensor, validate: bool = False):
         """audio (B, T) fp32 -> (q_feature (B, T_tok, C) fp32, {"indices": int32 (B, T_tok),
-        "level_indices": fp32 (B, T_tok, D)}); the zero right-padding to a hop multiple happens in-kernel."""
+        "level_indices": fp32 (B, T_tok, D)}); the zero right-padding to a hop multiple happens in-kernel.
+        ``validate=True`` synchronises and raises if a cooperative transformer launch of this call timed out (without it the
+        NEXT call on the context raises; include/l3ac_hip.h, l3ac_coop_timeout_count)."""
         ctx = self._check_input(audio_data, "audio_data")
         if audio_data.dim() != 2:
             raise ValueError(f"audio_data must be (batch, samples), got {tuple(audio_data.shape)}")
@@ -223,8 +234,11 @@ class L3AC:
         level_indices = torch.empty((b, n_tok, len(mc.levels)), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
+            lost_before = ctx.coop_timeout_count() if validate else 0
             _capi.check(ctx.lib.l3ac_encode(ctx.handle, audio.data_ptr(), b, t, audio.stride(0) if b > 1 else t,
                                             q_feature.data_ptr(), indices.data_ptr(), level_indices.data_ptr(), stream))
+            if validate:
+                self._raise_on_coop_timeout(ctx, lost_before, "encode_audio")
         return q_feature, {"indices": indices, "level_indices": level_indices}
 
     @torch.no_grad()
@@ -232,7 +246,7 @@ class L3AC:
         """(B, T_tok, C) features, or int indices (B, T_tok) -> audio (B, T_tok * hop), not trimmed.
         Indices outside [0, codebook_size) — a corrupted or truncated token stream — are clamped into range and counted on
         the device (``codec.network.context().bad_index_count()``); with ``validate=True`` the call synchronises and raises
-        if this call met any."""
+        if this call met any — or if a cooperative transformer launch of this call timed out (as encode_audio)."""
         src = audio_feature if audio_feature is not None else indices
         if src is None:
             raise ValueError("decode_audio needs audio_feature or indices")
@@ -257,7 +271,10 @@ class L3AC:
         with torch.cuda.device(src.device):
             stream = torch.cuda.current_stream(src.device).cuda_stream
             before = ctx.bad_index_count() if validate and i_ptr is not None else 0  # cumulative counter: read, never reset here
+            lost_before = ctx.coop_timeout_count() if validate else 0
             _capi.check(ctx.lib.l3ac_decode(ctx.handle, f_ptr, i_ptr, b, n_tok, audio.data_ptr(), stream))
+            if validate:
+                self._raise_on_coop_timeout(ctx, lost_before, "decode_audio")
             if validate and i_ptr is not None:
                 bad = ctx.bad_index_count() - before
                 if bad:

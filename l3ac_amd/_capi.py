@@ -9,7 +9,7 @@ import os
 
 # L3AC_LIB_PATH: load another build of the same library (experiment builds); default in-tree
 LIB_PATH = Path(os.environ.get("L3AC_LIB_PATH") or Path(__file__).resolve().parent / "libl3ac_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_STAGES = 8
 MAX_LEVELS = 8
 
@@ -54,6 +54,8 @@ SIGNATURES = {
     "l3ac_workspace_bytes": (_I64, [_P]),
     "l3ac_grn_min_norm": (C.c_int, [_P, _I32, C.POINTER(C.c_float)]),
     "l3ac_bad_index_count": (C.c_int, [_P, _I32, C.POINTER(_I64)]),
+    "l3ac_coop_timeout_count": (C.c_int, [_P, _I32, C.POINTER(_I64)]),
+    "l3ac_coop_claimed_cus": (_I32, [_I32]),
     "l3ac_hop_length": (_I32, [_P]),
     "l3ac_encode": (C.c_int, [_P, _P, _I32, _I32, _I64, _P, _P, _P, _P]),
     "l3ac_decode": (C.c_int, [_P, _P, _P, _I32, _I32, _P, _P]),
@@ -214,6 +216,13 @@ class Context:
         """Indices outside [0, codebook size) that decode calls of this context have met (and clamped).  Synchronises."""
         out = _I64(0)
         check(self.lib.l3ac_bad_index_count(self.handle, int(reset), C.byref(out)))
+        return int(out.value)
+
+    def coop_timeout_count(self, reset: bool = False) -> int:
+        """Arrival polls of the cooperative transformer kernel that expired since the last reset (calls whose outputs are invalid;
+        the context has then fallen back to the one-workgroup form).  Synchronises."""
+        out = _I64(0)
+        check(self.lib.l3ac_coop_timeout_count(self.handle, int(reset), C.byref(out)))
         return int(out.value)
 
     def grn_min_norm(self, reset: bool = False) -> float:

@@ -86,9 +86,43 @@ struct WorkspaceOrder {
     }
 };
 
-#define L3AC_ENTER_WS(ctx, stream)                          \
-    L3AC_ENTER(ctx);                                        \
-    WorkspaceOrder order_((ctx), (hipStream_t)(stream));    \
+// A cooperative transformer launch whose arrival poll expired has added to the context's host-visible failure word
+// (kernels/trans_stack.hip): results of the call it belonged to are invalid.  Acting on it: the context leaves the cooperative form
+// (the condition that starved it — another process on the device, a CU mask — is likely still there), the arrival counters, which
+// such a launch may leave non-zero, are zeroed again, and the count is remembered as acted on.  Returns the number of new expiries.
+unsigned coop_acknowledge(l3ac_ctx* ctx, bool may_sync) {
+    TransCoopState& st = ctx->coop;
+    if (!st.fail_host) return 0;
+    const unsigned now = *(volatile unsigned*)st.fail_host;
+    const unsigned fresh = now - st.seen;
+    if (fresh == 0) return 0;
+    st.seen = now;
+    st.enabled = 0;
+    if (may_sync && st.scratch) {
+        (void)hipDeviceSynchronize();
+        (void)hipMemset((char*)st.scratch + trans_stack_coop_counter_offset(), 0, trans_stack_coop_counter_bytes());
+    }
+    return fresh;
+}
+
+// Every workspace-using entry point first looks at the failure word (a host memory read): a context whose EARLIER call lost a
+// cooperative launch to a timeout says so now — once — instead of carrying on as if that call's outputs were good.
+int coop_check_on_entry(l3ac_ctx* ctx, hipStream_t s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (s) (void)hipStreamIsCapturing(s, &st);
+    const unsigned fresh = coop_acknowledge(ctx, st == hipStreamCaptureStatusNone);
+    if (fresh == 0) return L3AC_OK;
+    l3ac_set_error("an earlier call on this context lost %u arrival poll(s) of the cooperative transformer kernel to the time limit "
+                   "(its six workgroups per clip were not co-resident: another process or a CU mask on the device?): that call's "
+                   "outputs are INVALID; the context now runs the one-workgroup form (option trans_coop = 0) — repeat the call",
+                   fresh);
+    return L3AC_ECOOP;
+}
+
+#define L3AC_ENTER_WS(ctx, stream)                                          \
+    L3AC_ENTER(ctx);                                                        \
+    L3AC_TRY(coop_check_on_entry((ctx), (hipStream_t)(stream)));            \
+    WorkspaceOrder order_((ctx), (hipStream_t)(stream));                    \
     if (order_.rc != L3AC_OK) return order_.rc
 
 template <class Map>
@@ -178,6 +212,20 @@ int l3ac_bad_index_count(l3ac_ctx* ctx, int32_t reset, int64_t* out) {
     if (reset) L3AC_HIP_CHECK(hipMemset(ctx->bad_index_count, 0, sizeof(int)));
     return L3AC_OK;
 }
+
+int l3ac_coop_timeout_count(l3ac_ctx* ctx, int32_t reset, int64_t* out) {
+    L3AC_ENTER(ctx);
+    L3AC_REQUIRE(out != nullptr, "coop_timeout_count: null output");
+    L3AC_HIP_CHECK(hipDeviceSynchronize());
+    TransCoopState& st = ctx->coop;
+    const unsigned now = st.fail_host ? *(volatile unsigned*)st.fail_host : 0u;
+    *out = (int64_t)(unsigned)(now - st.count_base);
+    (void)coop_acknowledge(ctx, true);  // the caller has been told: fall back, re-zero the counters, no second report on the next call
+    if (reset) st.count_base = now;
+    return L3AC_OK;
+}
+
+int32_t l3ac_coop_claimed_cus(int32_t device) { return trans_coop_claimed_on_device(device); }
 
 int l3ac_grn_min_norm(l3ac_ctx* ctx, int32_t reset, float* out) {
     L3AC_ENTER(ctx);
@@ -323,6 +371,9 @@ int l3ac_op_down_layer(l3ac_ctx* ctx, const char* block, const float* x, int32_t
     L3AC_ENTER_WS(ctx, stream);
     const DownW* w = lookup(ctx->by_down, block, "down-layer");
     if (!w) return L3AC_EINVAL;
+    // (the layer's form — one fused kernel or GEMM + row kernel — must depend on the shape and the context's route only: the fused
+    // kernel cannot run in place, so in-place calls are refused instead of silently taking the other rounding)
+    L3AC_REQUIRE(x != y, "op_down_layer: x and y must not alias");
     return run_down(ctx, (hipStream_t)stream, *w, x, y, batch, frames);
 }
 
@@ -359,6 +410,7 @@ int l3ac_op_enhance_up(l3ac_ctx* ctx, const char* enhance_block, const char* up_
     const UpW* w = lookup(ctx->by_up, up_block, "up-layer");
     if (!e || !w) return L3AC_EINVAL;
     L3AC_REQUIRE(e->c == w->cin, "enhance_up: blocks of different widths (%d vs %d)", e->c, w->cin);
+    L3AC_REQUIRE(x != y, "op_enhance_up: x and y must not alias (x is only read)");
     L3AC_OP_SCRATCH(w->cin > w->cout ? w->cin : w->cout);
     // the pipeline's fused form: gate applied inside the up conv's A staging; x is only read
     return run_enhance_up(ctx, (hipStream_t)stream, *e, *w, const_cast<float*>(x), ctx->ws.a, y, batch, frames);
@@ -544,11 +596,13 @@ int l3ac_ctx_set_option(l3ac_ctx* ctx, const char* name, int32_t value) {
     else if (n == "head_pretanh") ctx->head_pretanh = value != 0;
     else if (n == "narrow_ring") ctx->narrow_ring = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "ring_geometry") ctx->ring_geometry = value;
-    else if (n == "trans_coop") ctx->trans_coop_enabled = value != 0;
+    else if (n == "trans_coop") ctx->coop.enabled = value != 0;
+    else if (n == "coop_timeout_ms") ctx->coop.timeout_ms = value < 1 ? 1 : (value > 20000 ? 20000 : value);
+    else if (n == "coop_test_fault") ctx->coop.fault_part = value - 1;  // 0 = off, j + 1 = workgroup j of every clip withholds its first arrival
     else if (n == "wide_narrow") ctx->wide_narrow = value != 0;
     else if (n == "down_fused") ctx->down_fused = value != 0;
     else {
-        l3ac_set_error("set_option: unknown option '%s' (gemm_split, head_pretanh, narrow_ring, ring_geometry, trans_coop, wide_narrow, down_fused)", name);
+        l3ac_set_error("set_option: unknown option '%s' (gemm_split, head_pretanh, narrow_ring, ring_geometry, trans_coop, coop_timeout_ms, coop_test_fault, wide_narrow, down_fused)", name);
         return L3AC_EINVAL;
     }
     return L3AC_OK;

@@ -33,8 +33,10 @@
 // clip six co-resident workgroups: workgroup j runs head j of every attention sub-layer and hidden chunks 2 j, 2 j + 1 of every
 // FeedForward for ALL frames of the clip, streaming only those weights (20 of a layer's 114 ring slots).  A sub-layer's output is
 // then a sum of six PARTIAL tiles (one per head / per chunk pair), each accumulated from zero; the partials cross workgroups through
-// write-through slabs in global memory behind an arrival counter (guide: 'inter-workgroup visibility', producer sc1 stores ->
-// vmcnt(0) -> barrier -> agent-scope add; consumer: poll -> acquire fence -> barrier -> loads) and EVERY workgroup adds them in the
+// write-through slabs in global memory behind an arrival counter (guide: 'inter-workgroup visibility', the hand-off form measured
+// with sc1 loads in place of the acquire — producer: every byte by 16-B sc1 stores -> every wave's vmcnt(0) -> workgroup barrier ->
+// ONE lane's agent-scope add; consumer: that lane polls with sc1 loads -> workgroup barrier -> every load of the bytes a 16-B sc1
+// buffer load to registers; no plain load ever touches a slab, so no L1 line of it can be stale) and EVERY workgroup adds them in the
 // same fixed order ((((p0 + p1) + p2) + p3) + p4) + p5 — which is also how the one-workgroup form (KS = 1) now sums its heads and
 // chunk pairs, so the two forms return the same bits and batch invariance holds across them.
 #include "../kernels.hpp"
@@ -100,6 +102,13 @@ struct TransStackArgs {
     unsigned* coop_cnt;
     int batch;
     int coop_slots;            // clip slots of this launch: the batch rounded up to a multiple of 8 (grid = TS_KS * coop_slots)
+    // An arrival poll that is not answered within `coop_timeout_ticks` (s_memrealtime, 100 MHz) is COUNTED in *coop_fail (host-visible,
+    // system-scope add) and the workgroup stops waiting for the rest of the launch: the launch ends promptly with invalid numbers
+    // and the host hears about it (l3ac_coop_timeout_count / the next call on the context).  coop_fault_part >= 0 (test hook):
+    // that workgroup of every clip withholds its first arrival.
+    unsigned* coop_fail;
+    unsigned coop_timeout_ticks;
+    int coop_fault_part;
 };
 constexpr int TS_KS = 6;                                    // workgroups per clip of the cooperative form (= heads)
 constexpr int TS_COOP_CLIPS = 32;                           // clip slots (a multiple of 8: blocks b and b + 8 are dealt to the same XCD — speed only)
@@ -360,6 +369,7 @@ void trans_stack_kernel(const TransStackArgs p) {
     // after the other.  Cooperative form: workgroup `part` computes partial `part`, all six exchange them through the slabs.
     f32x4_t yacc[8], tacc[8];
     int coop_phase = 0;  // sub-layers finished so far (wave-uniform)
+    bool coop_dead = false;  // (the polling lane's) an arrival poll of this launch has expired: counted, no further waiting
     const __amdgpu_buffer_rsrc_t slab_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(COOP ? p.coop_slab + (int64_t)clip * TS_COOP_SLAB_FLOATS : p.x), 0, (int)(TS_COOP_SLAB_FLOATS * 4), 0x00020000);
     auto add_partial = [&](int index) __attribute__((always_inline)) {  // KS == 1: partial `index` is complete in tacc
@@ -379,12 +389,25 @@ void trans_stack_kernel(const TransStackArgs p) {
         TS_STAMP(10);  // partial stored
         unsigned* const cnt = p.coop_cnt + 2 * clip;
         if (tid == 0) {
-            __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!(coop_phase == 0 && part == p.coop_fault_part))  // (test hook: this workgroup's first arrival is withheld)
+                __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned want = (unsigned)TS_KS * (unsigned)(coop_phase + 1);
-            // (bounded: were the six workgroups of a clip ever not co-resident — a CU mask, a debugger holding CUs — the launch ends
-            // with wrong numbers after some seconds instead of hanging the device)
-            for (unsigned spins = 0; __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && spins < (1u << 25); ++spins)
-                __builtin_amdgcn_s_sleep(2);
+            // Bounded in TIME: were the six workgroups of a clip ever not co-resident (more cooperative launches at once than the
+            // chip has CUs — launch_trans_stack's admission rules that out inside one process —, another process holding the CUs, a
+            // CU mask, a debugger) the poll expires after coop_timeout_ticks; the expiry is counted where the host sees it and this
+            // workgroup stops waiting, so the launch ends within one timeout — its numbers are invalid and the host is told.
+            if (!coop_dead && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                for (;;) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) break;
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)p.coop_timeout_ticks) {
+                        coop_dead = true;
+                        __hip_atomic_fetch_add(p.coop_fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
+                }
+            }
         }
         __builtin_amdgcn_s_barrier();                      // the poll has matched: all six partials of this phase are in memory
         TS_STAMP(11);  // arrival + wait for the other five
@@ -647,6 +670,41 @@ size_t trans_stack_coop_bytes() {  // scratch of the cooperative form: slabs + p
     return (size_t)TS_COOP_CLIPS * (size_t)(TS_COOP_SLAB_FLOATS + TS_COOP_X_FLOATS) * sizeof(float) + 2 * TS_COOP_CLIPS * sizeof(unsigned);
 }
 int trans_stack_coop_max_batch() { return TS_COOP_CLIPS; }
+size_t trans_stack_coop_counter_offset() { return (size_t)TS_COOP_CLIPS * (size_t)(TS_COOP_SLAB_FLOATS + TS_COOP_X_FLOATS) * sizeof(float); }
+size_t trans_stack_coop_counter_bytes() { return 2 * TS_COOP_CLIPS * sizeof(unsigned); }
+
+// ---- admission of cooperative launches ---------------------------------------------------------------------------------------
+// The six workgroups of a clip wait for each other, so every workgroup of every cooperative launch that can be on the device at
+// one time must be able to hold a CU of its own.  Launches of ONE context are ordered (one stream, or the workspace event), but two
+// contexts on two streams — or two graphs — run side by side, and nothing at enqueue time says which.  So each context CLAIMS CUs
+// in a process-wide per-device registry: a launch of `batch` clips needs TS_KS * batch of them (clip slots beyond the batch return
+// at once); a context's claim only ever grows (a graph captured from it may replay the launch at any later time) and is returned when
+// the context is destroyed.  A launch whose claim does not fit the device's CU count any more runs in the one-workgroup form — same
+// bits.  Other PROCESSES on the device are outside this registry: they need trans_coop = 0 (include/l3ac_hip.h), and the kernel's
+// timed poll reports it if they do not.
+static std::atomic<int> g_coop_claimed[L3AC_MAX_DEVICES] = {};
+
+bool trans_coop_admit(TransCoopState& st, int batch) {
+    const int slot = l3ac_device_slot();
+    if (slot < 0) return false;
+    const int need = TS_KS * batch;
+    if (need <= st.claim) return true;
+    const int more = need - st.claim, cus = l3ac_device_cu_count();
+    int cur = g_coop_claimed[slot].load(std::memory_order_relaxed);
+    do {
+        if (cur + more > cus) return false;
+    } while (!g_coop_claimed[slot].compare_exchange_weak(cur, cur + more, std::memory_order_relaxed));
+    st.claim = need;
+    st.claim_slot = slot;
+    return true;
+}
+void trans_coop_release(TransCoopState& st) {
+    if (st.claim > 0 && st.claim_slot >= 0) g_coop_claimed[st.claim_slot].fetch_sub(st.claim, std::memory_order_relaxed);
+    st.claim = 0;
+}
+int trans_coop_claimed_on_device(int device) {
+    return device < 0 || device >= L3AC_MAX_DEVICES ? -1 : g_coop_claimed[device].load(std::memory_order_relaxed);
+}
 
 template <int MAXW>
 static void launch_ts(hipStream_t s, bool coop, int batch, int waves, int n_layers, const TransStackArgs& a) {
@@ -657,9 +715,10 @@ static void launch_ts(hipStream_t s, bool coop, int batch, int waves, int n_laye
         hipLaunchKernelGGL((trans_stack_kernel<MAXW, 1>), dim3((unsigned)batch), dim3(threads), TsLds<MAXW>::bytes(n_layers), s, a);
 }
 
-// `coop`: scratch of trans_stack_coop_bytes() bytes whose counters (the last 2 * TS_COOP_CLIPS words) were zeroed when it was
-// allocated, or null.  With it, batches of at most TS_COOP_CLIPS clips run in the cooperative form (six workgroups per clip).
-int launch_trans_stack(hipStream_t s, const LocalTransW& w, float* x, int batch, int frames, float scale, void* coop) {
+// `coop`: the context's cooperative-form state (scratch of trans_stack_coop_bytes() bytes whose counters — the last 2 * TS_COOP_CLIPS
+// words — were zeroed when it was allocated, the host-visible failure word, the claim), or null.  With it, batches of at most
+// TS_COOP_CLIPS clips that are admitted (above) run in the cooperative form (six workgroups per clip).
+int launch_trans_stack(hipStream_t s, const LocalTransW& w, float* x, int batch, int frames, float scale, TransCoopState* coop) {
     const int n_layers = (int)w.layers.size();
     L3AC_REQUIRE(w.stack_img && w.stack_ln && batch > 0 && frames >= 1 && frames <= TS_MAX_FRAMES && frames <= w.window &&
                      n_layers >= 1 && n_layers <= TS_MAX_LAYERS,
@@ -677,14 +736,20 @@ int launch_trans_stack(hipStream_t s, const LocalTransW& w, float* x, int batch,
     int waves = 2 * (int)ceil_div64(frames, 32);  // even: every key tile a wave reads in pairs has been written by some wave
     if (waves < 4) waves = 4;                      // (the 4-wave instantiation adds its loader wave at the launch)
     // the cooperative form needs its TS_KS workgroups per clip co-resident (they wait for each other), one workgroup per CU
-    const bool use_coop = coop != nullptr && batch <= TS_COOP_CLIPS && l3ac_device_cu_count() >= TS_KS * ((batch + 7) / 8 * 8);
+    const bool use_coop = coop != nullptr && coop->enabled && coop->scratch != nullptr && coop->fail_dev != nullptr &&
+                          batch <= TS_COOP_CLIPS && trans_coop_admit(*coop, batch);
     TransStackArgs a{};
     a.x = x; a.frames = frames; a.n_layers = n_layers; a.img = w.stack_img; a.ln = w.stack_ln; a.bias_table = w.bias_table;
     a.table_stride = 2 * w.window; a.scale = scale; a.batch = batch; a.coop_slots = (batch + 7) / 8 * 8;
+    a.coop_fault_part = -1;
     if (use_coop) {
-        a.coop_slab = reinterpret_cast<float*>(coop);
+        a.coop_slab = reinterpret_cast<float*>(coop->scratch);
         a.coop_x = a.coop_slab + (int64_t)TS_COOP_CLIPS * TS_COOP_SLAB_FLOATS;
         a.coop_cnt = reinterpret_cast<unsigned*>(a.coop_x + (int64_t)TS_COOP_CLIPS * TS_COOP_X_FLOATS);
+        a.coop_fail = coop->fail_dev;
+        const long long ticks = (long long)(coop->timeout_ms > 0 ? coop->timeout_ms : 1) * 100000LL;  // s_memrealtime: 100 MHz
+        a.coop_timeout_ticks = (unsigned)(ticks > 0xffffffffLL ? 0xffffffffLL : ticks);
+        a.coop_fault_part = coop->fault_part;
     }
     const double rows = (double)batch * frames;
     const double lin = 2.0 * (3.0 * TS_INNER * TS_DIM + TS_DIM * TS_INNER + 3.0 * TS_FFI * TS_DIM);

@@ -468,11 +468,15 @@ int network_build(l3ac_ctx* ctx, const l3ac_tensor* tensors, int n_tensors) {
         for (const std::vector<LocalTransW>* v : {&ctx->en_enc, &ctx->en_dec})
             for (const LocalTransW& t : *v) any = any || t.stack_img != nullptr;
         if (any) {
-            L3AC_HIP_CHECK(hipMalloc(&ctx->trans_coop, trans_stack_coop_bytes()));
-            L3AC_HIP_CHECK(hipMemset(ctx->trans_coop, 0, trans_stack_coop_bytes()));
+            L3AC_HIP_CHECK(hipMalloc(&ctx->coop.scratch, trans_stack_coop_bytes()));
+            L3AC_HIP_CHECK(hipMemset(ctx->coop.scratch, 0, trans_stack_coop_bytes()));
+            // the failure word lives in pinned host memory the device can add to: the host reads it without a device call
+            L3AC_HIP_CHECK(hipHostMalloc((void**)&ctx->coop.fail_host, 64, hipHostMallocMapped | hipHostMallocCoherent));
+            *ctx->coop.fail_host = 0;
+            L3AC_HIP_CHECK(hipHostGetDevicePointer((void**)&ctx->coop.fail_dev, ctx->coop.fail_host, 0));
         }
         const char* e = std::getenv("L3AC_TRANS_COOP");
-        if (e) ctx->trans_coop_enabled = std::atoi(e);
+        if (e) ctx->coop.enabled = std::atoi(e);
     }
     {  // GRN guard: starts at +inf
         const float inf = INFINITY;
@@ -513,8 +517,11 @@ int network_build(l3ac_ctx* ctx, const l3ac_tensor* tensors, int n_tensors) {
 void network_free(l3ac_ctx* ctx) {
     if (ctx->bad_index_count) (void)hipFree(ctx->bad_index_count);
     ctx->bad_index_count = nullptr;
-    if (ctx->trans_coop) (void)hipFree(ctx->trans_coop);
-    ctx->trans_coop = nullptr;
+    trans_coop_release(ctx->coop);
+    if (ctx->coop.scratch) (void)hipFree(ctx->coop.scratch);
+    ctx->coop.scratch = nullptr;
+    if (ctx->coop.fail_host) (void)hipHostFree(ctx->coop.fail_host);
+    ctx->coop.fail_host = ctx->coop.fail_dev = nullptr;
     if (ctx->grn_min_sumsq) (void)hipFree(ctx->grn_min_sumsq);
     ctx->grn_min_sumsq = nullptr;
     if (ctx->arena) (void)hipFree(ctx->arena);
@@ -788,8 +795,16 @@ int run_enhance_up(l3ac_ctx* ctx, hipStream_t s, const EnhW& e, const UpW& w, fl
     // weight's shape and the context's route only, never on the batch.
     const bool wide_up = ctx->img(w.w) != nullptr && gemm_split_eligible(w.cout, w.cin);
     if (w.cin % 16 != 0 || e.c != w.cin || wide_up) {
-        L3AC_TRY(run_enhance(ctx, s, e, x, x, batch, frames));
-        return run_up(ctx, s, w, x, tmp, y, batch, frames);
+        L3AC_REQUIRE(tmp != nullptr, "enhance_up: scratch missing");
+        // the pipeline calls this in place (x == y: the gate may overwrite x); any other caller's x is only read, so the gated
+        // rows go to the hidden-tensor scratch (free here: the up layer's GEMM writes tmp)
+        float* gated = x;
+        if (x != y) {
+            L3AC_REQUIRE((size_t)batch * frames * e.c <= ctx->ws.h_cap, "enhance_up: workspace too small for the gated rows");
+            gated = ctx->ws.h;
+        }
+        L3AC_TRY(run_enhance(ctx, s, e, x, gated, batch, frames));
+        return run_up(ctx, s, w, gated, tmp, y, batch, frames);
     }
     Workspace& ws = ctx->ws;
     L3AC_TRY(launch_enhance_branches(s, e.t, x, batch, frames, e.c, ws.yi));
@@ -854,8 +869,7 @@ static bool use_trans_stack(const l3ac_ctx* ctx, const LocalTransW& w, int frame
 
 int run_local_trans(l3ac_ctx* ctx, hipStream_t s, const LocalTransW& w, float* x, int batch, int frames) {
     if (use_trans_stack(ctx, w, frames))  // one launch for the whole stack, one workgroup per clip
-        return launch_trans_stack(s, w, x, batch, frames, (float)std::pow((double)ctx->dim_head, -0.5),
-                                  ctx->trans_coop_enabled ? ctx->trans_coop : nullptr);
+        return launch_trans_stack(s, w, x, batch, frames, (float)std::pow((double)ctx->dim_head, -0.5), &ctx->coop);
     Workspace& ws = ctx->ws;
     const int dim = ctx->cfg.feature_dim;
     const int64_t rows = (int64_t)batch * frames;

@@ -63,6 +63,19 @@ struct LocalTransW {  // local_trans.py:7-53
     const float* stack_ln = nullptr;
 };
 
+// Cooperative form of trans_stack_kernel (kernels/trans_stack.hip): per-context state.
+struct TransCoopState {
+    void* scratch = nullptr;        // device: partial slabs, private residual streams, arrival counters (trans_stack_coop_bytes())
+    unsigned* fail_host = nullptr;  // pinned, device-visible host word: arrival polls that expired (cumulative); the kernel adds to it
+    unsigned* fail_dev = nullptr;   // its device address
+    int enabled = 1;                // option "trans_coop"; cleared for good once a timeout has been seen
+    int claim = 0, claim_slot = -1; // CUs of the device this context's cooperative launches may occupy (process-wide registry)
+    int timeout_ms = 250;           // option "coop_timeout_ms": how long an arrival poll waits
+    int fault_part = -1;            // option "coop_test_fault" (test hook): workgroup that withholds its first arrival, -1 = none
+    unsigned seen = 0;              // value of *fail_host the host has already acted on (fallback + report)
+    unsigned count_base = 0;        // value of *fail_host at the last l3ac_coop_timeout_count(reset = 1)
+};
+
 struct Workspace {
     float *x0 = nullptr, *x1 = nullptr, *a = nullptr, *h = nullptr, *yi = nullptr, *stats = nullptr, *sumsq = nullptr;
     size_t x_cap = 0, a_cap = 0, h_cap = 0, yi_cap = 0, b_cap = 0;  // capacities in floats
@@ -130,8 +143,7 @@ struct l3ac_ctx {
     // when it has enqueued its last kernel, and a later call on a DIFFERENT stream first makes that stream wait for it.
     // scratch of trans_stack_kernel's cooperative form (partial slabs, private residual streams, arrival counters); option
     // "trans_coop" (default 1) switches the form off without freeing it
-    void* trans_coop = nullptr;
-    int trans_coop_enabled = 1;
+    TransCoopState coop;
     int* bad_index_count = nullptr;  // device: indices outside [0, codebook size) seen by l3ac_decode since the last reset
     float* grn_min_sumsq = nullptr;  // device: smallest per-clip sum of squares any GRN of this context has seen (grn_exact only)
     hipEvent_t ws_done = nullptr;
@@ -168,11 +180,16 @@ bool trans_stack_supported(int dim, int dim_head, int heads, int ff_inner, int f
 void trans_stack_layer_image(std::vector<unsigned char>& img, const float* wqkv, const float* wout, const float* wff1, int ff_n,
                              const float* wff2, int ff_pad);
 int64_t trans_stack_layer_image_bytes();
-// `coop` (trans_stack_coop_bytes() bytes, counters zeroed at allocation; null = never): batches of at most
-// trans_stack_coop_max_batch() clips run in the cooperative form, six workgroups per clip — same bits as the one-workgroup form
-int launch_trans_stack(hipStream_t s, const LocalTransW& w, float* x, int batch, int frames, float scale, void* coop = nullptr);
+// `coop` (the context's TransCoopState; null = never): batches of at most trans_stack_coop_max_batch() clips that the per-device
+// admission lets in run in the cooperative form, six workgroups per clip — same bits as the one-workgroup form
+int launch_trans_stack(hipStream_t s, const LocalTransW& w, float* x, int batch, int frames, float scale, TransCoopState* coop = nullptr);
 size_t trans_stack_coop_bytes();
+size_t trans_stack_coop_counter_offset();  // the arrival counters inside the scratch: [offset, offset + bytes)
+size_t trans_stack_coop_counter_bytes();
 int trans_stack_coop_max_batch();
+bool trans_coop_admit(TransCoopState& st, int batch);
+void trans_coop_release(TransCoopState& st);
+int trans_coop_claimed_on_device(int device);  // -1: bad ordinal
 // EnhanceBlock gate + 1x1 conv + linear upsample + ChannelNorm of the narrow decoder stages in one kernel (kernels/up_fused.hip)
 bool up_fused_supported(int cin, int cout);
 std::vector<unsigned char> up_fused_image(const float* w, int cin, int cout);  // w [cout][cin]

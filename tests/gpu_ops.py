@@ -28,8 +28,8 @@ def op_block(ctx, fn_name, block, x_btc, out_shape):
     return y
 
 
-def op_block2(ctx, fn_name, block_a, block_b, x_btc, out_shape):
-    y = torch.empty(out_shape, dtype=torch.float32, device=x_btc.device)
+def op_block2(ctx, fn_name, block_a, block_b, x_btc, out_shape, out=None):
+    y = torch.empty(out_shape, dtype=torch.float32, device=x_btc.device) if out is None else out
     b, frames = x_btc.shape[0], x_btc.shape[1]
     fn = getattr(ctx.lib, fn_name)
     _capi.check(fn(ctx.handle, block_a.encode(), block_b.encode(), x_btc.data_ptr(), b, frames, y.data_ptr(), _stream(x_btc.device)))

@@ -185,3 +185,37 @@ def module_tree_from_state_dict(sd):
         node_at(path).register_parameter(name, nn.Parameter(torch.zeros_like(v)))
     root.load_state_dict(sd, strict=True)
     return root.eval()
+
+
+# ---- oracle outputs, computed once per session ------------------------------------------------------------------------------
+ORACLE_CHUNK = 32  # clips per oracle call (host memory: the unfused CPU path holds ~25 MB per clip-second)
+_ORACLE_ENCODE_CACHE = {}
+
+
+def _digest(*tensors):
+    import hashlib
+    h = hashlib.sha1()
+    for t in tensors:
+        h.update(t.detach().cpu().contiguous().numpy().tobytes())
+    return h.hexdigest()
+
+
+def oracle_indices(w, mc, audio):
+    """Oracle tokens + latents of `audio` [B, T] (CPU), in chunks of ORACLE_CHUNK clips.  Several tests compare the same seeded
+    batches (or a prefix of one) with the oracle: each chunk of clips is encoded once per session, keyed by the bytes of the chunk's
+    audio and a fingerprint of the weights (every tensor's sum and the bytes of the quantiser's projection)."""
+    from oracle import l3ac_oracle as O
+    wkey = (tuple(mc.levels), mc.hop_length, _digest(w["quantizer.project_in.weight"], w["quantizer.project_out.weight"]),
+            round(float(sum(float(v.double().sum()) for v in w.values())), 6))
+    idx, lat = [], []
+    for b0 in range(0, audio.shape[0], ORACLE_CHUNK):
+        chunk = audio[b0:b0 + ORACLE_CHUNK]
+        key = (wkey, tuple(chunk.shape), _digest(chunk))
+        if key not in _ORACLE_ENCODE_CACHE:
+            taps = {}
+            _, ind = O.encode_audio(w, mc, chunk, taps=taps)
+            _ORACLE_ENCODE_CACHE[key] = (ind["indices"], taps["latents"])
+        i, l = _ORACLE_ENCODE_CACHE[key]
+        idx.append(i)
+        lat.append(l)
+    return torch.cat(idx), torch.cat(lat)

@@ -1,10 +1,12 @@
 """HIP kernels vs the CPU oracle, block by block, through the C ABI (needs an MI355X: `pytest -m gpu`)."""
+import time
+
 import numpy as np
 import pytest
 import torch
 
 import l3ac_amd
-from l3ac_amd import weights as W
+from l3ac_amd import _capi, weights as W
 from oracle import l3ac_oracle as O
 from tests import gpu_ops as G
 from tests.helpers import GOLDEN, index_mismatch_report, load_case, seeded_audio
@@ -426,8 +428,13 @@ def test_enhance_and_up_layers(tiny, full):
             r = F.conv1d(ref, w[f"{ub}.0.weight"], w[f"{ub}.0.bias"])
             r = F.interpolate(r, scale_factor=s, mode="linear", align_corners=False)
             r = O.channel_norm_first(r, w[f"{ub}.2.weight"], w[f"{ub}.2.bias"])
-            got = G.op_block2(codec.network.context(), "l3ac_op_enhance_up", eb, ub, G.to_frames(x), (2, t * s, co))
+            xin = G.to_frames(x)
+            keep = xin.clone()
+            got = G.op_block2(codec.network.context(), "l3ac_op_enhance_up", eb, ub, xin, (2, t * s, co))
             _close(eb + "+" + ub, G.from_frames(got), r)
+            assert torch.equal(xin, keep), f"{eb}+{ub}: l3ac_op_enhance_up wrote to its input (x is only read)"
+            with pytest.raises(_capi.L3acError, match="alias"):  # in place is refused, not silently another rounding
+                G.op_block2(codec.network.context(), "l3ac_op_enhance_up", eb, ub, xin, (2, t * s, co), out=xin)
 
 
 def test_last_block(tiny, full):
@@ -555,6 +562,119 @@ def test_local_trans_stack_cooperative_form(full):
         got = G.op_block(ctx, "l3ac_op_local_trans", block, xg, (2, t, 128))
         assert torch.equal(got.cpu(), want), f"launch {i}"
     torch.cuda.synchronize()
+    assert ctx.coop_timeout_count() == 0  # no arrival poll of any launch above ran into its time limit
+
+
+def _stack_launch_names(fn):
+    """Names of the trans_stack launches `fn` makes (the library's own launch profile): '<coop>' marks the cooperative form."""
+    with _capi.profile() as prof:
+        fn()
+    return [e["name"] for e in prof.entries if e["name"].startswith("trans_stack_kernel")]
+
+
+def test_cooperative_stack_reports_a_lost_arrival():
+    """A cooperative launch whose six workgroups per clip are not all there (here: a test hook makes workgroup 3 of every clip
+    withhold its first arrival, and the time limit is 5 ms) must not return wrong tokens silently: the kernel counts the expired
+    polls in host-visible memory, every workgroup stops waiting (the launch ends at once), and the host hears it — through
+    encode_audio(validate=True), through l3ac_coop_timeout_count, and (without either) as L3AC_ECOOP from the NEXT call.  The context
+    then runs the one-workgroup form and the repeated call returns the right tokens."""
+    ref_codec = l3ac_amd.get_model("1kbps", synthetic_seed=0)
+    ref_codec.network.to(device="cuda").eval()
+    ref_codec.network.context().set_option("trans_coop", 0)
+    audio = ((torch.rand(2, 16000, generator=torch.Generator().manual_seed(4)) * 2 - 1) * 0.5).cuda()
+    want = ref_codec.encode_audio(audio)[1]["indices"]
+    want_wave = ref_codec.decode_audio(indices=want)
+
+    def fresh():
+        c = l3ac_amd.get_model("1kbps", synthetic_seed=0)
+        c.network.to(device="cuda").eval()
+        k = c.network.context()
+        k.set_option("coop_timeout_ms", 5)
+        k.set_option("coop_test_fault", 3 + 1)
+        return c, k
+
+    # (1) validate=True: the call itself raises, the message says what happened, the retry is right
+    codec, ctx = fresh()
+    assert any("<coop>" in n for n in _stack_launch_names(lambda: codec.encode_audio(audio[:1])))  # (the hook only bites cooperative launches)
+    assert ctx.coop_timeout_count(reset=True) > 0
+    ctx.set_option("trans_coop", 1)  # (acting on the count switched the form off: back on for the checks below)
+    t0 = time.perf_counter()
+    with pytest.raises(_capi.L3acError, match="(?s)cooperative.*time limit.*invalid"):
+        codec.encode_audio(audio, validate=True)
+    assert time.perf_counter() - t0 < 5.0  # every workgroup gives up after ONE expired poll: milliseconds, not one limit per phase
+    got = codec.encode_audio(audio, validate=True)[1]["indices"]  # one-workgroup form now
+    assert torch.equal(got, want)
+    assert not any("<coop>" in n for n in _stack_launch_names(lambda: codec.encode_audio(audio)))
+    # (2) no validate: the NEXT call returns L3AC_ECOOP once, then the context works
+    codec, ctx = fresh()
+    bad = codec.encode_audio(audio)[1]["indices"]
+    torch.cuda.synchronize()
+    with pytest.raises(_capi.L3acError, match="(?s)error -5.*earlier call.*INVALID"):
+        codec.decode_audio(indices=bad)
+    got = codec.encode_audio(audio)[1]["indices"]
+    assert torch.equal(got, want)
+    assert torch.equal(codec.decode_audio(indices=got), want_wave)
+    assert ctx.coop_timeout_count() > 0   # cumulative since the last reset; asking again does not raise
+    assert ctx.coop_timeout_count(reset=True) > 0 and ctx.coop_timeout_count() == 0
+    # (3) decode_audio(validate=True) the same way
+    codec, ctx = fresh()
+    with pytest.raises(_capi.L3acError, match="decode_audio.*cooperative"):
+        codec.decode_audio(indices=want, validate=True)
+    assert torch.equal(codec.decode_audio(indices=want, validate=True), want_wave)
+
+
+def test_cooperative_stacks_of_two_contexts_cannot_starve_each_other():
+    """Two contexts x 32 clips on two streams: 2 x 192 cooperative workgroups do not fit 256 CUs, and workgroups that wait for
+    partners which cannot be scheduled would wait for ever.  Contexts claim their CUs in a per-device registry
+    (l3ac_coop_claimed_cus): the context whose claim no longer fits runs the one-workgroup form (same bits).  Small batches of both
+    contexts fit together and both stay cooperative.  (Contexts of other tests that are still alive hold claims too: the batch is
+    sized from what is free.)"""
+    import gc
+    gc.collect()  # contexts of earlier tests return their claims when they are destroyed
+    lib = _capi.load_library()
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    base = lib.l3ac_coop_claimed_cus(0)
+    n = min(32, (cus - 6 - base) // 6)  # clips per batch: context a's claim fits, context b's then does not
+    if n < 2 or 12 * n <= cus - base:
+        pytest.skip(f"{base} of {cus} CUs claimed by other live contexts: no batch size separates the two cases")
+    mk = lambda: l3ac_amd.get_model("1kbps", synthetic_seed=0)
+    a, b = mk(), mk()
+    for c in (a, b):
+        c.network.to(device="cuda").eval()
+    ca, cb = a.network.context(), b.network.context()
+    g = torch.Generator().manual_seed(8)
+    audio = ((torch.rand(n, 16000, generator=g) * 2 - 1) * 0.5).cuda()
+    # one clip each: both cooperative
+    assert any("<coop>" in x for x in _stack_launch_names(lambda: a.encode_audio(audio[:1])))
+    assert any("<coop>" in x for x in _stack_launch_names(lambda: b.encode_audio(audio[:1])))
+    assert lib.l3ac_coop_claimed_cus(0) == base + 12
+    # n clips each: the first to ask gets its 6 n CUs, the second does not
+    names_a = _stack_launch_names(lambda: a.encode_audio(audio))
+    names_b = _stack_launch_names(lambda: b.encode_audio(audio))
+    assert all("<coop>" in x for x in names_a) and not any("<coop>" in x for x in names_b), (names_a, names_b)
+    assert lib.l3ac_coop_claimed_cus(0) == base + 6 * n + 6
+    ref = mk()
+    ref.network.to(device="cuda").eval()
+    ref.network.context().set_option("trans_coop", 0)
+    want = ref.encode_audio(audio)[1]["indices"]
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(6):  # side by side, repeatedly
+        with torch.cuda.stream(sa):
+            ia = a.encode_audio(audio)[1]["indices"]
+        with torch.cuda.stream(sb):
+            ib = b.encode_audio(audio)[1]["indices"]
+        outs.append((ia, ib))
+    torch.cuda.synchronize()
+    for ia, ib in outs:
+        assert torch.equal(ia, want) and torch.equal(ib, want)
+    assert ca.coop_timeout_count() == 0 and cb.coop_timeout_count() == 0
+    # the claim goes back with the context
+    del a, ca, names_a, outs, ia
+    gc.collect()
+    assert lib.l3ac_coop_claimed_cus(0) == base + 6
+    assert all("<coop>" in x for x in _stack_launch_names(lambda: b.encode_audio(audio)))  # ... and b's launches fit now
 
 
 # ---------------------------------------------------------------------------------------------------
