@@ -218,7 +218,8 @@ int l3ac_op_decoder(l3ac_ctx* ctx, const float* feature, int32_t batch, int32_t 
 
 /* snake activation on its own (layers.py:29-33): y = x + (alpha + 1e-8)^-1 * sin(alpha * x)^2 for x [rows][c], alpha [c]
  * (device pointers).  mode bit 0: evaluate the two-elements-per-lane form the GEMM epilogues and the fused units use;
- * mode bit 1: y = sin(x)^2 alone (the kernels' own sine; alpha is not used).
+ * mode bit 1: y = sin(x)^2 alone (the kernels' own sine; alpha is not used); mode 4: y = gelu(x), the exact (erf) GELU as the
+ * kernels evaluate it (tconv/__init__.py:13, the transformer's GEGLU; alpha is not used).
  * A test entry (it synchronises and allocates): the pipeline applies snake inside its GEMM / unit kernels. */
 int l3ac_op_snake(const float* x, float* y, int64_t rows, int32_t c, const float* alpha, int32_t mode, void* stream);
 /* Validation switch of ONE context: while enabled its output head (modules.py:192-194) stores the Conv1d(c -> 1, k7) result

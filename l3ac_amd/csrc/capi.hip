@@ -570,7 +570,7 @@ int l3ac_ctx_set_head_pretanh(l3ac_ctx* ctx, int32_t enable) {
 }
 
 int l3ac_op_snake(const float* x, float* y, int64_t rows, int32_t c, const float* alpha, int32_t mode, void* stream) {
-    L3AC_REQUIRE(x && y && alpha && rows >= 0 && c > 0 && c % 4 == 0 && c <= 4096 && mode >= 0 && mode <= 3, "op_snake: bad arguments");
+    L3AC_REQUIRE(x && y && alpha && rows >= 0 && c > 0 && c % 4 == 0 && c <= 4096 && mode >= 0 && mode <= 4, "op_snake: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     float* inv = nullptr;  // 1 / (alpha + 1e-8), evaluated in fp32 as layers.py:32 does
     std::vector<float> ha((size_t)c), hi((size_t)c);

@@ -313,7 +313,7 @@ int launch_rows_t(hipStream_t s, const RowArgs& r, int lpr) {
 
 // ---- elementwise -------------------------------------------------------------------------------
 // mode bit 0: evaluate with the two-elements-per-lane form (snake_act2 / sin_squared2) the GEMM epilogues and the fused
-// units use; bit 1: y = sin(x)^2 alone (alpha unused) instead of snake(x)
+// units use; bit 1: y = sin(x)^2 alone (alpha unused) instead of snake(x); mode 4: y = gelu(x), the kernels' exact-GELU (gelu_erf)
 __global__ __launch_bounds__(THREADS) void snake_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                        int64_t n4, int c4, const float* __restrict__ alpha,
                                                        const float* __restrict__ inv_alpha, const int mode) {
@@ -321,7 +321,9 @@ __global__ __launch_bounds__(THREADS) void snake_kernel(const float* __restrict_
         const int c0 = (int)(i % c4) << 2;
         const float4 v = reinterpret_cast<const float4*>(x)[i];
         float4 o;
-        if (mode & 2) {
+        if (mode == 4) {
+            o = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
+        } else if (mode & 2) {
             if (mode & 1) {
                 const f32x2 lo = sin_squared2(f32x2{v.x, v.y}), hi = sin_squared2(f32x2{v.z, v.w});
                 o = make_float4(lo.x, lo.y, hi.x, hi.y);

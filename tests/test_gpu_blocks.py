@@ -184,6 +184,35 @@ def test_sin_squared_range():
         _close(f"snake mode {mode}", G.snake(x.cuda(), al.cuda(), mode).cpu(), ref, atol=1e-6, rtol=1e-6)
 
 
+def test_gelu_known_answers():
+    """The kernels' exact GELU (device_math.hpp gelu_erf: 0.5 x (1 + erf(x / sqrt 2)) with the branch-free fp32 erf_f32; the encoder
+    stem evaluates 80 per sample, the transformer's GEGLU 341 per token) against fp64 on 2^20 points — a dense sweep of [-8, 8], normal
+    draws of the stem's argument scale, the fits' switch-over point and its one-ulp neighbours, large and tiny arguments — and against
+    torch.nn.functional.gelu in fp32 on the same points.  GELU's 1 + erf cancels for negative arguments, so the bound is on the TERMS:
+    |err| <= 0.5 |x| * 1.2e-7 (erf to 2 ulp of 1) + 1.5 ulp of the result; and the worst error may not exceed twice torch's own fp32 worst."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(77)
+    sw = 0.927734375 * 2 ** 0.5
+    edge = torch.tensor([sw, -sw, 0.0, -0.0, 1e-30, -1e-30, 1e-6, 40.0, -40.0, 1e20, -1e20], dtype=torch.float64).float()
+    edge = torch.cat([edge, torch.nextafter(edge, torch.full_like(edge, 9e9)), torch.nextafter(edge, torch.full_like(edge, -9e9))])
+    n = (1 << 20) - edge.numel()
+    x = torch.cat([torch.linspace(-8, 8, n // 2), torch.randn(n - n // 2, generator=g) * 1.5, edge]).float().reshape(-1, 4).contiguous()
+    alpha = torch.ones(4).cuda()
+    got = G.snake(x.cuda(), alpha, 4).cpu().double()
+    ref = F.gelu(x.double())
+    tor = F.gelu(x).double()
+    ulp = torch.from_numpy(np.spacing(np.abs(ref.float().numpy()))).double()
+    e_got, e_tor = (got - ref).abs(), (tor - ref).abs()
+    print(f"[gelu] kernels: max |err| {float(e_got.max()):.3e} = {float((e_got / (ulp + 1e-38)).max()):.2f} ulp; torch fp32: "
+          f"max |err| {float(e_tor.max()):.3e} = {float((e_tor / (ulp + 1e-38)).max()):.2f} ulp ({x.numel()} points)")
+    assert torch.isfinite(got).all()
+    bound = 0.5 * x.double().abs().clamp(max=10.0) * 1.2e-7 + 1.5 * ulp + 1e-38
+    worst = float((e_got / bound).max())
+    print(f"[gelu] worst err / bound {worst:.3f}")
+    assert (e_got <= bound).all()
+    assert float(e_got.max()) <= 2.0 * float(e_tor.max())
+
+
 def test_first_block(tiny, full):
     for codec, mc, w in (tiny, full):
         x = seeded_audio(2, 1000)
