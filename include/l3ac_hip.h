@@ -262,19 +262,15 @@ int l3ac_gemm_f32(const float* a, int64_t lda, const float* w, const float* bias
 void l3ac_split3_host(const float* x, int64_t n, uint16_t* planes);
 int l3ac_ctx_set_gemm_split(l3ac_ctx* ctx, int32_t enable);
 /* Route options of ONE context by name (same rules as the setters above): "gemm_split", "head_pretanh", and "narrow_ring" — which
- * fused kernel takes the ConvUnits with C <= 96 on the split route: 0 = conv_unit_split_kernel (32 frames per wave) everywhere,
- * 1 (default) = conv_unit_ring_kernel (16 frames per wave, weights through an LDS-DMA ring) at the widths where it is the faster
- * one (C = 48, 96), 2 = wherever it exists (C = 24 too).  Both evaluate the same operations; their results agree to rounding.
- * "ring_geometry" (diagnostics) runs conv_unit_ring_kernel in another geometry with the same results: 0 default, 1 other waves x
- * workgroups, 5 32 frames per wave, 8 fragments read one piece ahead.
+ * fused kernel takes the ConvUnits with C <= 48 on the split route: 0 = conv_unit_split_kernel (32 frames per wave) everywhere,
+ * 1 (default) = conv_unit_ring_kernel (16 frames per wave, weights resident in / streamed through LDS) at the width where it is the
+ * faster one (C = 48), 2 = wherever it exists (C = 24 too).  Both evaluate the same operations; their results agree to rounding.
  * "trans_coop" (default 1): batches of at most 32 clips — a streaming chunk is one — run every LocalTrans stack in the cooperative
  * form of trans_stack_kernel (six co-resident workgroups per clip exchanging partial tiles through global memory); 0 keeps one
  * workgroup per clip.  Both forms return the same bits.  The cooperative form's six workgroups per clip wait for each other: they need
  * six CUs per clip (claimed per context in a process-wide registry; a launch that does not fit runs in the one-workgroup form);
  * failure reporting: l3ac_coop_timeout_count above.  "coop_timeout_ms" (default 250): the time limit of an arrival poll.
  * "coop_test_fault" (test hook, default 0): j + 1 makes workgroup j of every clip withhold its first arrival.
- * "wide_narrow" (default 1): the C = 96 ConvUnits on conv_unit_wide_kernel<96> (hidden tensor in registers, two workgroups per CU);
- * 0 keeps conv_unit_ring_kernel<96>.  The two forms agree to rounding (not bit for bit).
  * "down_fused" (default 0): the encoder down layers 24 -> 48 and 48 -> 96 (Conv1d(k = stride) + ChannelNorm) in one kernel on the
  * bf16x3 route instead of an fp32-MFMA GEMM + row kernel: faster, equally accurate, a different rounding of those layers.
  * Unknown names return L3AC_EINVAL. */

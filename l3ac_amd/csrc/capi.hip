@@ -162,13 +162,7 @@ int l3ac_create(const l3ac_config* cfg, const l3ac_tensor* tensors, int32_t n_te
     ctx->device = device;
     ctx->gemm_split = gemm_split_default();
     {
-        const char* e = std::getenv("L3AC_NARROW_RING");
-        if (e) ctx->narrow_ring = std::atoi(e);
-        e = std::getenv("L3AC_RING_VARIANT");
-        if (e) ctx->ring_geometry = std::atoi(e);
-        e = std::getenv("L3AC_WIDE_NARROW");
-        if (e) ctx->wide_narrow = std::atoi(e) != 0;
-        e = std::getenv("L3AC_DOWN_FUSED");
+        const char* e = std::getenv("L3AC_DOWN_FUSED");
         if (e) ctx->down_fused = std::atoi(e) != 0;
     }
     DeviceGuard guard(device);
@@ -595,14 +589,12 @@ int l3ac_ctx_set_option(l3ac_ctx* ctx, const char* name, int32_t value) {
     if (n == "gemm_split") ctx->gemm_split = value != 0;
     else if (n == "head_pretanh") ctx->head_pretanh = value != 0;
     else if (n == "narrow_ring") ctx->narrow_ring = value < 0 ? 0 : (value > 2 ? 2 : value);
-    else if (n == "ring_geometry") ctx->ring_geometry = value;
     else if (n == "trans_coop") ctx->coop.enabled = value != 0;
     else if (n == "coop_timeout_ms") ctx->coop.timeout_ms = value < 1 ? 1 : (value > 20000 ? 20000 : value);
     else if (n == "coop_test_fault") ctx->coop.fault_part = value - 1;  // 0 = off, j + 1 = workgroup j of every clip withholds its first arrival
-    else if (n == "wide_narrow") ctx->wide_narrow = value != 0;
     else if (n == "down_fused") ctx->down_fused = value != 0;
     else {
-        l3ac_set_error("set_option: unknown option '%s' (gemm_split, head_pretanh, narrow_ring, ring_geometry, trans_coop, coop_timeout_ms, coop_test_fault, wide_narrow, down_fused)", name);
+        l3ac_set_error("set_option: unknown option '%s' (gemm_split, head_pretanh, narrow_ring, trans_coop, coop_timeout_ms, coop_test_fault, down_fused)", name);
         return L3AC_EINVAL;
     }
     return L3AC_OK;

@@ -396,10 +396,10 @@ int launch_fused(hipStream_t s, const ConvUnitW& w, const float* x, float* y, in
 bool conv_unit_fused_supported(int c) { return c == 24 || c == 48 || c == 96; }
 
 // In-place use is NOT allowed: a neighbouring wave's halo rows could already have been overwritten.
-int launch_conv_unit_fused(hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames, bool split, int ring, int ring_geometry) {
+int launch_conv_unit_fused(hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames, bool split, int ring) {
     L3AC_REQUIRE(x != y, "conv_unit_fused: in-place operation is not supported");
     if (split && w.ring_img && (ring == 2 ? conv_unit_ring_supported(w.c) : (ring == 1 && conv_unit_ring_preferred(w.c))))
-        return launch_conv_unit_ring(s, w, x, y, batch, frames, ring_geometry);
+        return launch_conv_unit_ring(s, w, x, y, batch, frames);
     if (split && w.w1_img && w.w2_img) return launch_conv_unit_split(s, w, x, y, batch, frames);
     switch (w.c) {
         case 24: return launch_fused<24, 8, 96, 1>(s, w, x, y, batch, frames, "conv_unit_fused_kernel<24>");

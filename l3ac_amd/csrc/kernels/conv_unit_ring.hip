@@ -32,32 +32,8 @@
 
 namespace {
 
-// Timing-only builds (results wrong; never in the product library): -DL3AC_RING_BOUND=<bits> removes one cost at a time —
-//   1 the matrix products (a 3-instruction stand-in keeps every fragment read alive)   2 snake + GRN   4 the operand split of the hidden pair
-//   8 the depth-wise conv's loads and FMAs   16 the weight stream's LDS-DMA and the slot barriers   32 the fragment reads from LDS
-//   64 the whole tile front (no x read, no conv, no LayerNorm: operand planes from the lane id)   128 the residual read and the store
-#ifndef L3AC_RING_BOUND
-#define L3AC_RING_BOUND 0
-#endif
-#ifdef L3AC_RING_STAMPS  // diagnostic build (tools/ring_stamps.py): s_memtime sums per phase of every wave of workgroup 0 (read the shares)
-__device__ long long g_ring_stamps[16 * 8];
-#define RING_STAMP(slot)                                                       \
-    do {                                                                       \
-        const long long now_ = (long long)__builtin_amdgcn_s_memtime();        \
-        stamp_sum[slot] += now_ - stamp_last;                                  \
-        stamp_last = now_;                                                     \
-    } while (0)
-#else
-#define RING_STAMP(slot) do { } while (0)
-#endif
 __device__ __forceinline__ f32x4_t ring_mfma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4_t acc) {
-    if constexpr ((L3AC_RING_BOUND & 1) != 0) {
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) acc[pl] += __builtin_bit_cast(f32x4_t, a[pl])[pl] * __builtin_bit_cast(f32x4_t, b[pl])[0];
-        return acc;
-    } else {
-        return mfma6(a, b, acc);
-    }
+    return mfma6(a, b, acc);
 }
 
 // WAVES_ waves per workgroup, PER_CU workgroups per CU (register budget 512 / (WAVES_ PER_CU / 4) per lane), SP_ pieces per ring
@@ -105,12 +81,6 @@ __global__ __launch_bounds__(64 * G::WAVES, G::WAVES * G::PER_CU / 4) void conv_
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fl = lane & 15, lg = lane >> 4;
-#ifdef L3AC_RING_STAMPS
-    // slots: 0 tile front (dw-conv + LayerNorm + split)  1 fragment read -> landed  2 the six products (issue + completion)
-    //        3 snake / GRN / split  4 slot barrier  5 LDS-DMA issue  6 residual + store  7 other
-    long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long long stamp_last = (long long)__builtin_amdgcn_s_memtime();
-#endif
 
     // ---- parameters resident for the lifetime of the workgroup (padding channels: zeros) ---------------------------------
     for (int i = tid; i < G::H4; i += 64 * G::WAVES) {
@@ -137,7 +107,7 @@ __global__ __launch_bounds__(64 * G::WAVES, G::WAVES * G::PER_CU / 4) void conv_
     int dma_slot = 0;  // slot of the unit's stream to fetch next, modulo the stream length (wave-uniform)
     int ring_pos_w = 0;
     auto issue = [&]() __attribute__((always_inline)) {
-        if constexpr (!G::RESIDENT && (L3AC_RING_BOUND & 16) == 0) {
+        if constexpr (!G::RESIDENT) {
             if (wave < G::DMA_WAVES) {
                 const unsigned char* src = w.ring_img + (int64_t)dma_slot * G::SLOT + 1024 * wave;
                 const unsigned dst = ring_lds + (unsigned)(ring_pos_w * G::SLOT + 1024 * wave);
@@ -149,7 +119,7 @@ __global__ __launch_bounds__(64 * G::WAVES, G::WAVES * G::PER_CU / 4) void conv_
         }
     };
     auto step_sync = [&]() __attribute__((always_inline)) {
-        if constexpr (!G::RESIDENT && (L3AC_RING_BOUND & 16) == 0) {
+        if constexpr (!G::RESIDENT) {
             asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(G::WAIT) : "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -169,10 +139,7 @@ __global__ __launch_bounds__(64 * G::WAVES, G::WAVES * G::PER_CU / 4) void conv_
     auto load_frag = [&](bf16x8 (&f)[3], const unsigned char* a) __attribute__((always_inline)) {
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
-            if constexpr ((L3AC_RING_BOUND & 32) != 0)
-                f[pl] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)(size_t)a, (unsigned)pl, 3u, 4u});
-            else
-                f[pl] = *reinterpret_cast<const bf16x8*>(a + 1024 * pl);
+            f[pl] = *reinterpret_cast<const bf16x8*>(a + 1024 * pl);
         }
     };
     // PRE: the fragment of the piece about to be consumed, read one piece ahead (carried across hidden pairs and tiles: the stream
@@ -192,20 +159,12 @@ __global__ __launch_bounds__(64 * G::WAVES, G::WAVES * G::PER_CU / 4) void conv_
         const int clip = tile_ok ? tile / tiles_per_clip : 0;
         const int t0 = tile_ok ? (tile - clip * tiles_per_clip) * G::TF : 0;
         const float* const xc = x + (int64_t)clip * frames * C + 4 * lg;  // (32-bit offsets inside a clip: frames * C < 2^31 / 4)
-        RING_STAMP(7);
         bool frame_ok[G::FT];
         bf16x8 ap[G::FT][G::K1][3];
 #pragma unroll
         for (int ft = 0; ft < G::FT; ++ft) {
             const int frame = t0 + 16 * ft + fl;             // this lane's frame (of column tile ft) inside its clip
             frame_ok[ft] = tile_ok && frame < frames;
-            if constexpr ((L3AC_RING_BOUND & 64) != 0) {
-#pragma unroll
-                for (int s = 0; s < G::K1; ++s)
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) ap[ft][s][pl] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)frame, (unsigned)(s + pl), 0x3f803f80u, 0x3c003c00u});
-                continue;
-            }
             // ---- depth-wise conv k7 (zero padding at the clip's ends) + LayerNorm of this lane's frame: channels 16 t + 4 g + i ----
             f32x4_t a[G::CT];
             float s1 = 0.f;
@@ -218,12 +177,12 @@ __global__ __launch_bounds__(64 * G::WAVES, G::WAVES * G::PER_CU / 4) void conv_
                 // every load is unconditional on a clamped address and masked afterwards: a guarded load is a branch and a full
                 // wait each (the first build: 42 branches per tile, the whole front end serialised and 250 registers spilled)
 #pragma unroll
-                for (int tap = 0; tap < ((L3AC_RING_BOUND & 8) != 0 ? 1 : 7); ++tap) {
+                for (int tap = 0; tap < 7; ++tap) {
                     const int frc = min(max(frame + tap - 3, 0), frames - 1);
                     xv[tap] = *reinterpret_cast<const f32x4_t*>(xc + (unsigned)(frc * C + ch_off));
                 }
 #pragma unroll
-                for (int tap = 0; tap < ((L3AC_RING_BOUND & 8) != 0 ? 1 : 7); ++tap) {
+                for (int tap = 0; tap < 7; ++tap) {
                     const int fr = frame + tap - 3;
                     const bool ok = frame_ok[ft] && fr >= 0 && fr < frames;
                     const f32x4_t wv = *reinterpret_cast<const f32x4_t*>(DWs + tap * G::CP + 16 * t + 4 * lg);
@@ -268,10 +227,6 @@ __global__ __launch_bounds__(64 * G::WAVES, G::WAVES * G::PER_CU / 4) void conv_
                 planes_of(v[0], v[1], ap[ft][s]);
             }
         }
-#ifdef L3AC_RING_STAMPS
-        asm volatile("" : "+v"(ap[0][0][0]), "+v"(ap[G::FT - 1][G::K1 - 1][2]));
-#endif
-        RING_STAMP(0);
         // ---- output accumulators start at the pw_conv2 bias ------------------------------------------------------------------
         f32x4_t yacc[G::FT][G::RT];
 #pragma unroll
@@ -298,10 +253,6 @@ __global__ __launch_bounds__(64 * G::WAVES, G::WAVES * G::PER_CU / 4) void conv_
                 if constexpr (q < 2 * G::K1) {
 #pragma unroll
                     for (int ft = 0; ft < G::FT; ++ft) hx[ft][q / G::K1] = ring_mfma6(fr, ap[ft][q % G::K1], hx[ft][q / G::K1]);
-#ifdef L3AC_RING_STAMPS
-                    (void)__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, hx[G::FT - 1][q / G::K1][0]));  // the products have completed
-                    RING_STAMP(2);
-#endif
                     if constexpr (q == 2 * G::K1 - 1) {
                         // snake + GRN (normaliser 1) on the accumulator registers (layers.py:29-33, :112-115), then the planes
 #pragma unroll
@@ -316,34 +267,17 @@ __global__ __launch_bounds__(64 * G::WAVES, G::WAVES * G::PER_CU / 4) void conv_
                                 const f32x4_t be = *reinterpret_cast<const f32x4_t*>(pp + 3 * G::H4);
 #pragma unroll
                                 for (int i = 0; i < 4; ++i) {
-                                    if constexpr ((L3AC_RING_BOUND & 2) != 0) {
-                                        o[u][i] = hx[ft][u][i] + al[i] + ia[i] + ga[i] + be[i];
-                                    } else {
-                                        const float sv = snake_act(hx[ft][u][i], al[i], ia[i]);
-                                        o[u][i] = fmaf(ga[i], sv, be[i]) + sv;
-                                    }
+                                    const float sv = snake_act(hx[ft][u][i], al[i], ia[i]);
+                                    o[u][i] = fmaf(ga[i], sv, be[i]) + sv;
                                 }
                             }
-                            if constexpr ((L3AC_RING_BOUND & 4) != 0) {
-#pragma unroll
-                                for (int pl = 0; pl < 3; ++pl) hb[ft][pl] = __builtin_bit_cast(bf16x8, pl == 2 ? o[0] + o[1] : o[pl]);
-                            } else {
-                                planes_of(o[0], o[1], hb[ft]);
-                            }
+                            planes_of(o[0], o[1], hb[ft]);
                         }
-#ifdef L3AC_RING_STAMPS
-                        asm volatile("" : "+v"(hb[0][0]), "+v"(hb[G::FT - 1][2]));
-                        RING_STAMP(3);
-#endif
                     }
                 } else {
                     constexpr int rt = q - 2 * G::K1;
 #pragma unroll
                     for (int ft = 0; ft < G::FT; ++ft) yacc[ft][rt] = ring_mfma6(fr, hb[ft], yacc[ft][rt]);
-#ifdef L3AC_RING_STAMPS
-                    (void)__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, yacc[G::FT - 1][rt][0]));
-                    RING_STAMP(2);
-#endif
                 }
             };
             ring_static_for<G::PP>([&](auto q_) {
@@ -372,40 +306,23 @@ __global__ __launch_bounds__(64 * G::WAVES, G::WAVES * G::PER_CU / 4) void conv_
                     for (int pl = 0; pl < 3; ++pl) fcur[pl] = fnext[pl];
                 } else {
                     if constexpr (q % G::SP == 0) {  // a slot step begins: refill the slot consumed one step ago
-                        RING_STAMP(7);
                         issue();
-                        RING_STAMP(5);
                         slot_a = ring_lane + (G::RESIDENT ? hp : ring_pos_r) * G::SLOT;
                     }
-                    RING_STAMP(7);
                     load_frag(f, slot_a + (q % G::SP) * 3072);
-#ifdef L3AC_RING_STAMPS
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]));
-                    RING_STAMP(1);
-#endif
                     products(q_, f);
                     if constexpr ((q + 1) % G::SP == 0) {
                         ring_pos_r = ring_pos_r + 1 == G::RSLOTS ? 0 : ring_pos_r + 1;
-                        RING_STAMP(7);
                         step_sync();
-                        RING_STAMP(4);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);  // one fragment live at a time (left alone the scheduler front-loads a slot's reads: 250 spills)
             });
         }
-        RING_STAMP(7);
         // ---- residual + store --------------------------------------------------------------------------------------------------
 #pragma unroll
         for (int ft = 0; ft < G::FT; ++ft) {
             const int frame = t0 + 16 * ft + fl;
-            if constexpr ((L3AC_RING_BOUND & 128) != 0) {
-                float keep = 0.f;
-#pragma unroll
-                for (int rt = 0; rt < G::RT; ++rt) keep += yacc[ft][rt][0] + yacc[ft][rt][1] + yacc[ft][rt][2] + yacc[ft][rt][3];
-                if (keep == 12345.678f) y[frame] = keep;
-                continue;
-            }
             if (frame_ok[ft]) {
                 const float* xrow = xc + (int64_t)frame * C;
                 float* yrow = y + ((int64_t)clip * frames + frame) * C + 4 * lg;
@@ -418,15 +335,8 @@ __global__ __launch_bounds__(64 * G::WAVES, G::WAVES * G::PER_CU / 4) void conv_
                 }
             }
         }
-        RING_STAMP(6);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // leave no LDS-DMA in flight behind the workgroup
-#ifdef L3AC_RING_STAMPS
-    if (blockIdx.x == 0 && lane == 0) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) g_ring_stamps[8 * wave + i] += stamp_sum[i];
-    }
-#endif
 }
 
 template <class G, int C>
@@ -451,64 +361,38 @@ int launch_ring(hipStream_t s, const ConvUnitW& w, const float* x, float* y, int
 
 }  // namespace
 
-#ifdef L3AC_RING_STAMPS
-extern "C" int l3ac_debug_ring_stamps(long long* out, int n, int reset) {  // diagnostic builds only (not part of the ABI)
-    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ring_stamps), (size_t)n * sizeof(long long));
-    if (reset) {
-        long long zero[16 * 8] = {};
-        rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ring_stamps), zero, sizeof(zero));
-    }
-    return rc;
-}
-#endif
 
-bool conv_unit_ring_supported(int c) { return c == 24 || c == 48 || c == 96; }
-// the widths the pipeline routes to this kernel by default (C = 24 stays on conv_unit_split_kernel, which is faster there — see the
-// table in launch_conv_unit_ring); the context option "narrow_ring" = 2 routes every supported width here (tests)
-bool conv_unit_ring_preferred(int c) { return c == 48 || c == 96; }
+bool conv_unit_ring_supported(int c) { return c == 24 || c == 48; }
+// the width the pipeline routes to this kernel by default (C = 24 stays on conv_unit_split_kernel, which is faster there — see the
+// table in launch_conv_unit_ring; C = 96, rounds 2-3, runs on conv_unit_wide_kernel<96> since round 4 and its ring form was retired in
+// round 5); the context option "narrow_ring" = 2 routes every supported width here (tests)
+bool conv_unit_ring_preferred(int c) { return c == 48; }
 
 // x must not alias y (neighbouring tiles read each other's halo frames)
-int launch_conv_unit_ring(hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames, int variant) {
+int launch_conv_unit_ring(hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames) {
     L3AC_REQUIRE(x != y && w.ring_img && batch > 0 && frames > 0, "conv_unit_ring: bad arguments");
-    // variant (context option "ring_geometry", diagnostics and tests): another geometry of the same kernel, same results —
-    // 1 other waves x workgroups, 5 32 frames per wave (FT = 2), 8 fragments read one piece ahead (PRE); anything else: the default
     // Geometries measured on the 256-clip step (profiles/r03/README.md; ms for the stage's launches, conv_unit_split_kernel beside):
-    //   C = 96 (3 launches)  split 1.72 | ring 8 waves x 2 workgroups, slots of 4 / 6 pieces: 1.55 / 1.50-1.54 | 16 x 1: 1.67-1.76 | 4 x 4: 1.48
-    //                        | 32 frames per wave (FT = 2), 4 x 2: 1.53-1.57, 8 x 1: 1.73-1.81 | read-ahead (PRE), 6 x 2: 1.97, FT = 2 4 x 2: 1.47
-    //   C = 48 (2 launches)  split 0.89 | resident 16 x 1: 0.83-0.85, 12 x 1: 0.88 | ring 8 x 2: 0.93 | FT = 2, 8 / 12 x 1: 0.94 / 0.90
-    //                        | PRE 16 x 1: 0.84, 12 x 1: 0.87
-    //   C = 24 (1 launch)    split 0.46-0.48 | resident 12 x 1: 0.57-0.59, 6 x 2: 0.79-0.81 | FT = 2, 16 x 1: 0.55 | PRE 16 x 1: 0.54: not routed here
+    //   C = 48 (2 launches)  split 0.89 | resident 16 x 1: 0.83-0.85, 12 x 1: 0.88 | ring 8 x 2: 0.93 | 32 frames per wave, 8 / 12 x 1: 0.94 / 0.90
+    //                        | fragments read one piece ahead 16 x 1: 0.84, 12 x 1: 0.87
+    //   C = 24 (1 launch)    split 0.46-0.48 | resident 12 x 1: 0.57-0.59, 6 x 2: 0.79-0.81 | 32 frames per wave 16 x 1: 0.55: not routed here
     // Neither 32 frames per wave (half the fragment reads per frame) nor reading one fragment ahead moves the time: the kernel is
-    // not bound by the LDS reads.  What bounds it, from timing-only builds (L3AC_RING_BOUND above, C = 96, 1.50 ms): without the
-    // products 1.04; without snake / GRN / split / conv taps 0.99; with neither 0.70; also without the weight stream and its barriers
-    // 0.53, also without the fragment reads 0.37 (one read of x, LayerNorm, one write of y).  The parts add up to 1.78: little of
-    // the vector work (VALU active 0.46 of the cycles at C = 96, 0.74 at C = 48) hides under the products (matrix pipe 0.38 / 0.37),
-    // and at C <= 48 the vector work — 20 instructions of activation and 5.5 of operand split per hidden element — is the larger
-    // of the two: these widths are bound by vector issue, not by the matrix pipe.
+    // not bound by the LDS reads.  What bounds it, from round 3's timing-only builds at C = 96 (1.50 ms): without the products 1.04;
+    // without snake / GRN / split / conv taps 0.99; with neither 0.70; also without the weight stream and its barriers 0.53, also without
+    // the fragment reads 0.37 (one read of x, LayerNorm, one write of y).  The parts add up to 1.78: little of the vector work (VALU
+    // active 0.74 of the cycles at C = 48) hides under the products (matrix pipe 0.37), and at C <= 48 the vector work — 20
+    // instructions of activation and 5.5 of operand split per hidden element — is the larger of the two: these widths are bound by
+    // vector issue, not by the matrix pipe.
     // Small grids (a single clip: the streaming chunk): at most one wave per SIMD of the chip — workgroups of FOUR waves, one per CU,
-    // so that every wave has its SIMD to itself (at 8 x 2 or 16 x 1 the few workgroups of a clip stack their waves four deep on a
-    // dozen CUs while the rest of the chip idles: C = 96, 2 700 frames: 42 us).  Variant 9 forces it (tests: same bits).
+    // so that every wave has its SIMD to itself (at 16 x 1 the few workgroups of a clip stack their waves four deep on a dozen CUs
+    // while the rest of the chip idles).  Per frame the same operations in the same order: the same bits (tested: a clip alone
+    // against the same clip inside a large batch).
     const int64_t tiles16 = (int64_t)batch * ((frames + 15) / 16);
-    if (variant == 9 || (variant == 0 && tiles16 <= 4LL * l3ac_device_cu_count())) {
-        if (w.c == 96) return launch_ring<RGeo<96, 4, 3, 3, 4, false>, 96>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<96>");
-        if (w.c == 48) return launch_ring<RGeo<48, 4, 1, 0, 0, true>, 48>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<48>");
-    }
+    if (w.c == 48 && tiles16 <= 4LL * l3ac_device_cu_count())
+        return launch_ring<RGeo<48, 4, 1, 0, 0, true>, 48>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<48>");
     switch (w.c) {
-        case 24:
-            if (variant == 1) return launch_ring<RGeo<24, 6, 2, 0, 0, true>, 24>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<24>");
-            if (variant == 5) return launch_ring<RGeo<24, 16, 1, 0, 0, true, 2>, 24>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<24>");
-            if (variant == 8) return launch_ring<RGeo<24, 16, 1, 0, 0, true, 1, true>, 24>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<24>");
-            return launch_ring<RGeo<24, 12, 1, 0, 0, true>, 24>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<24>");
+        case 24: return launch_ring<RGeo<24, 12, 1, 0, 0, true>, 24>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<24>");
         case 48:  // 126 KB stream: resident, one workgroup of 16 waves per CU, no barrier after the prologue
-            if (variant == 1) return launch_ring<RGeo<48, 8, 2, 7, 3, false>, 48>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<48>");
-            if (variant == 5) return launch_ring<RGeo<48, 12, 1, 0, 0, true, 2>, 48>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<48>");
-            if (variant == 8) return launch_ring<RGeo<48, 16, 1, 0, 0, true, 1, true>, 48>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<48>");
             return launch_ring<RGeo<48, 16, 1, 0, 0, true>, 48>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<48>");
-        case 96:  // 432 KB stream: ring of 3 slots of 6 pieces, two workgroups of 8 waves per CU
-            if (variant == 1) return launch_ring<RGeo<96, 4, 3, 3, 4, false>, 96>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<96>");
-            if (variant == 5) return launch_ring<RGeo<96, 4, 2, 6, 3, false, 2>, 96>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<96>");
-            if (variant == 8) return launch_ring<RGeo<96, 4, 2, 6, 3, false, 2, true>, 96>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<96>");
-            return launch_ring<RGeo<96, 8, 2, 6, 3, false>, 96>(s, w, x, y, batch, frames, "conv_unit_ring_kernel<96>");
         default:
             l3ac_set_error("conv_unit_ring: C=%d not supported", w.c);
             return L3AC_EINVAL;

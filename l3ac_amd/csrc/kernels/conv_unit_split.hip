@@ -1,4 +1,4 @@
-// Fused ConvUnit (C = 24 / 48 / 96) with both channel contractions on the bf16 matrix cores at fp32 accuracy
+// Fused ConvUnit (C = 24 / 48; C = 96 until round 4: conv_unit_wide_kernel<96> took that width over) with both channel contractions on the bf16 matrix cores at fp32 accuracy
 // ("bf16x3", split_bf16.hpp); reference l3ac/modules.py:10-41 + Residual (l3ac/xtract/nn/layers.py:59-62):
 //
 //     y = x + pw_conv2( GRN( snake( pw_conv1( LayerNorm( dw_conv7(x) ) ) ) ) )
@@ -390,7 +390,6 @@ int launch_conv_unit_split(hipStream_t s, const ConvUnitW& w, const float* x, fl
     switch (w.c) {
         case 24: return launch_split<24, 8, 96, 1>(s, w, x, y, batch, frames, "conv_unit_split_kernel<24>");
         case 48: return launch_split<48, 8, 64, 1>(s, w, x, y, batch, frames, "conv_unit_split_kernel<48>");
-        case 96: return launch_split<96, 8, 32, 2>(s, w, x, y, batch, frames, "conv_unit_split_kernel<96>");
         default:
             l3ac_set_error("conv_unit_split: C=%d not supported", w.c);
             return L3AC_EINVAL;

@@ -36,6 +36,8 @@
 #include "device_math.hpp"
 #include "ring_common.hpp"
 #include "split_bf16.hpp"
+#define L3AC_DIAG_UNIT_CONV_UNIT_WIDE
+#include "diag.hpp"
 
 #include <vector>
 
@@ -87,16 +89,6 @@ struct WGeo {
     static_assert(LDS <= 160 * 1024, "LDS budget exceeded");
 };
 
-#ifdef L3AC_WIDE_STAMPS  // diagnostic build (tools/wide_stamps.py): s_memtime at the phase boundaries of every pass of wave 0
-__device__ unsigned long long g_wide_stamps[512 * 16 * 8];
-#define WIDE_STAMP(slot)                                                                                      \
-    do {                                                                                                      \
-        if (lane == 0 && wave == 0 && pass_no < 16)                                                           \
-            g_wide_stamps[((size_t)blockIdx.x * 16 + pass_no) * 8 + (slot)] = __builtin_amdgcn_s_memtime();   \
-    } while (0)
-#else
-#define WIDE_STAMP(slot) do { } while (0)
-#endif
 
 __device__ __forceinline__ int rowmap(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 
@@ -329,9 +321,6 @@ __device__ __forceinline__ void wide_front(const ConvUnitW& w, const float* __re
                         const float wv[7] = {wt[0][h][e], wt[1][h][e], wt[2][h][e], wt[3][h][e], wt[4][h][e], wt[5][h][e], wt[6][h][e]};
                         cv[fh][b][4 * h + e] = dw_taps_dpp(bs[h][e], grp[fh + 1][h][e], grp[fh][h][e], grp[fh + 2][h][e], wv);
                     }
-#ifdef L3AC_FRONT_SB
-            __builtin_amdgcn_sched_barrier(0);
-#endif
         }
     } else {
 #pragma unroll
@@ -403,16 +392,11 @@ __device__ __forceinline__ void wide_front(const ConvUnitW& w, const float* __re
 // of MFMAs on its one SIMD however fast the weights arrive.  With 16 frames per wave there are twice the waves, every weight piece
 // meets one column group instead of two, and the activation has only its "frame half 0" stream (beside the second product of the
 // previous hidden tile).  Per element the same products in the same order: the same bits as FH = 2 (tested).
-// L3AC_WIDE_NT: non-temporal policy on the main kernel's STREAMED data — bit 0 the operand planes, bit 1 the residual rows, bit 2 the
+// Non-temporal policy on the main kernel's STREAMED data — the operand planes, the residual rows, the
 // output rows — so that they do not evict the weight image from L2 (PMC: the C = 256 unit fetched 1.96 x its algorithmic bytes, the
 // excess being ~250 re-fetches of the 3.1 MB image per launch).  Measured (profiles/r04/wide_nt.md, two interleaved rounds on one
 // box): all three on, the three C = 256 units 3.16-3.21 -> 3.06-3.07 ms, the next unit's front end 0.47 -> 0.44, the step - 1.7 %.
-#ifndef L3AC_WIDE_NT
-#define L3AC_WIDE_NT 7
-#endif
-#ifndef L3AC_WIDE_HALF_NT
-#define L3AC_WIDE_HALF_NT 0  // 1: the half-tile form's weight copies non-temporal — measured: no gain (86 vs 83 us at C = 256, 51 vs 52 at C = 192)
-#endif
+// (The half-tile form's weight copies with the non-temporal policy: measured, no gain — 86 vs 83 us at C = 256, 51 vs 52 at C = 192.)
 // tail_tiles (FHK = 2 only): the LAST tail_tiles 32-frame tiles are left out of the lock-step passes and run afterwards as half tiles on
 // the first workgroups — 256 x 900 frames at C = 256 are 7 full passes + 32 tiles, and an eighth pass for 0.4 % of the tiles cost 12 %
 // of the unit; as 64 half tiles on 16 workgroups it costs half a pass.
@@ -450,19 +434,15 @@ __global__ __launch_bounds__(256, WGeo<C>::WG_PER_CU) void conv_unit_wide_kernel
     const unsigned lane_off = 16u * (unsigned)lane;
     int dma_slot = 0;  // next slot of the stream to fetch (wave-uniform)
     auto issue = [&](int ring_pos) __attribute__((always_inline)) {
-#ifndef L3AC_WIDE_NODMA  // (timing experiments only)
         if (G::COPY_WAVES == 4 || wave < G::COPY_WAVES)  // (a wave without copies meets the same counted waits with nothing outstanding)
-            dma_slot_quarter<G::DMA_N, (FHK == 1) && L3AC_WIDE_HALF_NT>(src_wave + (int64_t)dma_slot * G::SLOT, lane_off, ring_lds + (unsigned)(ring_pos * G::SLOT) + (unsigned)(G::DMA_N * 1024) * (unsigned)wave);
-#endif
+            dma_slot_quarter<G::DMA_N>(src_wave + (int64_t)dma_slot * G::SLOT, lane_off, ring_lds + (unsigned)(ring_pos * G::SLOT) + (unsigned)(G::DMA_N * 1024) * (unsigned)wave);
         dma_slot = dma_slot + 1 == G::TOTAL ? 0 : dma_slot + 1;
     };
     // end of a step: this wave's pieces of the slot after next have landed, then everybody's have, and everybody is done
     // reading the slot that the next step's DMA overwrites
     auto step_sync = [&]() __attribute__((always_inline)) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::WAIT) : "memory");
-#ifndef L3AC_WIDE_NOBAR  // (timing experiments only: results are wrong without the barrier)
         __builtin_amdgcn_s_barrier();
-#endif
         asm volatile("" ::: "memory");
     };
 #pragma unroll
@@ -484,7 +464,6 @@ __global__ __launch_bounds__(256, WGeo<C>::WG_PER_CU) void conv_unit_wide_kernel
     const int64_t tiles32 = (rows + 31) / 32;
     const int64_t n_tiles = FHK == 2 ? tiles32 - tail_tiles : 2 * tiles32;  // units of the lock-step passes: 32-frame tiles, or 16-frame halves
     const int64_t tile_stride = (int64_t)gridDim.x * 4;
-#ifndef L3AC_WIDE_NO_STAGGER
     // Passes run in lock step across the chip, so every workgroup would fetch its operand planes and store its tile at the
     // same moment: HBM idles through the loops and saturates in between (the store phase measured 24 k cycles = 10.7 B / clk /
     // CU).  Workgroups that run one pass fewer than the busiest ones (at 256 x 900 frames: all but 8) have a whole pass of
@@ -503,7 +482,6 @@ __global__ __launch_bounds__(256, WGeo<C>::WG_PER_CU) void conv_unit_wide_kernel
         const long long t0 = (long long)__builtin_amdgcn_s_memtime();
         while ((long long)__builtin_amdgcn_s_memtime() - t0 < delay) __builtin_amdgcn_s_sleep(16);
     }
-#endif
     // every wave of the block runs the same number of passes (block barriers inside)
     int pass_no = 0;
     (void)pass_no;
@@ -530,7 +508,7 @@ __global__ __launch_bounds__(256, WGeo<C>::WG_PER_CU) void conv_unit_wide_kernel
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) {
                     const bf16x8* q = reinterpret_cast<const bf16x8*>(src + ((FH == 1 ? 2 * s : s) * 3 + pl) * 1024);
-                    ap[s][pl] = (L3AC_WIDE_NT & 1) ? __builtin_nontemporal_load(q) : *q;
+                    ap[s][pl] = __builtin_nontemporal_load(q);
                 }
         }
 
@@ -636,22 +614,16 @@ __global__ __launch_bounds__(256, WGeo<C>::WG_PER_CU) void conv_unit_wide_kernel
                 }
                 if constexpr (g == 0) issue(issue_pos);
                 if constexpr (ACT >= 0) act_gap(std::integral_constant<int, GPP * G::KS * I + g>{}, std::integral_constant<int, ACT>{}, xa, tab);
-#ifndef L3AC_WIDE_WALL_EVERY
-#define L3AC_WIDE_WALL_EVERY 3  // a wall after every gap (or every second) sends hipcc's register allocation over the edge at C = 256
-#endif
-                if constexpr (g % L3AC_WIDE_WALL_EVERY == L3AC_WIDE_WALL_EVERY - 1) {
-#ifndef L3AC_WIDE_SGB
-#define L3AC_WIDE_SGB 2
-#endif
-#if L3AC_WIDE_SGB > 0
-                    // inside a window: one MFMA, then at most L3AC_WIDE_SGB fillers — a 16-cycle MFMA holds the issue port for 8, so a
-                    // gap costs max(16, 8 + 4 fillers) cycles: two per gap are free, the third and fourth cost 4 cycles each
-                    // (measured: the loop's cycles follow that sum over the gaps of the compiled stream)
-                    static_for<L3AC_WIDE_WALL_EVERY>([&](auto) {
+                // a wall (sched_barrier) closes every window of WALL gaps (after every gap, or every second, hipcc's register allocation
+                // goes over the edge at C = 256); inside a window: one MFMA, then at most two fillers — a 16-cycle MFMA holds the issue
+                // port for 8, so a gap costs max(16, 8 + 4 fillers) cycles: two per gap are free, the third and fourth cost 4 cycles each
+                // (measured: the loop's cycles follow that sum over the gaps of the compiled stream)
+                constexpr int WALL = 3;
+                if constexpr (g % WALL == WALL - 1) {
+                    static_for<WALL>([&](auto) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x106, L3AC_WIDE_SGB, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x106, 2, 0);
                     });
-#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
             });
@@ -726,7 +698,7 @@ __global__ __launch_bounds__(256, WGeo<C>::WG_PER_CU) void conv_unit_wide_kernel
                 {
                     typedef float f4nt __attribute__((ext_vector_type(4)));
                     const f4nt* q = reinterpret_cast<const f4nt*>(x + (ok ? rr : 0) * C + 32 * ct + 4 * es);
-                    const f4nt v = (L3AC_WIDE_NT & 2) ? __builtin_nontemporal_load(q) : *q;
+                    const f4nt v = __builtin_nontemporal_load(q);
                     xres[ct][i] = make_float4(v.x, v.y, v.z, v.w);
                 }
             }
@@ -778,8 +750,7 @@ __global__ __launch_bounds__(256, WGeo<C>::WG_PER_CU) void conv_unit_wide_kernel
                     if (tile_ok && rr < rows) {
                         typedef float f4nt __attribute__((ext_vector_type(4)));
                         const f4nt o = {xres[ct][i].x + v.x, xres[ct][i].y + v.y, xres[ct][i].z + v.z, xres[ct][i].w + v.w};
-                        if (L3AC_WIDE_NT & 4) __builtin_nontemporal_store(o, reinterpret_cast<f4nt*>(y + rr * C + 32 * ct + 4 * es));
-                        else *reinterpret_cast<f4nt*>(y + rr * C + 32 * ct + 4 * es) = o;
+                        __builtin_nontemporal_store(o, reinterpret_cast<f4nt*>(y + rr * C + 32 * ct + 4 * es));
                     }
                 }
             }
@@ -901,12 +872,8 @@ int launch_wide(hipStream_t s, const ConvUnitW& w, const float* x, float* y, uns
     }
     const int64_t tiles = ceil_div64(rows, 32);
     int64_t blocks = ceil_div64(tiles, 4);
-    static const int half_mode = [] {  // L3AC_WIDE_HALF: 0 = 32-frame tiles only, 1 = half tiles for small grids, 2 (default) = also for
-        const char* e = std::getenv("L3AC_WIDE_HALF");  // the last, mostly empty pass of a large grid (A/B runs; same bits)
-        return e ? std::atoi(e) : 2;
-    }();
     const int cus = l3ac_device_cu_count();
-    const bool half = half_mode >= 1 && 2 * blocks <= (int64_t)cus * G::WG_PER_CU;  // half tiles while twice the workgroups still fit one pass
+    const bool half = 2 * blocks <= (int64_t)cus * G::WG_PER_CU;  // half tiles while twice the workgroups still fit one pass
     ProfScope prof(s, name, (double)rows * (16.0 * C * C + (G::FRONT ? 30.0 * C : 0.0)), (double)rows * (G::FRONT ? 8.0 : 14.0) * C);
     if (half) {
         blocks = ceil_div64(2 * tiles, 4);
@@ -917,7 +884,7 @@ int launch_wide(hipStream_t s, const ConvUnitW& w, const float* x, float* y, uns
         // by the first workgroups, inside the same launch (conv_unit_wide_kernel, tail_tiles).
         const int64_t per_pass = 4LL * 256 * G::WG_PER_CU;
         const int64_t full = tiles / per_pass * per_pass, rest = tiles - full;
-        const int64_t tail = (half_mode >= 2 && full > 0 && 2 * rest <= per_pass) ? rest : 0;
+        const int64_t tail = (full > 0 && 2 * rest <= per_pass) ? rest : 0;
         if (blocks > 256 * G::WG_PER_CU) blocks = 256 * G::WG_PER_CU;
         hipLaunchKernelGGL((conv_unit_wide_kernel<C, 2>), dim3((unsigned)blocks), dim3(256), G::LDS, s, w, planes, x, y, rows, tail, frames);
     }
@@ -927,11 +894,6 @@ int launch_wide(hipStream_t s, const ConvUnitW& w, const float* x, float* y, uns
 
 }  // namespace
 
-#ifdef L3AC_WIDE_STAMPS
-extern "C" int l3ac_debug_wide_stamps(unsigned long long* out, int n) {  // diagnostic builds only (not part of the ABI)
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wide_stamps), (size_t)n * sizeof(unsigned long long));
-}
-#endif
 
 bool conv_unit_wide_supported(int c) { return c == 96 || c == 128 || c == 192 || c == 256; }
 // scratch the pair of kernels needs: the split LayerNorm output of `rows` frames (whole 32-frame tiles), 6 bytes per element

@@ -72,43 +72,19 @@ __device__ __forceinline__ void nt_store4(float* p, const float4& v) {
 // across the token loop (158 registers, 3 blocks per CU).  A variant that re-read them from LDS at 64-96 registers and 4 / 6 / 8
 // blocks per CU was SLOWER: removed.  What paid: one resident round, the level indices as ONE contiguous store per wave, and
 // (round 4, profiles/r04/fsq_notes.md) the ORDER in which the chip walks the tokens + non-temporal accesses: 4.97 -> 5.46 TB/s.
-// Access order and cache policy of the streamed rows (round 4, tools/probes/fsq_pattern_probe.hip: the quantiser's traffic with no
-// arithmetic, by how tokens are dealt to blocks / waves / lanes).  Build-time switches so that variants can be timed side by side
-// as tagged builds (L3AC_BUILD_TAG + L3AC_EXTRA_HIPCC_FLAGS); the defaults are what the library ships.
-//   L3AC_FSQ_ORDER 0: every block walks one contiguous token range; 1: grid-stride (block b takes groups b, b + G, ...: the chip
-//                  sweeps one compact window of memory at a time); 3: grid-stride inside each XCD's own eighth of the tokens
-//   L3AC_FSQ_NT    bit 0: non-temporal loads of x, bit 1: non-temporal stores of q_feature, bit 2: of indices / level indices
-#ifndef L3AC_FSQ_ORDER
-#define L3AC_FSQ_ORDER 1
-#endif
-#ifndef L3AC_FSQ_NT
-#define L3AC_FSQ_NT 7
-#endif
+// Access order and cache policy of the streamed rows (round 4, tools/probes/fsq_pattern_probe.hip + profiles/r04/fsq_notes.md: the
+// quantiser's traffic with no arithmetic, by how tokens are dealt to blocks / waves / lanes): tokens are walked GRID-STRIDE (block b
+// takes groups b, b + G, ...: the chip sweeps one compact window of memory at a time; one contiguous range per block was 3 % slower,
+// grid-stride inside each XCD's own eighth no better), and every streamed access — x, q_feature, indices, level indices — is
+// non-temporal (+ 5 %).
 template <typename T>
-__device__ __forceinline__ void side_store(T* p, T v) {
-    if (L3AC_FSQ_NT & 4) __builtin_nontemporal_store(v, p);
-    else *p = v;
-}
+__device__ __forceinline__ void side_store(T* p, T v) { __builtin_nontemporal_store(v, p); }
 // the it-th token group of block `b` of `G` (n_groups = none left)
 __device__ __forceinline__ int64_t fsq_group_at(int64_t it, int64_t b, int64_t G, int64_t n_groups) {
-    if (L3AC_FSQ_ORDER == 0) {
-        const int64_t per_block = (n_groups + G - 1) / G;
-        return it < per_block && b * per_block + it < n_groups ? b * per_block + it : n_groups;
-    }
-    if (L3AC_FSQ_ORDER == 3 && (G & 7) == 0 && n_groups >= 8 * G) {
-        const int64_t span = (n_groups + 7) / 8, j = it * (G >> 3) + (b >> 3), g = (b & 7) * span + j;
-        return j < span && g < n_groups ? g : n_groups;
-    }
     const int64_t g = it * G + b;
     return g < n_groups ? g : n_groups;
 }
 
-#ifndef L3AC_FSQ_DPP_BCAST
-#define L3AC_FSQ_DPP_BCAST 1  // A/B builds: 0 = level indices exchanged by __shfl (ds_bpermute)
-#endif
-#ifndef L3AC_FSQ_DPP_SUM
-#define L3AC_FSQ_DPP_SUM 1  // A/B builds: 0 = the latents' lane sums by __shfl_xor butterflies
-#endif
 template <int D, int NV>
 __global__ __launch_bounds__(THREADS) void fsq_kernel(const FsqDev p, const int lpt) {
     const int feat = p.feat;
@@ -147,7 +123,7 @@ __global__ __launch_bounds__(THREADS) void fsq_kernel(const FsqDev p, const int 
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const float* src = p.x + t * feat + cq + cstep * v;
-                x_next[v] = (L3AC_FSQ_NT & 1) ? nt_load4(src) : *reinterpret_cast<const float4*>(src);
+                x_next[v] = nt_load4(src);
             }
         }
     };
@@ -189,11 +165,7 @@ __global__ __launch_bounds__(THREADS) void fsq_kernel(const FsqDev p, const int 
                         s = fmaf(xv[v].x, wv.x, s); s = fmaf(xv[v].y, wv.y, s);
                         s = fmaf(xv[v].z, wv.z, s); s = fmaf(xv[v].w, wv.w, s);
                     }
-#if L3AC_FSQ_DPP_SUM
                     s = lanes_sum(s, lpt);  // (DPP adds instead of log2(lpt) ds_bpermute round trips per latent: lane_sums.hpp)
-#else
-                    for (int mask = lpt >> 1; mask > 0; mask >>= 1) s += __shfl_xor(s, mask, 64);
-#endif
                     lat[d] = s + (p.b_in ? p.b_in[d] : 0.f);
                 }
             } else {
@@ -212,7 +184,6 @@ __global__ __launch_bounds__(THREADS) void fsq_kernel(const FsqDev p, const int 
                 const int group_base = lane - sub;
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
-#if L3AC_FSQ_DPP_BCAST
                     if (lpt == 8) {  // lane d of the token's eight: row_newbcast of lane d / 8 + d of the 16-lane row, chosen by the lane's half
 #define L3AC_BC(n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, li_mine), 0x150 + (n), 0xf, 0xf, false))
                         float lo, hi;
@@ -230,7 +201,6 @@ __global__ __launch_bounds__(THREADS) void fsq_kernel(const FsqDev p, const int 
                         li[d] = (lane & 8) ? hi : lo;
                         continue;
                     }
-#endif
                     li[d] = __shfl(li_mine, group_base + d, 64);
                 }
             } else {
@@ -258,8 +228,7 @@ __global__ __launch_bounds__(THREADS) void fsq_kernel(const FsqDev p, const int 
             float* dst = p.q_feature + tok * feat + cq;
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
-                if (L3AC_FSQ_NT & 2) nt_store4(dst + cstep * v, o[v]);
-                else *reinterpret_cast<float4*>(dst + cstep * v) = o[v];
+                nt_store4(dst + cstep * v, o[v]);
             }
             if (sub == 0 && p.indices) side_store(p.indices + tok, (int32_t)idx_f);
             if (p.level_indices) {
@@ -293,7 +262,7 @@ __global__ __launch_bounds__(THREADS) void fsq_copy_ceiling_kernel(const float* 
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const float* src = x + t * FEAT + cq + cstep * v;
-                nxt[v] = (L3AC_FSQ_NT & 1) ? nt_load4(src) : *reinterpret_cast<const float4*>(src);
+                nxt[v] = nt_load4(src);
             }
         }
     };
@@ -309,8 +278,7 @@ __global__ __launch_bounds__(THREADS) void fsq_copy_ceiling_kernel(const float* 
         if (tok < n) {
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
-                if (L3AC_FSQ_NT & 2) nt_store4(q + tok * FEAT + cq + cstep * v, cur[v]);
-                else *reinterpret_cast<float4*>(q + tok * FEAT + cq + cstep * v) = cur[v];
+                nt_store4(q + tok * FEAT + cq + cstep * v, cur[v]);
             }
             if (sub == 0) side_store(idx + tok, __float_as_int(cur[0].x));
             if (sub < D) side_store(li + tok * D + sub, cur[0].y);
@@ -1037,10 +1005,8 @@ int launch_fsq(hipStream_t s, const FsqArgs& a) {
 int launch_fsq_copy_ceiling(hipStream_t s, const float* x, int64_t n, float* q, int32_t* idx, float* li) {
     L3AC_REQUIRE(x && q && idx && li && n > 0, "fsq_copy_ceiling: bad arguments");
     int64_t blocks = ceil_div64(n, THREADS / 8);
-#ifndef L3AC_FSQ_CEILING_PER_CU
-#define L3AC_FSQ_CEILING_PER_CU 3  // the quantiser kernel's own residency (register-bound): the ceiling of ITS launch shape
-#endif
-    const int64_t places = (int64_t)l3ac_device_cu_count() * L3AC_FSQ_CEILING_PER_CU;
+    constexpr int CEILING_PER_CU = 3;  // the quantiser kernel's own residency (register-bound): the ceiling of ITS launch shape
+    const int64_t places = (int64_t)l3ac_device_cu_count() * CEILING_PER_CU;
     if (blocks > places) blocks = places;
     ProfScope prof(s, "fsq_copy_ceiling_kernel", 0.0, (double)n * 1052.0);
     hipLaunchKernelGGL(fsq_copy_ceiling_kernel, dim3((unsigned)blocks), dim3(THREADS), 0, s, x, n, q, idx, li);

@@ -214,128 +214,8 @@ __global__ __launch_bounds__(THREADS, BK == 16 ? 3 : 2) void gemm_f32_kernel(con
     gemm_epilogue<NT>(p, acc, m0, n0, wave, li, lh);
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// LDS-DMA variant (plain A, k % 16 == 0): operand tiles go global -> LDS directly (global_load_lds_dwordx4: no staging
-// VGPRs, no ds_write), three LDS stages, TWO K tiles in flight behind a counted s_waitcnt vmcnt and a raw s_barrier
-// (a __syncthreads() would drain the DMA queue).  The DMA writes LDS linearly (wave base + lane * 16 B), so the XOR
-// swizzle of the tile is applied to the per-lane SOURCE address: lane l of a 16-row group fetches chunk
-// (l & 3) ^ ((row >> 2) & 3) of row l >> 2, and the fragment reads use the same lds_off<16>() as the staged kernel.
-// ---------------------------------------------------------------------------------------------------------
-template <int NT>
-__global__ __launch_bounds__(THREADS, 3) void gemm_f32_dma_kernel(const GemmArgs p) {
-    constexpr int BK = 16;
-    constexpr int BN = 32 * NT;
-    constexpr int STAGE = (BM + BN) * BK;   // floats per pipeline stage: A tile then W tile
-    constexpr int A_INSTR = BM / 16 / 4;    // DMA instructions per wave per tile for A (16 rows each)
-    constexpr int W_INSTR = BN / 16 / 4;    // ... and for W
-    static_assert(NT == 2 || NT == 4, "every wave must issue the same number of DMAs per tile");
-    constexpr int PER_TILE = A_INSTR + (W_INSTR > 0 ? W_INSTR : 1);
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n_blocks = (p.n + BN - 1) / BN;
-    const int64_t m_panels = (p.m + BM - 1) / BM;
-    // (32-bit on purpose: the 64-bit forms of these four wave-uniform divisions are ~100 scalar instructions each, a visible part of
-    // a short-K block's life; the launcher keeps the grid, hence every quotient, below 2^31)
-    const unsigned group = blockIdx.x / (unsigned)(8 * n_blocks);
-    const unsigned in_group = blockIdx.x % (unsigned)(8 * n_blocks);
-    const unsigned panels_here = ((int64_t)group * 8 + 8 <= m_panels) ? (unsigned)8 : (unsigned)(m_panels - (int64_t)group * 8);
-    const int64_t m0 = ((int64_t)group * 8 + in_group % panels_here) * BM;
-    const int n0 = (int)(in_group / panels_here) * BN;
-
-    // per-lane DMA sources (rows past the edge are clamped to row 0: they feed accumulators that are never stored)
-    const int rg = lane >> 2, pos = lane & 3;
-    const float* a_src[A_INSTR];
-    int a_dst[A_INSTR];
-#pragma unroll
-    for (int j = 0; j < A_INSTR; ++j) {
-        const int row = 16 * (A_INSTR * wave + j) + rg;
-        const int64_t m = m0 + row;
-        a_src[j] = p.a + (m < p.m ? m : 0) * p.lda + 4 * (pos ^ ((row >> 2) & 3));
-        a_dst[j] = 16 * (A_INSTR * wave + j) * BK;
-    }
-    constexpr int WI = W_INSTR > 0 ? W_INSTR : 1;
-    const float* w_src[WI];
-    int w_dst[WI];
-#pragma unroll
-    for (int j = 0; j < WI; ++j) {
-        const int grp = W_INSTR > 0 ? W_INSTR * wave + j : (wave & 1);  // NT == 2: waves 2,3 duplicate groups 0,1
-        const int row = 16 * grp + rg;
-        const int n = n0 + row;
-        w_src[j] = p.w + (int64_t)(n < p.n ? n : 0) * p.ldw + 4 * (pos ^ ((row >> 2) & 3));
-        w_dst[j] = BM * BK + 16 * grp * BK;
-    }
-    // The DMA is issued from inline asm: hipcc would otherwise put an s_waitcnt vmcnt(0) in front of the first ds_read
-    // of every K step (it cannot prove the DMA target does not alias the read) and drain the pipeline.  M0 (the LDS
-    // destination base) is written in the same statement that uses it (guide section 5.7); completion is tracked only by the
-    // counted waits below — there is no other VMEM traffic inside the loop.
-    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
-    auto dma16 = [&](const float* src, unsigned lds_byte) {
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep)
-                     : "v"(src), "s"(lds_byte)
-                     : "memory");
-    };
-    auto issue = [&](int kt, int stage) {
-        const unsigned base = lds_base + (unsigned)(stage * STAGE) * 4u;
-#pragma unroll
-        for (int j = 0; j < A_INSTR; ++j)
-            dma16(a_src[j] + kt * BK, __builtin_amdgcn_readfirstlane(base + (unsigned)a_dst[j] * 4u));
-#pragma unroll
-        for (int j = 0; j < WI; ++j)
-            dma16(w_src[j] + kt * BK, __builtin_amdgcn_readfirstlane(base + (unsigned)w_dst[j] * 4u));
-    };
-
-    f32x16 acc[NT];
-#pragma unroll
-    for (int i = 0; i < NT; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    const int li = lane & 31;
-    const int lh = lane >> 5;
-    const int n_tiles = p.k / BK;
-
-    issue(0, 0);
-    if (n_tiles > 1) {
-        issue(1, 1);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    int stage = 0;
-    for (int kt = 0; kt < n_tiles; ++kt) {
-        const bool ahead = kt + 2 < n_tiles;
-        if (ahead) issue(kt + 2, stage >= 1 ? stage - 1 : 2);  // (stage + 2) % 3: last read one iteration ago
-        const float* as = smem + stage * STAGE;
-        const float* ws = as + BM * BK;
-#pragma unroll
-        for (int q = 0; q < BK / 8; ++q) {
-            const int chunk = 2 * q + lh;
-            const float4 af = *reinterpret_cast<const float4*>(as + lds_off<BK>(32 * wave + li, chunk));
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const float4 bf = *reinterpret_cast<const float4*>(ws + lds_off<BK>(32 * nt + li, chunk));
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc[nt], 0, 0, 0);
-            }
-        }
-        // tile kt+1 must have landed (this wave's share) before anyone reads it; tile kt+2 may stay in flight
-        if (ahead)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        stage = stage == 2 ? 0 : stage + 1;
-    }
-    gemm_epilogue<NT>(p, acc, m0, n0, wave, li, lh);
-}
-
+// (An LDS-DMA staged variant — global_load_lds, three LDS stages — was measured equal to the register-staged kernel in round 2 and
+// retired in round 5: git show 782323b:l3ac_amd/csrc/kernels/gemm_f32.hip.)
 template <int NT, bool CONV, int BK>
 int launch_one(hipStream_t s, const GemmArgs& g) {
     const bool fullk = !CONV && g.k % BK == 0;
@@ -345,28 +225,12 @@ int launch_one(hipStream_t s, const GemmArgs& g) {
     L3AC_REQUIRE(blocks < (int64_t)1 << 31, "gemm: grid too large (m=%lld n=%d)", (long long)g.m, g.n);
     const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
     char name[64];  // instantiation + shape + epilogue: the profile aggregates launches of identical work
-    const bool dma_name = BK == 16 && (NT == 2 || NT == 4) && fullk && (std::getenv("L3AC_GEMM_DMA") ? std::atoi(std::getenv("L3AC_GEMM_DMA")) != 0 : false);
-    if (dma_name)
-        std::snprintf(name, sizeof(name), "gemm_f32_dma_kernel<%d> %lldx%dx%d e%d", NT, (long long)g.m, g.n, g.k, g.epi);
-    else
-        std::snprintf(name, sizeof(name), "gemm_f32_kernel<%d,%s,%d,%s%s> %lldx%dx%d e%d", NT, CONV ? "true" : "false", BK,
+    std::snprintf(name, sizeof(name), "gemm_f32_kernel<%d,%s,%d,%s%s> %lldx%dx%d e%d", NT, CONV ? "true" : "false", BK,
                       fullk ? "true" : "false", g.gate_yi ? ",gated" : "", (long long)g.m, g.n, g.k, g.epi);
     const double a_elems = CONV ? (double)g.m * g.cin : (double)g.m * g.k;
     const double c_cols = g.epi == EPI_GEGLU ? (double)g.ldc : (double)g.n;
     ProfScope prof(s, name, 2.0 * (double)g.m * g.n * g.k,
                    4.0 * (a_elems + (double)g.n * g.k + (double)g.m * c_cols * (g.epi == EPI_BIAS_RES ? 2.0 : 1.0)));
-    static const bool use_dma = [] {
-        const char* e = std::getenv("L3AC_GEMM_DMA");
-        return e ? std::atoi(e) != 0 : false;  // measured equal to the register-staged kernel: off by default
-    }();
-    if constexpr (BK == 16 && (NT == 2 || NT == 4)) {
-        if (fullk && use_dma) {
-            const size_t lds3 = (size_t)3 * (BM + BN) * BK * sizeof(float);
-            hipLaunchKernelGGL((gemm_f32_dma_kernel<NT>), dim3((unsigned)blocks), dim3(THREADS), lds3, s, g);
-            L3AC_LAUNCH_CHECK();
-            return L3AC_OK;
-        }
-    }
     if constexpr (!CONV && BK == 16) {
         if (g.gate_yi) {
             L3AC_REQUIRE(fullk, "gemm: the gated A operand needs k %% 16 == 0 (k=%d)", g.k);
@@ -408,15 +272,11 @@ int launch_gemm(hipStream_t s, const GemmArgs& g) {
                      (long long)g.frames, (long long)g.m);
     }
     // K tile: 32 floats (64 KB of LDS per block, 2 blocks per CU) or 16 (32 KB, 3 blocks per CU: more waves to cover
-    // the prologue / epilogue of short-K products).  L3AC_GEMM_BK overrides the choice for A/B measurements.
-    static const int bk_override = [] {
-        const char* e = std::getenv("L3AC_GEMM_BK");
-        return e ? std::atoi(e) : 0;
-    }();
-    int bk = (bk_override == 16 || bk_override == 32) && !g.gate_yi ? bk_override : 16;  // the gated kernel exists for 16 only
+    // the prologue / epilogue of short-K products).
+    int bk = 16;  // (the gated kernel exists for 16 only)
     // A grid that leaves CUs idle (a single clip) runs at one block per CU: nothing covers a k tile's fetch -> LDS -> barrier chain,
     // so take half as many of them (same k order inside every group of 8: same bits)
-    if (!bk_override && !g.gate_yi && ceil_div64(g.m, BM) * ceil_div64(g.n, 32) <= 256) bk = 32;
+    if (!g.gate_yi && ceil_div64(g.m, BM) * ceil_div64(g.n, 32) <= 256) bk = 32;
 #define L3AC_GEMM_LAUNCH(NT_, CONV_) (bk == 16 ? launch_one<NT_, CONV_, 16>(s, g) : launch_one<NT_, CONV_, 32>(s, g))
     if (g.epi == EPI_GEGLU) {
         L3AC_REQUIRE(g.n % 64 == 0 && !conv, "gemm: GEGLU epilogue needs interleaved 64-column tiles");

@@ -17,8 +17,7 @@
 // 2.67x fewer matrix-core cycles per fp32 MAC; effective peak 2516.6 / 6 = 419 TFLOP/s(fp32-equivalent) vs 157.3.
 //
 // gfx950 design
-//   * block = 4 waves, tile 128 (m) x 128 (n) x 32 (k); wave w owns rows [32w, 32w+32) across the 4 column tiles
-//     (same ownership as gemm_f32.hip, so the fused epilogues are shared: gemm_epilogue.hpp); 3 blocks per CU.
+//   * block = 4 waves, tile 128 (m) x 128 (n) x 32 (k); wave w owns rows [32w, 32w+32) across the column tiles; 3 blocks per CU.
 //   * A never touches LDS: lane (row r, half h) loads the 16 fp32 of ITS MFMA fragments (k = 8h..8h+7 and
 //     16+8h..16+8h+7 of the k tile: one 128-B line per two lanes) straight into registers, two k tiles ahead, and
 //     splits them there (11 VALU ops per two values, v_cvt_pk_bf16_f32 based).
@@ -77,122 +76,12 @@ __global__ void split_image_kernel(const float* __restrict__ w, int64_t ldw, int
         *reinterpret_cast<u32x4*>(tile + pl * W_PLANE + tile_off(row % BN, kc % 4)) = u32x4{p[pl][0], p[pl][1], p[pl][2], p[pl][3]};
 }
 
-// KTAIL: k % 32 != 0 (k % 8 == 0): the last tile's out-of-range 8-value groups re-read the row's last valid group —
-// finite numbers that meet the image's zero padding
-template <bool KTAIL>
-__device__ __forceinline__ void gemm_split_body32(const GemmArgs& p, const int gp) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_split[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31, lh = lane >> 5;
-    // XCD-aware tile order (gemm_f32.hip): all column tiles of one A row panel run on one XCD
-    const int n_blocks = (p.n + BN - 1) / BN;
-    const int64_t m_panels = (p.m + BM - 1) / BM;
-    const int GP = gp;  // row panels per group (a multiple of the 8 XCDs)
-    // (32-bit on purpose: the 64-bit forms of these four wave-uniform divisions are ~100 scalar instructions each, a visible part of
-    // a short-K block's life; the launcher keeps the grid, hence every quotient, below 2^31)
-    const unsigned group = blockIdx.x / (unsigned)(GP * n_blocks);
-    const unsigned in_group = blockIdx.x % (unsigned)(GP * n_blocks);
-    const unsigned panels_here = ((int64_t)group * GP + GP <= m_panels) ? (unsigned)GP : (unsigned)(m_panels - (int64_t)group * GP);
-    const int64_t m0 = ((int64_t)group * GP + in_group % panels_here) * BM;
-    const int n0 = (int)(in_group / panels_here) * BN;
-    const int n_tiles = (p.k + BK - 1) / BK;
-    const int last = n_tiles - 1;
+// KTAIL (template parameter of the kernels below): k % 32 != 0 (k % 8 == 0): the last tile's out-of-range 8-value groups re-read the
+// row's last valid group — finite numbers that meet the image's zero padding.
 
-    // rows past the edge are clamped to row 0: they only feed accumulators that are never stored
-    const int64_t row = m0 + 32 * wave + li;
-    const float* a_src = p.a + (row < p.m ? row : 0) * p.lda + 8 * lh;
-    const unsigned char* w_src = p.w_img + (int64_t)(n0 / BN) * n_tiles * W_TILE + 16 * tid;
-
-    float4 a_pre[2][4];
-    u32x4 w_reg[W_LOADS];
-    auto load_a = [&](int kt, float4 (&dst)[4]) __attribute__((always_inline)) {
-        int o0 = kt * BK, o1 = kt * BK + 16;
-        if (KTAIL) {
-            const int kmax = p.k - 8 - 8 * lh;
-            o0 = o0 < kmax ? o0 : kmax;
-            o1 = o1 < kmax ? o1 : kmax;
-        }
-        dst[0] = *reinterpret_cast<const float4*>(a_src + o0);
-        dst[1] = *reinterpret_cast<const float4*>(a_src + o0 + 4);
-        dst[2] = *reinterpret_cast<const float4*>(a_src + o1);
-        dst[3] = *reinterpret_cast<const float4*>(a_src + o1 + 4);
-    };
-    auto load_w = [&](int kt) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < W_LOADS; ++i) w_reg[i] = *reinterpret_cast<const u32x4*>(w_src + (int64_t)kt * W_TILE + 16 * THREADS * i);
-    };
-    auto store_w = [&](int buf) __attribute__((always_inline)) {
-        unsigned char* base = smem_split + buf * W_TILE + 16 * tid;
-#pragma unroll
-        for (int i = 0; i < W_LOADS; ++i) *reinterpret_cast<u32x4*>(base + 16 * THREADS * i) = w_reg[i];
-    };
-    auto read_b = [&](const unsigned char* ws, int s, int j, bf16x8 (&b)[3]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) b[pl] = *reinterpret_cast<const bf16x8*>(ws + pl * W_PLANE + tile_off(32 * j + li, 2 * s + lh));
-    };
-
-    f32x16 acc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-
-    load_a(0, a_pre[0]);
-    load_a(last < 1 ? last : 1, a_pre[1]);
-    load_w(0);
-    store_w(0);
-    __syncthreads();
-    // straight-line body: tile indices are clamped instead of branched on, which keeps hipcc's s_waitcnt counts exact
-    // (the tail re-loads the last tile and stores it into the idle buffer)
-    auto step = [&](int kt, float4 (&cur)[4]) __attribute__((always_inline)) {
-        const int buf = kt & 1;
-        load_w(kt + 1 < last ? kt + 1 : last);
-        u32x4 af[2][3];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            unsigned x0, x1, x2, y0, y1, y2, z0, z1, z2, u0, u1, u2;
-            split2(cur[2 * s].x, cur[2 * s].y, x0, x1, x2);
-            split2(cur[2 * s].z, cur[2 * s].w, y0, y1, y2);
-            split2(cur[2 * s + 1].x, cur[2 * s + 1].y, z0, z1, z2);
-            split2(cur[2 * s + 1].z, cur[2 * s + 1].w, u0, u1, u2);
-            af[s][0] = u32x4{x0, y0, z0, u0};
-            af[s][1] = u32x4{x1, y1, z1, u1};
-            af[s][2] = u32x4{x2, y2, z2, u2};
-        }
-        load_a(kt + 2 < last ? kt + 2 : last, cur);  // the registers are free again: two tiles ahead
-        const unsigned char* ws = smem_split + buf * W_TILE;
-        bf16x8 bq[2][3];
-        read_b(ws, 0, 0, bq[0]);
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int s = it >> 2, j = it & 3;
-            if (it + 1 < 8) read_b(ws, (it + 1) >> 2, (it + 1) & 3, bq[(it + 1) & 1]);
-            const bf16x8 a0 = __builtin_bit_cast(bf16x8, af[s][0]);
-            const bf16x8 a1 = __builtin_bit_cast(bf16x8, af[s][1]);
-            const bf16x8 a2 = __builtin_bit_cast(bf16x8, af[s][2]);
-            const bf16x8 b0 = bq[it & 1][0], b1 = bq[it & 1][1], b2 = bq[it & 1][2];
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[j], 0, 0, 0);
-            if (it == 3) store_w(buf ^ 1);
-        }
-        __syncthreads();
-    };
-    for (int kt = 0; kt < n_tiles; kt += 2) {
-        step(kt, a_pre[0]);
-        if (kt + 1 < n_tiles) step(kt + 1, a_pre[1]);
-    }
-    gemm_epilogue<4>(p, acc, m0, n0, wave, li, lh);
-}
-
-// ---- the same GEMM on v_mfma_f32_16x16x32_bf16 ------------------------------------------------------------------------
-// Same tile (128 x 128 x 32, wave w = rows [32w, 32w+32) across all 128 columns), same weight image, same six plane products
-// per MAC, but every 32x32x16 product becomes 16x16x32 ones (16 cycles each, the same matrix-core cycles per FLOP).  Why: on
+// ---- the GEMM on v_mfma_f32_16x16x32_bf16 ------------------------------------------------------------------------------
+// Tile 128 x 128 x 32, wave w = rows [32w, 32w+32) across all 128 columns, six plane products per MAC on 16x16x32 instructions (16
+// cycles each; rounds 1-2 used v_mfma_f32_32x32x16_bf16: the same matrix-core cycles per FLOP).  Why: on
 // this power-limited chip the clock a dense MFMA loop holds depends on the instruction's shape — MI355X_MICROARCH.md (DVFS, item
 // 7) measures the 16x16x32 loop at 1.12-1.15 x the FLOP/s of the 32x32x16 loop at equal cycles; a timing-only substitution in
 // this kernel gave 4.24 -> 3.75 ms per step over its 29 launches.
@@ -202,16 +91,10 @@ __device__ __forceinline__ void gemm_split_body32(const GemmArgs& p, const int g
 //                    swizzle are the 32x32 kernel's (any 64 lanes of this pattern touch 64 distinct 16-B slots of one KB).
 //   D:               acc[h][t][i] = c[row 16 h + 4 (lane >> 4) + i][column 16 t + (lane & 15)].
 typedef float f32x4a __attribute__((ext_vector_type(4)));
-// L3AC_GEMM_NT: the bf16x3 GEMMs' output stores non-temporal (bias / residual / snake epilogues): the streamed-out C tile does not
+// The bf16x3 GEMMs' output stores are non-temporal (bias / residual / snake epilogues): the streamed-out C tile does not
 // push the A panel and the W tiles, which the column blocks of the same XCD re-read, out of L2.  Measured (profiles/r04/wide_nt.md):
 // the step's 14 launches 3.05-3.07 -> 2.99 ms in both of two interleaved rounds (the consumer of the hidden tensor included).
-#ifndef L3AC_GEMM_NT
-#define L3AC_GEMM_NT 1
-#endif
-__device__ __forceinline__ void c_store(float* p, float v) {
-    if (L3AC_GEMM_NT) __builtin_nontemporal_store(v, p);
-    else *p = v;
-}
+__device__ __forceinline__ void c_store(float* p, float v) { __builtin_nontemporal_store(v, p); }
 
 // Epilogue of the 16x16 accumulator layout.  Stored as they are, the tiles give 64-B row segments (16 lanes x 4 B) — measured: 29-42 k
 // cycles per block, a quarter to a half of a block's life, ten times the 32x32 layout's epilogue.  v_permlane16_swap_b32 exchanges the
@@ -286,14 +169,6 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmArgs& p, f32x4a (&acc)
                         const f32x2 sv = snake_act2(hv + bi, al, ia);
                         const f32x2 o = p.epi == EPI_SNAKE_GRN ? __builtin_elementwise_fma(ga, sv, be) + sv : sv;  // layers.py:115, n_x == 1
                         const int64_t m = mw + 16 * h + 4 * half + i;
-#ifdef L3AC_BOUND_NOHIDDEN  // TIMING-ONLY bounding build (wrong results): what would fusing pw1 -> snake/GRN -> pw2 of the C = 512 stage
-                            // be worth?  The 2048-wide hidden tensor is computed but only its first 256 rows are stored (finite
-                            // data for the second product, which reads those rows over and over: L2-resident)
-                        if (p.epi == EPI_SNAKE_GRN && p.n >= 2048 && m >= 256) {
-                            asm volatile("" ::"v"(o.x), "v"(o.y));
-                            continue;
-                        }
-#endif
                         if (m < p.m) c_store(p.c + m * p.ldc + n, o.x);
                         if (m + 1 < p.m) c_store(p.c + (m + 1) * p.ldc + n, o.y);
                     }
@@ -313,9 +188,6 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmArgs& p, f32x4a (&acc)
     }
 }
 
-#ifdef L3AC_SPLIT_STAMPS  // diagnostic build (tools/split_stamps.py): per-phase s_memtime sums of wave 0 of the first 4096 blocks
-__device__ long long g_split_stamps[8 * 4096];
-#endif
 // DEEP: the W tiles are requested TWO k tiles ahead through two register sets (the same MFMAs in the same order: same bits).
 // With one block per CU — a single clip's products: 8-32 blocks — nothing else covers the half k tile between a W request and
 // its LDS store, and every k tile waited ~1.5 us for it; the 24 extra registers would cost the full grids their third block per CU.
@@ -351,11 +223,7 @@ __device__ __forceinline__ void gemm_split_body16(const GemmArgs& p, const int g
 #pragma unroll
     for (int h = 0; h < RG; ++h) {
         const int64_t row = m0 + WM * wave + 16 * h + ln;
-#ifdef L3AC_BOUND_NOHIDDEN
-        const int64_t rr = row < p.m ? (p.k >= 2048 && p.lda >= 2048 ? row % 256 : row) : 0;
-#else
         const int64_t rr = row < p.m ? row : 0;
-#endif
         a_row[h] = p.a + rr * p.lda + 8 * lg;
         a_t[h] = CONV ? (int)((unsigned)rr % (unsigned)p.frames) : 0;  // (m < 2^31: checked by the launcher)
     }
@@ -424,19 +292,11 @@ __device__ __forceinline__ void gemm_split_body16(const GemmArgs& p, const int g
     if (DEEP) load_w(last < 1 ? last : 1, Set1{});  // tile 1 waits in the second set for step 0's store
     __syncthreads();
     // straight-line body: tile indices are clamped instead of branched on, which keeps hipcc's s_waitcnt counts exact
-#ifdef L3AC_SPLIT_STAMPS
-    long long t_split = 0, t_mfma = 0, t_tail = 0;
-    const long long t_begin = (long long)__builtin_amdgcn_s_memtime();
-#define SPLIT_STAMP() ((long long)__builtin_amdgcn_s_memtime())
-#endif
     // (odd: the step's parity — which register set receives this step's W request and which one is stored)
     auto step = [&](int kt, float4 (&cur)[2 * RG], auto odd) __attribute__((always_inline)) {
         using Mine = std::integral_constant<int, DEEP ? decltype(odd)::value : 0>;       // receives tile kt + 2 (DEEP) / kt + 1
         using Next = std::integral_constant<int, DEEP ? 1 - decltype(odd)::value : 0>;   // holds tile kt + 1: stored in this step
         const int buf = kt & 1;
-#ifdef L3AC_SPLIT_STAMPS
-        const long long s0 = SPLIT_STAMP();
-#endif
         if (DEEP) {  // (tile kt + 1 was requested during step kt - 1 / in the prologue)
             load_w(kt + 2 < last ? kt + 2 : last, Mine{});
         } else {
@@ -460,11 +320,6 @@ __device__ __forceinline__ void gemm_split_body16(const GemmArgs& p, const int g
         // memory latency for its A operand: 3.0-3.5 k of a wave's 6.6 k cycles per k tile (tools/split_stamps.py).
         __builtin_amdgcn_sched_barrier(0);
         const unsigned char* ws = smem_split + buf * W_TILE;
-#ifdef L3AC_SPLIT_STAMPS
-        asm volatile("" : "+v"(af[0][0]), "+v"(af[RG - 1][2]));
-        const long long s1 = SPLIT_STAMP();
-        t_split += s1 - s0;
-#endif
         if constexpr (DEEP) {
             // Alone on its SIMD a wave issues the six products of one accumulator one MFMA latency apart (~36 instead of 16 cycles:
             // 3.5 k of a k tile's 3.7 k cycles).  Two column tiles x RG row groups are therefore kept in flight: four accumulators
@@ -489,9 +344,7 @@ __device__ __forceinline__ void gemm_split_body16(const GemmArgs& p, const int g
                         for (int h = 0; h < RG; ++h)
                             acc[h][t + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[h][PA[q]]),
                                                                                    bq[UT * cur + u][PB[q]], acc[h][t + u], 0, 0, 0);
-#ifndef L3AC_SPLIT_STAMPS
                 if (t + UT == 4) store_w(buf ^ 1, Next{});
-#endif
             }
         } else {
         bf16x8 bq[2][3];
@@ -512,36 +365,16 @@ __device__ __forceinline__ void gemm_split_body16(const GemmArgs& p, const int g
                 acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, acc[h][t], 0, 0, 0);
                 acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc[h][t], 0, 0, 0);
             }
-#ifndef L3AC_SPLIT_STAMPS
             if (t == 3) store_w(buf ^ 1, Next{});
-#endif
         }
         }
-#ifdef L3AC_SPLIT_STAMPS
-        asm volatile("" : "+v"(acc[0][7]), "+v"(acc[RG - 1][7]));
-        const long long s2 = SPLIT_STAMP();
-        t_mfma += s2 - s1;
-        store_w(buf ^ 1, Next{});
-#endif
         __syncthreads();
-#ifdef L3AC_SPLIT_STAMPS
-        t_tail += SPLIT_STAMP() - s2;
-#endif
     };
     for (int kt = 0; kt < n_tiles; kt += 2) {
         step(kt, a_pre[0], std::integral_constant<int, 0>{});
         if (kt + 1 < n_tiles) step(kt + 1, a_pre[1], std::integral_constant<int, 1>{});
     }
-#ifdef L3AC_SPLIT_STAMPS
-    const long long t_loop_end = SPLIT_STAMP();
-#endif
     gemm_epilogue16<RG>(p, acc, m0, n0, wave, lane);
-#ifdef L3AC_SPLIT_STAMPS
-    if (lane == 0 && wave == 0 && blockIdx.x < 4096) {
-        long long* o = g_split_stamps + 8 * blockIdx.x;
-        o[0] = t_split, o[1] = t_mfma, o[2] = t_tail, o[3] = t_loop_end - t_begin, o[4] = SPLIT_STAMP() - t_loop_end, o[5] = n_tiles;
-    }
-#endif
 }
 
 // ---- a single clip's products (a streaming chunk: 60-180 rows): column SLICES ------------------------------------------------------
@@ -647,15 +480,11 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_split_kernel_slices(const Gem
     gemm_epilogue16<1, 2>(p, acc, m0, n0, wave, lane);
 }
 
-// SHAPE: 16 = v_mfma_f32_16x16x32_bf16 (default); 32 = v_mfma_f32_32x32x16_bf16 (L3AC_SPLIT_MFMA=32).
-// (The 16x16x32 body is written for RG row groups of 16 per wave; RG = 4, i.e. 256-row blocks at two per CU, halves the LDS reads
+// (The body is written for RG row groups of 16 per wave; RG = 4, i.e. 256-row blocks at two per CU, halves the LDS reads
 // and the W traffic per MFMA and was measured: +3 % on the K = 2048 shapes, -17 % on the K = 512 ones, whose epilogue it doubles.)
-template <bool KTAIL, int SHAPE>
+template <bool KTAIL>
 __global__ __launch_bounds__(THREADS, 3) void gemm_split_kernel(const GemmArgs p, const int gp) {
-    if constexpr (SHAPE == 16)
-        gemm_split_body16<KTAIL, 2, false>(p, gp);
-    else
-        gemm_split_body32<KTAIL>(p, gp);
+    gemm_split_body16<KTAIL, 2, false>(p, gp);
 }
 // the implicit-convolution A operand (a kernel of its own in the profiles: its A path differs)
 __global__ __launch_bounds__(THREADS, 3) void gemm_split_conv_kernel(const GemmArgs p, const int gp) {
@@ -672,11 +501,6 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_split_kernel_few_blocks(const
 
 }  // namespace
 
-#ifdef L3AC_SPLIT_STAMPS
-extern "C" int l3ac_debug_split_stamps(long long* out, int n) {  // diagnostic builds only (not part of the ABI)
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_split_stamps), (size_t)n * sizeof(long long));
-}
-#endif
 // the route a new context starts on (l3ac_ctx::gemm_split; l3ac_ctx_set_gemm_split changes it per context)
 bool gemm_split_default() {
     const char* e = std::getenv("L3AC_GEMM_SPLIT");
@@ -739,50 +563,33 @@ int launch_gemm_split(hipStream_t s, const GemmArgs& g) {
     const double c_cols = g.epi == EPI_GEGLU ? (double)g.ldc : (double)g.n;
     ProfScope prof(s, name, 2.0 * (double)g.m * g.n * g.k,
                    4.0 * ((double)g.m * g.k + (double)g.m * c_cols * (g.epi == EPI_BIAS_RES ? 2.0 : 1.0)) + 6.0 * (double)g.n * g.k);
-    static const int gp_env = [] {
-        const char* e = std::getenv("L3AC_SPLIT_GP");
-        return e ? std::atoi(e) : 0;
-    }();
-    const int gp = gp_env > 0 ? gp_env : 8;
-    static const bool shape32 = [] {  // L3AC_SPLIT_MFMA=32: the 32x32x16 form of the kernel (A/B runs)
-        const char* e = std::getenv("L3AC_SPLIT_MFMA");
-        return e && std::atoi(e) == 32;
-    }();
+    const int gp = 8;  // row panels per group of the XCD-aware tile order (a multiple of the 8 XCDs)
     const bool tail = g.k % BK != 0;
     const int cus = l3ac_device_cu_count();
-    static const bool slices_on = [] {  // L3AC_SPLIT_SLICES=0: the 64 x 128 blocks for a single clip's products too (A/B runs; same bits)
-        const char* e = std::getenv("L3AC_SPLIT_SLICES");
-        return !(e && std::atoi(e) == 0);
-    }();
     if (conv) {  // (whole k tiles: no tail; the 16x16x32 form only)
         if (blocks <= cus)
             hipLaunchKernelGGL(gemm_split_conv_kernel_few_blocks, dim3((unsigned)(ceil_div64(g.m, BM / 2) * ceil_div64(g.n, BN))), dim3(THREADS),
                                2 * W_TILE, s, g, gp);
         else
             hipLaunchKernelGGL(gemm_split_conv_kernel, dim3((unsigned)blocks), dim3(THREADS), 2 * W_TILE, s, g, gp);
-    } else if (!shape32 && g.epi != EPI_GEGLU && ceil_div64(g.m, BM / 2) * ceil_div64(g.n, BN) <= cus / 4 && slices_on) {
+    } else if (g.epi != EPI_GEGLU && ceil_div64(g.m, BM / 2) * ceil_div64(g.n, BN) <= cus / 4) {
         // a single clip: column slices (64 rows x 32 columns per block)
         const unsigned grid = (unsigned)(ceil_div64(g.m, 64) * ceil_div64(g.n, 32));
         if (tail)
             hipLaunchKernelGGL((gemm_split_kernel_slices<true>), dim3(grid), dim3(THREADS), 2 * W_TILE, s, g);
         else
             hipLaunchKernelGGL((gemm_split_kernel_slices<false>), dim3(grid), dim3(THREADS), 2 * W_TILE, s, g);
-    } else if (!shape32 && blocks <= cus) {
+    } else if (blocks <= cus) {
         const unsigned few = (unsigned)(ceil_div64(g.m, BM / 2) * ceil_div64(g.n, BN));
         if (tail)
             hipLaunchKernelGGL((gemm_split_kernel_few_blocks<true>), dim3(few), dim3(THREADS), 2 * W_TILE, s, g, gp);
         else
             hipLaunchKernelGGL((gemm_split_kernel_few_blocks<false>), dim3(few), dim3(THREADS), 2 * W_TILE, s, g, gp);
-    } else if (shape32) {
-        if (tail)
-            hipLaunchKernelGGL((gemm_split_kernel<true, 32>), dim3((unsigned)blocks), dim3(THREADS), 2 * W_TILE, s, g, gp);
-        else
-            hipLaunchKernelGGL((gemm_split_kernel<false, 32>), dim3((unsigned)blocks), dim3(THREADS), 2 * W_TILE, s, g, gp);
     } else {
         if (tail)
-            hipLaunchKernelGGL((gemm_split_kernel<true, 16>), dim3((unsigned)blocks), dim3(THREADS), 2 * W_TILE, s, g, gp);
+            hipLaunchKernelGGL((gemm_split_kernel<true>), dim3((unsigned)blocks), dim3(THREADS), 2 * W_TILE, s, g, gp);
         else
-            hipLaunchKernelGGL((gemm_split_kernel<false, 16>), dim3((unsigned)blocks), dim3(THREADS), 2 * W_TILE, s, g, gp);
+            hipLaunchKernelGGL((gemm_split_kernel<false>), dim3((unsigned)blocks), dim3(THREADS), 2 * W_TILE, s, g, gp);
     }
     L3AC_LAUNCH_CHECK();
     return L3AC_OK;

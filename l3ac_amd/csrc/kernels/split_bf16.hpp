@@ -30,17 +30,6 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& p0, unsigne
 
 // acc += a . b over one k step of 16, operands given as their three planes (index = plane)
 __device__ __forceinline__ f32x16_t mfma_split(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16_t acc) {
-#ifdef L3AC_MFMA_X16  // timing experiment only (wrong results): the same operands through pairs of 16x16x32 MFMAs
-    {
-        typedef float f32x4v __attribute__((ext_vector_type(4)));
-        f32x4v c0 = {acc[0], acc[1], acc[2], acc[3]}, c1 = {acc[4], acc[5], acc[6], acc[7]};
-#define L3AC_X16(A, B) c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, c1, 0, 0, 0);
-        L3AC_X16(a[2], b[0]) L3AC_X16(a[1], b[1]) L3AC_X16(a[0], b[2]) L3AC_X16(a[1], b[0]) L3AC_X16(a[0], b[1]) L3AC_X16(a[0], b[0])
-#undef L3AC_X16
-        acc[0] = c0.x, acc[1] = c0.y, acc[2] = c0.z, acc[3] = c0.w, acc[4] = c1.x, acc[5] = c1.y, acc[6] = c1.z, acc[7] = c1.w;
-        return acc;
-    }
-#endif
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);

@@ -44,6 +44,8 @@
 #include "device_math.hpp"
 #include "split_bf16.hpp"
 #include "ring_common.hpp"
+#define L3AC_DIAG_UNIT_TRANS_STACK
+#include "diag.hpp"
 
 #include <cmath>
 #include <vector>
@@ -130,19 +132,6 @@ __device__ __forceinline__ float ts_exp_neg(float x) {
 // MAXW: most waves a workgroup of this instantiation is launched with (register budget 512 / ceil(MAXW / 4) per lane).  Where the
 // budget allows (MAXW <= 8: clips of at most 128 frames, e.g. the 60-token stages) the next weight fragment is fetched from LDS
 // while the current one multiplies; with one wave per SIMD nothing else covers that latency.
-#ifdef L3AC_TS_STAMPS  // diagnostic build (tools/ts_stamps.py): s_memtime sums per phase of wave 0 of workgroup 0
-__device__ long long g_ts_stamps[16];
-#define TS_STAMP(slot)                                                                        \
-    do {                                                                                      \
-        if (blockIdx.x == 0 && tid == 0) {                                                    \
-            const long long now_ = (long long)__builtin_amdgcn_s_memtime();                   \
-            g_ts_stamps[slot] += now_ - ts_last;                                              \
-            ts_last = now_;                                                                   \
-        }                                                                                     \
-    } while (0)
-#else
-#define TS_STAMP(slot) do { } while (0)
-#endif
 
 // (amdgpu_waves_per_eu: one workgroup per CU, so THREADS / 256 waves per SIMD is all the occupancy there will ever be — told so, the
 // scheduler spends the registers on keeping fragments in flight instead of re-reading them next to their use behind a full wait)
@@ -164,9 +153,7 @@ void trans_stack_kernel(const TransStackArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fl = lane & 15, lg = lane >> 4;
     const int frames = p.frames;
-#ifdef L3AC_TS_STAMPS
-    long long ts_last = (long long)__builtin_amdgcn_s_memtime();
-#endif
+    TS_STAMP_INIT();
     const int frame = 16 * wave + fl;            // this lane's frame (column of every tile)
     const bool frame_ok = frame < frames;
     float* const xclip = p.x + (int64_t)clip * frames * TS_DIM;
@@ -229,10 +216,8 @@ void trans_stack_kernel(const TransStackArgs p) {
     // stores of x in the queue only make the wait stronger), its own LDS reads and writes are done, then everybody's are; the
     // group just consumed is free for the next step's DMA
     auto step_sync = [&]() __attribute__((always_inline)) {
-#ifndef L3AC_TS_NOSYNC  // (TIMING-ONLY bounding build without the group barrier: wrong results)
         asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(L::WAIT) : "memory");
         __builtin_amdgcn_s_barrier();
-#endif
         asm volatile("" ::: "memory");
     };
 #pragma unroll
@@ -259,18 +244,8 @@ void trans_stack_kernel(const TransStackArgs p) {
     int slot_no = 0;  // slots consumed so far (wave-uniform)
     const unsigned char* const ring_lane = smem_ts + L::OFF_RING + 16 * lane;
     auto load_frag = [&](bf16x8 (&f)[3], const unsigned char* a) __attribute__((always_inline)) {
-#ifdef L3AC_TS_NOFRAG  // TIMING-ONLY bounding build (wrong results): every fragment is the same three registers, nothing is read
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-            u32x4 v = {(unsigned)lane, 0x3f803f80u, (unsigned)wave, 0x3c003c00u};
-            asm volatile("" : "+v"(v));
-            f[pl] = __builtin_bit_cast(bf16x8, v);
-        }
-        (void)a;
-#else
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) f[pl] = *reinterpret_cast<const bf16x8*>(a + 1024 * pl);
-#endif
     };
     // One slot step: the slot's 4 weight pieces in order, body(j, fragment) for piece j (compile-time j); `last` runs after the
     // last piece's products and before the step's barrier (LDS writes other waves read after it).
@@ -436,9 +411,7 @@ void trans_stack_kernel(const TransStackArgs p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-#ifdef L3AC_TS_STAMPS
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
+        TS_STAMP_DRAIN();
         TS_STAMP(12);  // six partials read and added
         ++coop_phase;
     };
@@ -630,16 +603,6 @@ void trans_stack_kernel(const TransStackArgs p) {
 
 }  // namespace
 
-#ifdef L3AC_TS_STAMPS
-extern "C" int l3ac_debug_ts_stamps(long long* out, int n, int reset) {  // diagnostic builds only (not part of the ABI)
-    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ts_stamps), (size_t)n * sizeof(long long));
-    if (reset) {
-        long long zero[16] = {};
-        rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ts_stamps), zero, sizeof(zero));
-    }
-    return rc;
-}
-#endif
 
 bool trans_stack_supported(int dim, int dim_head, int heads, int ff_inner, int frames, int window, int n_layers) {
     return dim == TS_DIM && dim_head == TS_DH && heads == TS_HEADS && ff_inner == TS_FFI && frames >= 1 && frames <= TS_MAX_FRAMES &&

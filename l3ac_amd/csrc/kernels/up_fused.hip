@@ -251,12 +251,8 @@ int launch_uf(hipStream_t s, const UpFusedArgs& a) {
     char name[64];
     std::snprintf(name, sizeof(name), DOWN ? "down_fused_kernel<%d,%d>" : "up_fused_kernel<%d,%d>", CIN, COUT);
     ProfScope prof(s, name, rows * 2.0 * CIN * COUT, rows * 4.0 * (CIN + (DOWN ? 0 : 4) + (double)a.scale * COUT));
-    static const int small_mode = [] {  // L3AC_UF_SMALL=0: 16-wave workgroups whatever the grid (A/B runs; same bits)
-        const char* e = std::getenv("L3AC_UF_SMALL");
-        return e ? std::atoi(e) : 1;
-    }();
-    // fewer 16-wave workgroups than half the CUs: four-wave workgroups spread the tiles over four times as many CUs
-    if (small_mode && 2 * ceil_div64(tiles, UF_WAVES) <= l3ac_device_cu_count()) return launch_uf_waves<CIN, COUT, DOWN, 4>(s, a, tiles_per_clip, tiles);
+    // fewer 16-wave workgroups than half the CUs: four-wave workgroups spread the tiles over four times as many CUs (same bits)
+    if (2 * ceil_div64(tiles, UF_WAVES) <= l3ac_device_cu_count()) return launch_uf_waves<CIN, COUT, DOWN, 4>(s, a, tiles_per_clip, tiles);
     return launch_uf_waves<CIN, COUT, DOWN, UF_WAVES>(s, a, tiles_per_clip, tiles);
 }
 

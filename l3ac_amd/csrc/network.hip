@@ -398,15 +398,13 @@ int network_build(l3ac_ctx* ctx, const l3ac_tensor* tensors, int n_tensors) {
             for (auto* stages : {&ctx->enc_units, &ctx->dec_units})
                 for (auto& stage : *stages)
                     for (ConvUnitW& u : stage)
-                        if (conv_unit_fused_supported(u.c)) {
+                        if (conv_unit_wide_supported(u.c)) {  // (C = 96 .. 256; on the exact route C = 96 takes conv_unit_fused_kernel: fp32 weights)
+                            b.extra_imgs.push_back({conv_unit_wide_image(b.host_of(u.w1), b.host_of(u.w2), u.c), &u.wide_img});
+                        } else if (conv_unit_fused_supported(u.c)) {
                             b.extra_imgs.push_back({conv_unit_w1_image(b.host_of(u.w1), u.c), &u.w1_img});
                             b.extra_imgs.push_back({conv_unit_w2_image(b.host_of(u.w2), u.c), &u.w2_img});
                             if (conv_unit_ring_supported(u.c))
                                 b.extra_imgs.push_back({conv_unit_ring_image(b.host_of(u.w1), b.host_of(u.w2), u.c), &u.ring_img});
-                            if (conv_unit_wide_supported(u.c))  // C = 96: both forms (use_wide)
-                                b.extra_imgs.push_back({conv_unit_wide_image(b.host_of(u.w1), b.host_of(u.w2), u.c), &u.wide_img});
-                        } else if (conv_unit_wide_supported(u.c)) {
-                            b.extra_imgs.push_back({conv_unit_wide_image(b.host_of(u.w1), b.host_of(u.w2), u.c), &u.wide_img});
                         }
         }
         if (b.err.empty()) {  // (ctx->dec_up was sized before the loop above: the targets stay valid)
@@ -625,14 +623,7 @@ int workspace_ensure_clip(l3ac_ctx* ctx, int batch, int samples, hipStream_t s) 
 // ---------------------------------------------------------------------------------------------------------
 // the wide fused kernel computes on the bf16 matrix cores only (bf16x3): it belongs to the split route
 static bool use_wide(const l3ac_ctx* ctx, const ConvUnitW& w) {
-    static const bool off = [] {
-        const char* e = std::getenv("L3AC_WIDE_FUSED");
-        return e && std::atoi(e) == 0;
-    }();
-    // C = 96 has both fused forms: the register-resident one (round 4) unless the context option "wide_narrow" (env L3AC_WIDE_NARROW)
-    // is 0, which keeps conv_unit_ring_kernel<96>
-    if (!ctx->wide_narrow && conv_unit_fused_supported(w.c)) return false;
-    return !off && !ctx->cfg.grn_exact && w.wide_img && ctx->gemm_split && conv_unit_wide_supported(w.c);
+    return !ctx->cfg.grn_exact && w.wide_img && ctx->gemm_split && conv_unit_wide_supported(w.c);
 }
 
 int conv_unit_step(l3ac_ctx* ctx, hipStream_t s, const ConvUnitW& w, float** cur, float** alt, int batch, int frames) {
@@ -644,7 +635,7 @@ int conv_unit_step(l3ac_ctx* ctx, hipStream_t s, const ConvUnitW& w, float** cur
         return L3AC_OK;
     }
     if (!ctx->cfg.grn_exact && conv_unit_fused_supported(w.c)) {
-        L3AC_TRY(launch_conv_unit_fused(s, w, *cur, *alt, batch, frames, ctx->gemm_split, ctx->narrow_ring, ctx->ring_geometry));
+        L3AC_TRY(launch_conv_unit_fused(s, w, *cur, *alt, batch, frames, ctx->gemm_split, ctx->narrow_ring));
         float* t = *cur;
         *cur = *alt;
         *alt = t;
@@ -699,7 +690,7 @@ int run_conv_units(l3ac_ctx* ctx, hipStream_t s, const std::vector<ConvUnitW>& u
 int run_conv_unit(l3ac_ctx* ctx, hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames) {
     if (x != y && use_wide(ctx, w))
         return launch_conv_unit_wide(s, w, x, y, reinterpret_cast<unsigned char*>(ctx->ws.h), ctx->ws.h_cap * sizeof(float), batch, frames);
-    if (!ctx->cfg.grn_exact && x != y && conv_unit_fused_supported(w.c)) return launch_conv_unit_fused(s, w, x, y, batch, frames, ctx->gemm_split, ctx->narrow_ring, ctx->ring_geometry);
+    if (!ctx->cfg.grn_exact && x != y && conv_unit_fused_supported(w.c)) return launch_conv_unit_fused(s, w, x, y, batch, frames, ctx->gemm_split, ctx->narrow_ring);
     const int group = conv_unit_group(ctx, w, batch, frames);
     for (int b0 = 0; b0 < batch; b0 += group) {
         const int nb = std::min(group, batch - b0);
@@ -778,13 +769,7 @@ int run_up(l3ac_ctx* ctx, hipStream_t s, const UpW& w, const float* x, float* tm
 }
 
 // the one-kernel form of EnhanceBlock gate + up layer (kernels/up_fused.hip): bf16x3 route, the narrow stages' widths
-static bool use_up_fused(const l3ac_ctx* ctx, const UpW& w) {
-    static const bool off = [] {  // L3AC_UP_FUSED=0: gated GEMM + row kernel instead (A/B runs)
-        const char* ev = std::getenv("L3AC_UP_FUSED");
-        return ev && std::atoi(ev) == 0;
-    }();
-    return !off && ctx->gemm_split && w.fused_img != nullptr;
-}
+static bool use_up_fused(const l3ac_ctx* ctx, const UpW& w) { return ctx->gemm_split && w.fused_img != nullptr; }
 
 // EnhanceBlock + UpLayer of one decoder stage: the gate is applied inside the up conv's A staging (no pass of its own).
 // x is left untouched; tmp holds the conv output at the input rate.
@@ -859,11 +844,7 @@ int run_last_block(l3ac_ctx* ctx, hipStream_t s, float* x, float* audio, int bat
 
 // the fused stack kernel computes on the bf16 matrix cores only (bf16x3): it belongs to the split route
 static bool use_trans_stack(const l3ac_ctx* ctx, const LocalTransW& w, int frames) {
-    static const bool off = [] {
-        const char* e = std::getenv("L3AC_TRANS_FUSED");
-        return e && std::atoi(e) == 0;
-    }();
-    return !off && ctx->gemm_split && w.stack_img && w.stack_ln &&
+    return ctx->gemm_split && w.stack_img && w.stack_ln &&
            trans_stack_supported(ctx->cfg.feature_dim, ctx->dim_head, HEADS, ctx->ff_inner, frames, w.window, (int)w.layers.size());
 }
 

@@ -96,19 +96,14 @@ struct l3ac_ctx {
     // channel contractions on the bf16 matrix cores through exact bf16x3 operand splits (default) or everything on the fp32 MFMA
     // instruction; head_pretanh (validation): the output head stores its value before the final tanh.
     bool gemm_split = true, head_pretanh = false;
-    // which fused kernel takes the narrow ConvUnits (C <= 96) on the split route: conv_unit_ring_kernel (16 frames per wave, LDS-DMA
+    // which fused kernel takes the narrow ConvUnits (C <= 48) on the split route: conv_unit_ring_kernel (16 frames per wave, LDS-DMA
     // weight ring) or conv_unit_split_kernel (32 frames per wave, chunk barriers); l3ac_ctx_set_option(ctx, "narrow_ring", 0 / 1)
-    int narrow_ring = 1;  // 0: conv_unit_split_kernel everywhere, 1: the ring kernel where it is faster (C = 48, 96), 2: wherever it exists
-    // C = 96 has both fused forms: 1 (default) conv_unit_wide_kernel<96> (round 4), 0 conv_unit_ring_kernel<96> (rounds 2-3); option
-    // "wide_narrow" / env L3AC_WIDE_NARROW.  The forms agree to rounding, not bit for bit: switch it per context, not between the calls
-    // whose results are compared bit for bit (a clip alone / inside a batch).
-    int wide_narrow = 1;
+    int narrow_ring = 1;  // 0: conv_unit_split_kernel everywhere, 1: the ring kernel where it is faster (C = 48), 2: wherever it exists (C = 24 too)
     // encoder down layers 24 -> 48 and 48 -> 96 (Conv1d(k = stride) + ChannelNorm) in one kernel on the bf16x3 route (the DOWN form of
     // up_fused_kernel) instead of a small-N fp32-MFMA GEMM + row kernel: option "down_fused" / env L3AC_DOWN_FUSED.  Default 0: it is
     // 0.12 ms faster at 256 clips and as accurate, but a different rounding of the encoder's first layers, and of the tokens compared
     // with the oracle so far one (stress weights, 1.9e-6 of a rounding boundary) changes sides with it — DESIGN.md section 4.
     int down_fused = 0;
-    int ring_geometry = 0;  // diagnostics (option "ring_geometry" / env L3AC_RING_VARIANT): another geometry of conv_unit_ring_kernel, same results
     const unsigned char* img(const float* w) const {  // null on the exact route: launch_gemm then takes the fp32 kernel
         if (!gemm_split) return nullptr;
         auto it = split_img.find(w);
@@ -159,11 +154,11 @@ int workspace_ensure_clip(l3ac_ctx* ctx, int batch, int samples, hipStream_t s);
 
 // fused ConvUnit for the narrow stages (kernels/conv_unit_fused.hip); x must not alias y
 bool conv_unit_fused_supported(int c);
-int launch_conv_unit_fused(hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames, bool split, int ring = 0, int ring_geometry = 0);
+int launch_conv_unit_fused(hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames, bool split, int ring = 0);
 // third form of the narrow ConvUnit (kernels/conv_unit_ring.hip): 16 frames per wave, weights through an LDS-DMA ring
 bool conv_unit_ring_supported(int c);
 bool conv_unit_ring_preferred(int c);  // the widths the pipeline routes there by default
-int launch_conv_unit_ring(hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames, int geometry);
+int launch_conv_unit_ring(hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames);
 std::vector<unsigned char> conv_unit_ring_image(const float* w1, const float* w2, int c);  // w1 [4c][c], w2 [c][4c]
 // bf16x3 variant (kernels/conv_unit_split.hip), chosen by launch_conv_unit_fused when the images exist and the split route is on
 int launch_conv_unit_split(hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames);

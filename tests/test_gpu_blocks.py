@@ -241,26 +241,16 @@ def test_conv_units(tiny, full):
 
 
 def test_conv_units_narrow_ring_and_split_forms(full):
-    """The two fused forms of the narrow ConvUnits (C = 24 / 48 / 96) — conv_unit_ring_kernel (16 frames per wave, LDS-DMA weight
-    ring; default) and conv_unit_split_kernel (32 frames per wave) — against the oracle on shapes that exercise tile and clip
-    boundaries (frames = 1, 15, 17, not a multiple of 16, enough tiles for several passes of the persistent grid with the ring
-    wrapping around), and against each other through an fp64 evaluation: neither may be the less accurate one by more than
-    rounding noise."""
+    """The two fused forms of the narrow ConvUnits (C = 24 / 48; C = 96 runs on conv_unit_wide_kernel<96>: test_conv_units_wide_fused) —
+    conv_unit_ring_kernel (16 frames per wave, weights resident in LDS; default at C = 48) and conv_unit_split_kernel (32 frames per
+    wave; default at C = 24) — against the oracle on shapes that exercise tile and clip boundaries (frames = 1, 15, not a multiple of
+    16, enough tiles for several passes of the persistent grid), against each other through an fp64 evaluation (neither may be the
+    less accurate one by more than rounding noise), and the ring kernel's small-grid geometry (four waves per workgroup: a single
+    clip) against its large-grid one bit for bit."""
     codec, mc, w = full
     ctx = codec.network.context()
-    # C = 96 runs on conv_unit_wide_kernel<96> since round 4 (test_conv_units_wide_fused); "wide_narrow" = 0 keeps the two narrow forms
-    # reachable, and this test compares all three
-    ctx.set_option("wide_narrow", 0)
-    try:
-        _narrow_forms(ctx, w)
-    finally:
-        ctx.set_option("wide_narrow", 1)
-
-
-def _narrow_forms(ctx, w):
     cases = (("encoder.blocks.1.0.module", 24, 3, 1), ("encoder.blocks.1.0.module", 24, 2, 47), ("encoder.blocks.1.0.module", 24, 40, 16200),
-             ("encoder.blocks.3.0.module", 48, 5, 15), ("decoder.blocks.10.0.module", 48, 3, 8100), ("decoder.blocks.10.0.module", 48, 300, 97),
-             ("encoder.blocks.5.0.module", 96, 7, 17), ("decoder.blocks.7.0.module", 96, 2, 2700), ("decoder.blocks.7.1.module", 96, 130, 333))
+             ("encoder.blocks.3.0.module", 48, 5, 15), ("decoder.blocks.10.0.module", 48, 3, 8100), ("decoder.blocks.10.0.module", 48, 300, 97))
     for block, c, b, t in cases:
         x = _rand((b, c, t), 900 + c + t)
         ref = O.conv_unit(w, block, x[:2])
@@ -269,51 +259,29 @@ def _narrow_forms(ctx, w):
             ctx.set_option("narrow_ring", ring)
             try:
                 outs[name] = G.from_frames(G.op_block(ctx, "l3ac_op_conv_unit", block, G.to_frames(x), (b, t, c)))
+                if name == "ring" and b > 1:  # a clip alone (small grid: four-wave workgroups at C = 48) == the same clip inside the batch
+                    alone = G.from_frames(G.op_block(ctx, "l3ac_op_conv_unit", block, G.to_frames(x[:1]), (1, t, c)))
+                    assert torch.equal(alone, outs[name][:1]), f"ring kernel: clip alone differs from the batch's on {block} B={b} T={t}"
             finally:
                 ctx.set_option("narrow_ring", 1)
             _close(f"{name} {block} B={b} T={t}", outs[name][:2], ref, atol=5e-5, rtol=5e-5)
         d = float((outs["ring"] - outs["split"]).abs().max())
         print(f"[ring vs split {block} B={b} T={t}] max difference {d:.3e}")
         assert d < 5e-5
-        if c == 96:
-            ctx.set_option("wide_narrow", 1)
-            try:
-                wide = G.from_frames(G.op_block(ctx, "l3ac_op_conv_unit", block, G.to_frames(x), (b, t, c)))
-            finally:
-                ctx.set_option("wide_narrow", 0)
-            _close(f"wide {block} B={b} T={t}", wide[:2], ref, atol=5e-5, rtol=5e-5)
-            d = float((wide - outs["ring"]).abs().max())
-            print(f"[wide vs ring {block} B={b} T={t}] max difference {d:.3e}")
-            assert d < 5e-5
-        # the kernel's other geometries (other waves x workgroups, 32 frames per wave, fragments read one piece ahead) evaluate the
-        # same operations in the same order per frame: identical results
-        for geometry in (1, 5, 8, 9):  # 9: the small-grid geometry (four waves per workgroup) whatever the size
-            ctx.set_option("narrow_ring", 2)
-            ctx.set_option("ring_geometry", geometry)
-            try:
-                alt = G.from_frames(G.op_block(ctx, "l3ac_op_conv_unit", block, G.to_frames(x), (b, t, c)))
-            finally:
-                ctx.set_option("narrow_ring", 1)
-                ctx.set_option("ring_geometry", 0)
-            assert torch.equal(alt, outs["ring"]), f"ring geometry {geometry} differs from the default on {block} B={b} T={t}"
-    block, c = "decoder.blocks.7.0.module", 96
-    x = _rand((2, c, 1000), 4242)
+    block, c = "decoder.blocks.10.0.module", 48
+    x = _rand((2, c, 2000), 4242)
     ref64 = O.conv_unit({k: v.double() for k, v in w.items() if k.startswith(block)}, block, x.double())
     errs = {}
-    for name, ring, wide_on in (("ring", 2, 0), ("split", 0, 0), ("wide", 1, 1)):
+    for name, ring in (("ring", 2), ("split", 0)):
         ctx.set_option("narrow_ring", ring)
-        ctx.set_option("wide_narrow", wide_on)
         try:
-            got = G.from_frames(G.op_block(ctx, "l3ac_op_conv_unit", block, G.to_frames(x), (2, 1000, c))).double()
+            got = G.from_frames(G.op_block(ctx, "l3ac_op_conv_unit", block, G.to_frames(x), (2, 2000, c))).double()
         finally:
             ctx.set_option("narrow_ring", 1)
-            ctx.set_option("wide_narrow", 0)
         e = (got - ref64).abs()
         errs[name] = (float(e.max()), float(e.pow(2).mean().sqrt()))
-    print(f"[C = 96 forms vs fp64] ring max {errs['ring'][0]:.3e} rms {errs['ring'][1]:.3e} | split max {errs['split'][0]:.3e} rms {errs['split'][1]:.3e}"
-          f" | wide max {errs['wide'][0]:.3e} rms {errs['wide'][1]:.3e}")
-    assert errs["ring"][1] <= 1.5 * errs["split"][1] + 1e-9
-    assert errs["wide"][1] <= 1.5 * errs["split"][1] + 1e-9
+    print(f"[C = 48 forms vs fp64] ring max {errs['ring'][0]:.3e} rms {errs['ring'][1]:.3e} | split max {errs['split'][0]:.3e} rms {errs['split'][1]:.3e}")
+    assert errs["ring"][1] <= 1.5 * errs["split"][1] + 1e-9 and errs["split"][1] <= 1.5 * errs["ring"][1] + 1e-9
 
 
 def test_conv_units_wide_fused(full):
@@ -895,12 +863,12 @@ def test_vq_argmin_graph_capture():
 
 def test_context_options_by_name(full):
     """l3ac_ctx_set_option: the route switches by name belong to ONE context, unknown names are refused (L3AC_EINVAL with a
-    message naming the options), out-of-range values of `narrow_ring` are clamped, and an unknown `ring_geometry` runs the default
-    geometry (same bits)."""
+    message naming the options) — among them the options retired in round 5 — and out-of-range values of `narrow_ring` are clamped."""
     codec, mc, w = full
     ctx = codec.network.context()
-    with pytest.raises(RuntimeError, match="unknown option"):
-        ctx.set_option("no_such_option", 1)
+    for name in ("no_such_option", "wide_narrow", "ring_geometry"):
+        with pytest.raises(RuntimeError, match="unknown option"):
+            ctx.set_option(name, 1)
     other = l3ac_amd.get_model("1kbps", synthetic_seed=0)
     other.network.cuda().eval()
     octx = other.network.context()
@@ -909,16 +877,13 @@ def test_context_options_by_name(full):
         assert ctx.get_gemm_split() is False and octx.get_gemm_split() is True  # another context is untouched
     finally:
         ctx.set_option("gemm_split", 1)
-    block, c, b, t = "decoder.blocks.7.0.module", 96, 3, 333
+    block, c, b, t = "decoder.blocks.10.0.module", 48, 3, 333
     x = _rand((b, c, t), 77)
-    ctx.set_option("wide_narrow", 0)  # (C = 96 on the narrow kernels, as before round 4)
-    ref = G.from_frames(G.op_block(ctx, "l3ac_op_conv_unit", block, G.to_frames(x), (b, t, c)))
+    ctx.set_option("narrow_ring", 2)
     try:
+        ref = G.from_frames(G.op_block(ctx, "l3ac_op_conv_unit", block, G.to_frames(x), (b, t, c)))
         ctx.set_option("narrow_ring", 99)     # clamped to 2: still the ring kernel at this width
-        ctx.set_option("ring_geometry", 12345)  # not a known geometry: the default one
         got = G.from_frames(G.op_block(ctx, "l3ac_op_conv_unit", block, G.to_frames(x), (b, t, c)))
     finally:
         ctx.set_option("narrow_ring", 1)
-        ctx.set_option("ring_geometry", 0)
-        ctx.set_option("wide_narrow", 1)
     assert torch.equal(got, ref)
