@@ -245,6 +245,124 @@ __global__ __launch_bounds__(THREADS) void fsq_kernel(const FsqDev p, const int 
     }
 }
 
+// ---- the hot form (round 5): forward pass at feat = 128 — 8 lanes per token, 4 channel quads per lane — with everything the generic
+// kernel decides at run time fixed at compile time, and the per-token tail done ONCE per latent instead of once per lane:
+//   * lane d of a token's eight owns latent d end to end: tanh, round, and — new — the dequantised value q_d = li / (L - 1) * 2 - 1
+//     (one exact division per lane instead of six per lane) and its term li_d * basis_d of the index;
+//   * the six q_d reach the token's lanes by DPP row broadcasts (as the level indices did), the index by a three-step DPP lane sum
+//     (small integers: exact in any order); the level indices are stored by their owners and never exchanged.
+// Per token the arithmetic that produces latents, level indices, index and q_feature is operation for operation the generic kernel's
+// (same fmaf chains, same lane-sum order, the same exact IEEE tail): the same bits (tests: both kernels against the reference's
+// known-answer vectors and against each other).  ~60 fewer vector instructions and ~100 fewer scalar branches per token group: on
+// boxes that hold a lower shader clock the generic kernel ran at 0.89 of its copy ceiling (the driver's round-4 box, one of this round's).
+// Registers: compiled for TWO workgroups per CU hipcc keeps the 2 D x 16 projection weights of a lane in registers across the token
+// loop (200 at D = 6) and the loop reads nothing from LDS.  (Forcing it — explicit register arrays — spills 22; requesting two token
+// groups ahead makes hipcc re-read the weights from LDS again.)  Measured on one box, two interleaved rounds (profiles/r05/fsq_hot_ab.txt, fractions of 8 TB/s): the
+// generic kernel 0.691; this kernel at three workgroups per CU (168 registers, 24 spilled) 0.635; weights re-read from LDS every token
+// group (92 registers, five workgroups per CU) 0.66-0.73; two workgroups per CU 0.767 = 1.01 x the copy kernel of the same residency.
+template <int D>
+__global__ __launch_bounds__(THREADS, 2) void fsq_forward128_kernel(const FsqDev p) {
+    constexpr int FEAT = 128, NV = 4, LPT = 8, TPB = THREADS / LPT;
+    static_assert(D <= LPT, "one latent per lane of a token's group");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Win = smem;                // [D][FEAT]
+    float* Wout = smem + D * FEAT;    // [D][FEAT] (project_out transposed)
+    float* Bout = Wout + D * FEAT;    // [FEAT]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < D * FEAT; i += THREADS) {
+        const int d = i / FEAT, c = i % FEAT;
+        Win[i] = p.w_in[i];
+        Wout[i] = p.w_out[c * D + d];
+    }
+    for (int i = tid; i < FEAT; i += THREADS) Bout[i] = p.b_out[i];
+    __syncthreads();
+
+    const int sub = tid & (LPT - 1), lane = tid & 63;
+    const int cq = 4 * sub;
+    constexpr int cstep = 4 * LPT;
+    const int64_t n_groups = (p.n + TPB - 1) / TPB;
+    // this lane's latent (lanes sub >= D shadow latent 0: their results are never used)
+    const int dm = sub < D ? sub : 0;
+    const float lm1 = (float)(p.levels[dm] - 1);
+    const float basis_m = sub < D ? (float)p.basis[dm] : 0.f;
+    const float bin_m = p.b_in ? p.b_in[dm] : 0.f;
+
+    float4 x_next[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) x_next[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto fetch = [&](int64_t g) __attribute__((always_inline)) {
+        const int64_t t = g * TPB + tid / LPT;
+        if (g < n_groups && t < p.n) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) x_next[v] = nt_load4(p.x + t * FEAT + cq + cstep * v);
+        }
+    };
+    int64_t g_next = fsq_group_at(0, blockIdx.x, gridDim.x, n_groups);
+    fetch(g_next);
+    for (int64_t it = 0; g_next < n_groups; ++it) {
+        const int64_t tok = g_next * TPB + tid / LPT;
+        const bool ok = tok < p.n;
+        float4 xv[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) xv[v] = x_next[v];
+        g_next = fsq_group_at(it + 1, blockIdx.x, gridDim.x, n_groups);
+        fetch(g_next);
+        // latent d = x . Win[d] + b_in[d]: partial dot of this lane's 16 channels, summed over the token's 8 lanes (lanes_sum's order)
+        float mine = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            float s = 0.f;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const float4 wv = *reinterpret_cast<const float4*>(Win + d * FEAT + cq + cstep * v);
+                s = fmaf(xv[v].x, wv.x, s); s = fmaf(xv[v].y, wv.y, s);
+                s = fmaf(xv[v].z, wv.z, s); s = fmaf(xv[v].w, wv.w, s);
+            }
+            s = lanes_sum(s, LPT);
+            mine = sub == d ? s : mine;
+        }
+        mine += bin_m;
+        const float act = (tanhf(mine) + 1.0f) * 0.5f;                           // fsq_act.py:39
+        const float li_mine = rintf(__fmul_rn(act, lm1));                          // vq/fsq.py:59 (half-to-even)
+        const float q_mine = __fsub_rn(__fmul_rn(__fdiv_rn(li_mine, lm1), 2.0f), 1.0f);  // vq/fsq.py:60, :21
+        const float idx_f = lanes_sum(li_mine * basis_m, LPT);                  // exact (vq/fsq.py:67-68): integers below 2^24
+        float4 o[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) o[v] = *reinterpret_cast<const float4*>(Bout + cq + cstep * v);
+#define L3AC_BCQ(n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q_mine), 0x150 + (n), 0xf, 0xf, false))
+        const bool upper = (lane & 8) != 0;  // the second token of the 16-lane row
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            float lo, hi;  // q_d of the row's first / second token: row_newbcast of row lane d / 8 + d
+            switch (d) {
+                case 0: lo = L3AC_BCQ(0), hi = L3AC_BCQ(8); break;
+                case 1: lo = L3AC_BCQ(1), hi = L3AC_BCQ(9); break;
+                case 2: lo = L3AC_BCQ(2), hi = L3AC_BCQ(10); break;
+                case 3: lo = L3AC_BCQ(3), hi = L3AC_BCQ(11); break;
+                case 4: lo = L3AC_BCQ(4), hi = L3AC_BCQ(12); break;
+                case 5: lo = L3AC_BCQ(5), hi = L3AC_BCQ(13); break;
+                case 6: lo = L3AC_BCQ(6), hi = L3AC_BCQ(14); break;
+                default: lo = L3AC_BCQ(7), hi = L3AC_BCQ(15); break;
+            }
+            const float q = upper ? hi : lo;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const float4 wv = *reinterpret_cast<const float4*>(Wout + d * FEAT + cq + cstep * v);
+                o[v].x = fmaf(q, wv.x, o[v].x); o[v].y = fmaf(q, wv.y, o[v].y);
+                o[v].z = fmaf(q, wv.z, o[v].z); o[v].w = fmaf(q, wv.w, o[v].w);
+            }
+        }
+#undef L3AC_BCQ
+        if (ok) {
+            float* dst = p.q_feature + tok * FEAT + cq;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) nt_store4(dst + cstep * v, o[v]);
+            if (sub == 0 && p.indices) side_store(p.indices + tok, (int32_t)idx_f);
+            if (sub < D && p.level_indices) side_store(p.level_indices + tok * D + sub, li_mine);
+        }
+    }
+}
+
 // The ceiling fsq_kernel is measured against: the same grid, the same per-lane access pattern (4 x 16 B loads per lane one
 // token group ahead, 4 x 16 B stores, 4 B per token of indices, 24 B per token of level indices) and NO arithmetic.
 __global__ __launch_bounds__(THREADS) void fsq_copy_ceiling_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ q,
@@ -286,6 +404,23 @@ __global__ __launch_bounds__(THREADS) void fsq_copy_ceiling_kernel(const float* 
     }
 }
 
+// resident workgroups per CU of a quantiser kernel at its LDS size (the occupancy query is a host-side computation; cached per device and form)
+static int fsq_resident(const void* fn, size_t lds, int form) {
+    static std::atomic<uint64_t> per_cu[L3AC_MAX_DEVICES][3] = {};
+    const int slot = l3ac_device_slot();
+    const uint64_t cached = slot >= 0 ? per_cu[slot][form].load(std::memory_order_relaxed) : 0;
+    int resident = (cached >> 8) == (uint64_t)lds ? (int)(cached & 0xff) : 0;
+    if (resident <= 0) {
+        int v = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, fn, THREADS, lds) != hipSuccess || v <= 0) v = 3;
+        resident = v > 8 ? 8 : v;
+        if (slot >= 0) per_cu[slot][form].store(((uint64_t)lds << 8) | (uint64_t)resident, std::memory_order_relaxed);
+    }
+    return resident;
+}
+// is this call the hot form (fsq_forward128_kernel)?
+static bool fsq_is_hot(const FsqDev& p) { return p.x && !p.idx_in && !p.act_in && !p.latents && p.feat == 128 && p.d <= 8; }
+
 template <int D>
 int launch_fsq_t(hipStream_t s, const FsqDev& p) {
     const int nv = p.feat >= 128 ? 4 : 2;        // 16 or 8 channels per lane
@@ -294,29 +429,21 @@ int launch_fsq_t(hipStream_t s, const FsqDev& p) {
     int64_t blocks = ceil_div64(p.n, tok_per_block);
     if (blocks <= 0) return L3AC_OK;
     const size_t lds = (size_t)(2 * D + 1) * p.feat * sizeof(float);
-    // One weight staging per block, a contiguous token range each, and ONE resident round: with more blocks than the chip
+    // One weight staging per block, tokens walked grid-stride, and ONE resident round: with more blocks than the chip
     // holds at once the last, partly filled round streams at a fraction of the HBM rate for a whole block lifetime
     // (2 048 blocks on 6 x 256 places: the last quarter of the work at a third of the bytes in flight).
-    const int form = nv == 4 ? 1 : 0;
-    const void* fns[2] = {reinterpret_cast<const void*>(fsq_kernel<D, 2>), reinterpret_cast<const void*>(fsq_kernel<D, 4>)};
-    // resident workgroups per CU of THIS launch's kernel and LDS size, cached per device as (lds << 8 | count): another feature
-    // width on the same instantiation asks again (the query is a host-side computation)
-    static std::atomic<uint64_t> per_cu[L3AC_MAX_DEVICES][2] = {};
-    const int slot = l3ac_device_slot();
-    const uint64_t cached = slot >= 0 ? per_cu[slot][form].load(std::memory_order_relaxed) : 0;
-    int resident = (cached >> 8) == (uint64_t)lds ? (int)(cached & 0xff) : 0;
-    if (resident <= 0) {
-        int v = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, fns[form], THREADS, lds) != hipSuccess || v <= 0) v = 3;
-        resident = v > 8 ? 8 : v;
-        if (slot >= 0) per_cu[slot][form].store(((uint64_t)lds << 8) | (uint64_t)resident, std::memory_order_relaxed);
-    }
-    const int64_t places = (int64_t)l3ac_device_cu_count() * resident;
+    const bool hot = fsq_is_hot(p);
+    const int form = hot ? 2 : (nv == 4 ? 1 : 0);
+    const void* fns[3] = {reinterpret_cast<const void*>(fsq_kernel<D, 2>), reinterpret_cast<const void*>(fsq_kernel<D, 4>),
+                          reinterpret_cast<const void*>(fsq_forward128_kernel<D>)};
+    const int64_t places = (int64_t)l3ac_device_cu_count() * fsq_resident(fns[form], lds, form);
     if (blocks > places) blocks = places;
     const double in_b = p.x ? 4.0 * p.feat : (p.idx_in ? 4.0 : 4.0 * D);
     ProfScope prof(s, "fsq_kernel", 4.0 * D * p.feat * (double)p.n,
                    (double)p.n * (in_b + 4.0 * p.feat + (p.indices ? 4.0 : 0.0) + (p.level_indices ? 4.0 * D : 0.0)));
-    if (form == 1)
+    if (hot)
+        hipLaunchKernelGGL((fsq_forward128_kernel<D>), dim3((unsigned)blocks), dim3(THREADS), lds, s, p);
+    else if (form == 1)
         hipLaunchKernelGGL((fsq_kernel<D, 4>), dim3((unsigned)blocks), dim3(THREADS), lds, s, p, lpt);
     else
         hipLaunchKernelGGL((fsq_kernel<D, 2>), dim3((unsigned)blocks), dim3(THREADS), lds, s, p, lpt);
@@ -1005,8 +1132,9 @@ int launch_fsq(hipStream_t s, const FsqArgs& a) {
 int launch_fsq_copy_ceiling(hipStream_t s, const float* x, int64_t n, float* q, int32_t* idx, float* li) {
     L3AC_REQUIRE(x && q && idx && li && n > 0, "fsq_copy_ceiling: bad arguments");
     int64_t blocks = ceil_div64(n, THREADS / 8);
-    constexpr int CEILING_PER_CU = 3;  // the quantiser kernel's own residency (register-bound): the ceiling of ITS launch shape
-    const int64_t places = (int64_t)l3ac_device_cu_count() * CEILING_PER_CU;
+    // the quantiser kernel's own residency (register-bound): the ceiling of ITS launch shape
+    const int per_cu = fsq_resident(reinterpret_cast<const void*>(fsq_forward128_kernel<6>), (size_t)(2 * 6 + 1) * 128 * sizeof(float), 2);
+    const int64_t places = (int64_t)l3ac_device_cu_count() * per_cu;
     if (blocks > places) blocks = places;
     ProfScope prof(s, "fsq_copy_ceiling_kernel", 0.0, (double)n * 1052.0);
     hipLaunchKernelGGL(fsq_copy_ceiling_kernel, dim3((unsigned)blocks), dim3(THREADS), 0, s, x, n, q, idx, li);

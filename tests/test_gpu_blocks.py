@@ -732,6 +732,15 @@ def test_fsq_fused_forward_and_roundtrip(full):
         n_bad, ok = index_mismatch_report(idx.cpu().numpy(), ind_ref["indices"].numpy(), lat_ref.numpy(), mc2.levels, tau=1e-4)
         print(f"[fsq fused {tag}] {n_bad}/4096 tokens differ (project_in summation order)")
         assert ok and n_bad <= 1  # observed on the MI355X: 0 (gate = observed + 1)
+        # the hot form of the forward pass (fsq_forward128_kernel: no latents tap, one latent per lane end to end, q_d broadcast instead of
+        # six divisions per lane) returns the generic kernel's bits — also on a token count that is not a multiple of its 32-token groups
+        # and with saturating / tiny inputs
+        for xs in (x, torch.cat([x[:1001] * 40.0, x[:37] * 1e-6])):
+            qh, ih, lh, _ = G.fsq_forward(xs.cuda(), list(mc2.levels), dev["project_in.weight"], dev["project_in.bias"],
+                                          dev["project_out.weight"], dev["project_out.bias"])
+            qg, ig, lg_, _ = G.fsq_forward(xs.cuda(), list(mc2.levels), dev["project_in.weight"], dev["project_in.bias"],
+                                           dev["project_out.weight"], dev["project_out.bias"], want_latents=True)
+            assert torch.equal(ih, ig) and torch.equal(lh, lg_) and torch.equal(qh, qg), f"{tag}: hot and generic quantiser kernels differ"
         # from the SAME latents the indices are bit-exact
         q2, idx2, li2, _ = G.fsq_forward(None, list(mc2.levels), None, None, dev["project_out.weight"], dev["project_out.bias"],
                                          latents_in=lat_ref.cuda())
