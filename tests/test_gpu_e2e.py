@@ -13,14 +13,18 @@ from tests.helpers import GOLDEN, index_agreement, index_mismatch_report, load_c
 pytestmark = pytest.mark.gpu
 
 TAU = 1e-4        # a flipped index must come from a latent within TAU of a rounding boundary (in level units)
-# Tolerances = the largest error observed on the MI355X for the cases of this file (profiles/r03/pytest_gpu.log) x ~2: the values
-# come from one box, one hipcc and one seed set, and a different summation order (a new kernel geometry, a compiler update) moves
-# them by tens of % without any defect (round 3 gated at x 1.3).  The decoder amplifies the ~1e-7 rounding noise of ANY evaluation
-# order to a few 1e-4 at the tanh output.  Every test prints what it observed.
-WAVE_ATOL = 1.1e-3      # 1 s clips, decoder given identical indices (observed <= 5.6e-4: 1k5bps, 8 clips)
+# Tolerances: MAX gates = the largest error observed on the MI355X for the cases of this file x ~2 (the values come from one box, one
+# hipcc and one seed set, and a different summation order — a new kernel geometry, a compiler update — moves the worst sample by tens
+# of % without any defect; the decoder amplifies the ~1e-7 rounding noise of ANY evaluation order to a few 1e-4 at the tanh output),
+# each backed by an RMS gate at ~2 x the observed rms: a real regression moves the rms of every clip, not one sample.
+# Observed = profiles/r05/pytest_gpu.log (every test prints it).
+WAVE_ATOL = 1.1e-3      # 1 s clips, decoder given identical indices (observed max <= 6.1e-4: 1kbps exact route vs the reference vector)
+WAVE_RMS = 9e-5         # ... and their rms error (observed <= 4.4e-5)
 WAVE_ATOL_LONG = 3e-3   # 6.5 s clips and chunked long audio (observed <= 1.47e-3)
-WAVE_ATOL_ROUTES = 1.5e-3 # bf16x3 route against exact-fp32 route, same tokens (observed <= 7.7e-4)
-FEAT_ATOL = 1.3e-5      # encoder / transformer features, activations O(1) (observed <= 6.4e-6)
+WAVE_RMS_LONG = 1.5e-4  # (observed <= 6.9e-5)
+WAVE_ATOL_ROUTES = 1.5e-3 # bf16x3 route against exact-fp32 route, same tokens (observed <= 7.0e-4)
+FEAT_ATOL = 1.3e-5      # encoder / transformer features, activations O(1) (observed <= 6.0e-6)
+FEAT_RMS = 2.5e-6       # (observed <= 1.2e-6)
 
 
 def _max_err(name, got, ref):
@@ -40,9 +44,13 @@ def _codec(tag, seed, grn_exact=False):
     return codec
 
 
-def _err(name, got, ref):
+def _err(name, got, ref, rms_tol=None):
+    """max |got - ref| (printed with the rms); with `rms_tol` the rms error is gated here as well."""
     e = (got.detach().cpu().double() - ref.detach().cpu().double()).abs()
-    print(f"[{name}] max|err|={e.max().item():.3e} rms={e.pow(2).mean().sqrt().item():.3e} max|ref|={ref.abs().max().item():.3e}")
+    rms = e.pow(2).mean().sqrt().item()
+    print(f"[{name}] max|err|={e.max().item():.3e} rms={rms:.3e} max|ref|={ref.abs().max().item():.3e}")
+    if rms_tol is not None:
+        assert rms < rms_tol, f"{name}: rms error {rms:.3e} >= {rms_tol:.1e}"
     return e.max().item()
 
 
@@ -64,15 +72,15 @@ def test_submodules_against_oracle(tag, seed, batch, samples):
         dec_in_ref = O.en_decoder(w, mc, q_ref)
         wave_ref = O.decoder(w, mc, dec_in_ref).squeeze(1)
     feat = G.op_plain(ctx, "l3ac_op_encoder", x.cuda(), batch, frames, (batch, frames // enc_rate, mc.feature_dim))
-    assert _err(f"{tag} encoder", G.from_frames(feat), feat_ref) < FEAT_ATOL
+    assert _err(f"{tag} encoder", G.from_frames(feat), feat_ref, FEAT_RMS) < FEAT_ATOL
     tok = G.op_plain(ctx, "l3ac_op_en_encoder", G.to_frames(feat_ref), batch, frames // enc_rate,
                      (batch, frames // mc.hop_length, mc.feature_dim))
-    assert _err(f"{tag} en_encoder", tok.cpu(), tok_ref) < FEAT_ATOL
+    assert _err(f"{tag} en_encoder", tok.cpu(), tok_ref, FEAT_RMS) < FEAT_ATOL
     dec_in = G.op_plain(ctx, "l3ac_op_en_decoder", q_ref.cuda(), batch, frames // mc.hop_length,
                         (batch, frames // enc_rate, mc.feature_dim))
-    assert _err(f"{tag} en_decoder", G.from_frames(dec_in), dec_in_ref) < FEAT_ATOL
+    assert _err(f"{tag} en_decoder", G.from_frames(dec_in), dec_in_ref, FEAT_RMS) < FEAT_ATOL
     wave = G.op_plain(ctx, "l3ac_op_decoder", G.to_frames(dec_in_ref), batch, frames // enc_rate, (batch, frames))
-    assert _err(f"{tag} decoder", wave.cpu(), wave_ref) < WAVE_ATOL
+    assert _err(f"{tag} decoder", wave.cpu(), wave_ref, WAVE_RMS) < WAVE_ATOL
 
 
 @pytest.mark.parametrize("tag,seed,batch,samples", [("tiny", 3, 4, 250), ("1kbps", 0, 4, 16000), ("3kbps", 0, 3, 16000),
@@ -107,7 +115,7 @@ def test_encode_decode_against_oracle(tag, seed, batch, samples):
     wave_ref = O.decode_audio(w, mc, indices=ind_ref["indices"])
     wave = codec.decode_audio(indices=ind_ref["indices"].cuda())
     assert wave.shape == (batch, n_tok * mc.hop_length)
-    assert _err(f"{tag} wave(from oracle indices)", wave, wave_ref) < WAVE_ATOL
+    assert _err(f"{tag} wave(from oracle indices)", wave, wave_ref, WAVE_RMS) < WAVE_ATOL
     # decode_audio(q_feature) and decode_audio(indices=...) agree bit for bit on the device's own outputs
     wave_a = codec.decode_audio(q)
     wave_b = codec.decode_audio(indices=ind["indices"])
@@ -254,7 +262,8 @@ def test_index_agreement_full_batch(tag):
 # observed on the MI355X with the stress profile (round 4; printed by the test): index mismatches per (config, route) and the
 # largest waveform error given identical indices
 OBSERVED_STRESS_MISMATCHES = {}
-STRESS_WAVE_ATOL = 3.7e-3  # observed <= 1.84e-3 (stress_1kbps, split route, 48 clips, unsaturated output)
+STRESS_WAVE_ATOL = 3.7e-3  # observed <= 1.84e-3 (stress_1kbps, split route, 48 clips, unsaturated output; round 5: 1.22e-3)
+STRESS_WAVE_RMS = 8e-5     # rms of the same error (observed <= 3.9e-5)
 
 
 @pytest.mark.parametrize("tag", ["stress_1kbps", "stress_3kbps"])
@@ -307,7 +316,7 @@ def test_parity_under_trained_weight_statistics(tag):
             err = (wave - wave_ref).abs()
             print(f"[{tag} {name}] waveform given identical indices: max|err| {float(err.max()):.3e} rms {float(err.pow(2).mean().sqrt()):.3e} "
                   f"(|wave| max {float(wave_ref.abs().max()):.3f}, {float((wave_ref.abs() > 0.999).float().mean()):.3f} saturated)")
-            assert float(err.max()) < STRESS_WAVE_ATOL
+            assert float(err.max()) < STRESS_WAVE_ATOL and float(err.pow(2).mean().sqrt()) < STRESS_WAVE_RMS
     finally:
         codec.network.set_gemm_split(before)
     # the GRN fast path (n = g / (g + 1e-8) taken as 1) under gamma / beta of O(1): the validation mode evaluates the literal formula,
@@ -586,7 +595,7 @@ def test_long_clip_multi_window_attention():
     print(f"[long clip] index mismatches vs oracle: {n_bad}/{ind_ref['indices'].numel()}")
     assert ok and n_bad <= 1  # observed: 0
     wave = codec.decode_audio(indices=ind_ref["indices"].cuda())
-    assert _err("long clip wave", wave, O.decode_audio(w, mc, indices=ind_ref["indices"])) < WAVE_ATOL_LONG
+    assert _err("long clip wave", wave, O.decode_audio(w, mc, indices=ind_ref["indices"]), WAVE_RMS_LONG) < WAVE_ATOL_LONG
 
 
 def test_weights_from_disk_and_example_flow(tmp_path):
@@ -688,7 +697,7 @@ def test_long_audio_chunker():
                                  audio_length=audio.shape[1])
         ref = CO.decode_unit(w, mc, ri)[:, :audio.shape[1]]
         assert wave.shape == (1, audio.shape[1])
-        assert _err(f"chunked wave w={window} p={prefix}", wave, ref) < WAVE_ATOL_LONG
+        assert _err(f"chunked wave w={window} p={prefix}", wave, ref, WAVE_RMS_LONG) < WAVE_ATOL_LONG
         # from q_feature chunks == from index chunks, bit for bit
         assert torch.equal(codec.decode_unit(chunk_q_feature=cq), codec.decode_unit(chunk_indices=ci))
     # one window covers the clip: identical to the plain call
