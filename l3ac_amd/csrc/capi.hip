@@ -588,13 +588,14 @@ int l3ac_ctx_set_option(l3ac_ctx* ctx, const char* name, int32_t value) {
     const std::string n(name);
     if (n == "gemm_split") ctx->gemm_split = value != 0;
     else if (n == "head_pretanh") ctx->head_pretanh = value != 0;
+    else if (n == "wide_sliced") ctx->wide_sliced = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "narrow_ring") ctx->narrow_ring = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "trans_coop") ctx->coop.enabled = value != 0;
     else if (n == "coop_timeout_ms") ctx->coop.timeout_ms = value < 1 ? 1 : (value > 20000 ? 20000 : value);
     else if (n == "coop_test_fault") ctx->coop.fault_part = value - 1;  // 0 = off, j + 1 = workgroup j of every clip withholds its first arrival
     else if (n == "down_fused") ctx->down_fused = value != 0;
     else {
-        l3ac_set_error("set_option: unknown option '%s' (gemm_split, head_pretanh, narrow_ring, trans_coop, coop_timeout_ms, coop_test_fault, down_fused)", name);
+        l3ac_set_error("set_option: unknown option '%s' (gemm_split, head_pretanh, narrow_ring, wide_sliced, trans_coop, coop_timeout_ms, coop_test_fault, down_fused)", name);
         return L3AC_EINVAL;
     }
     return L3AC_OK;

@@ -852,9 +852,203 @@ __global__ __launch_bounds__(256) void dwconv_ln_split_kernel(const ConvUnitW w,
     for (int o = 16 * threadIdx.x; o < IMG; o += 16 * 256) *reinterpret_cast<u32x4*>(out + o) = *reinterpret_cast<const u32x4*>(img + o);
 }
 
+// ---- the SLICED form (round 5): few frames, many CUs -------------------------------------------------------------------------------
+// conv_unit_wide_kernel gives every wave 16 or 32 frames END TO END: 6 144 MFMAs per 16 frames at C = 256 — 47 us on the wave's one
+// SIMD however fast the weights arrive — and a single clip (the streaming chunk: 900 frames at C = 256, 178 at C = 192) fills 15 / 3
+// workgroups: 80 / 49 us with 240 CUs idle.  Here the unit's two products are two launches over (frame tiles x channel slices), the
+// hidden tensor going through L2 once as the bf16x3 operand blocks the second product reads (6 B per element, 5.5 MB for one clip):
+//   wide_sliced_hidden_kernel   workgroup = 4 frame tiles of 16 (one per wave) x GH hidden tiles of 32: W1(nt) — the SAME pieces of the
+//                               SAME image (conv_unit_wide_image) — copied to LDS in one shot, b1 + products over the k blocks in order,
+//                               act_stage, split: block (nt, tile) of the hidden image = the registers xb of the fused kernel.
+//   wide_sliced_out_kernel      workgroup = 2 frame tiles x 2 output row tiles of 16 channels (one pair per wave): per hidden tile nt a
+//                               12-KB ring slot = W2(nt)'s two pieces + the two tiles' hidden blocks, 11 slots in flight by LDS-DMA
+//                               behind counted waits; b2 + products over nt in order, + residual.
+// Every accumulator sees the same operands in the same order as in conv_unit_wide_kernel<C, 1>: the SAME BITS (tested at block
+// level and by the batch-invariance tests: a clip alone takes this form, inside a large batch the fused one).
 template <int C>
-int launch_wide(hipStream_t s, const ConvUnitW& w, const float* x, float* y, unsigned char* planes, int64_t rows, int frames, const char* name,
-                const char* name_front) {
+struct SGeo {
+    using G = WGeo<C>;
+    static constexpr int PIECES = C / 16;        // pieces of W1(nt) (k block b, hidden half hh) / of W2(nt) (output row tile rt)
+    static constexpr int T1 = PIECES * 3072;     // bytes of W1(nt) = bytes of W2(nt)
+    static constexpr int GH = C >= 256 ? 2 : 1;  // hidden tiles per workgroup of the first kernel
+    static constexpr int LDS1 = GH * T1;
+    static constexpr int RING = 12, PF = RING - 1, SLOT = 4 * 3072;
+    static constexpr int LDS2 = RING * SLOT;
+    static_assert(T1 % (4 * 3072) == 0 && G::NT % GH == 0 && G::RT % 2 == 0 && LDS1 <= 160 * 1024 && LDS2 <= 160 * 1024, "bad geometry");
+    // byte offsets inside conv_unit_wide_image: W1(0) | W1(1) W2(0) | ... | W1(NT-1) W2(NT-2) | W2(NT-1)
+    __host__ __device__ static constexpr int64_t w1_off(int nt) { return nt == 0 ? 0 : (int64_t)T1 * (2 * nt - 1); }
+    __host__ __device__ static constexpr int64_t w2_off(int nt) { return nt == G::NT - 1 ? (int64_t)T1 * (2 * G::NT - 1) : (int64_t)T1 * 2 * (nt + 1); }
+};
+
+// hid: [hidden tile nt][frame tile of 16][plane][1 KB]: lane (frame n = lane & 15, k group g = lane >> 4) owns 16 B = the hidden channels
+// 32 nt + sigma(g, j) of its frame, the B operand of the second product (conv_unit_wide_image, W2)
+template <int C>
+__global__ __launch_bounds__(256, 1) void wide_sliced_hidden_kernel(const ConvUnitW w, const unsigned char* __restrict__ planes,
+                                                                    unsigned char* __restrict__ hid, const int64_t tiles16, const int64_t tiles_pad) {
+    using G = WGeo<C>;
+    using S = SGeo<C>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_wide[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lg = lane >> 4;
+    constexpr int HG = G::NT / S::GH;
+    const int nt0 = (int)(blockIdx.x % (unsigned)HG) * S::GH;
+    const int64_t tile = (int64_t)(blockIdx.x / (unsigned)HG) * 4 + wave;
+    const bool tile_ok = tile < tiles16;
+    // the weights of this workgroup's hidden tiles, all in flight at once: wave v copies bytes [T1 / 4 v, T1 / 4 (v + 1)) of each
+    {
+        const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_wide;
+        constexpr int Q = S::T1 / 4;
+#pragma unroll
+        for (int g = 0; g < S::GH; ++g)
+#pragma unroll
+            for (int j = 0; j < Q / 3072; ++j)
+                dma_slot_quarter<3>(w.wide_img + S::w1_off(nt0 + g) + Q * wave + 3072 * j, 16u * (unsigned)lane,
+                                    lds0 + (unsigned)(g * S::T1 + Q * wave + 3072 * j));
+    }
+    // LayerNorm(dw_conv7(x)) of this wave's 16 frames, split (dwconv_ln_split_kernel): k block b, plane p = one 1-KB block
+    bf16x8 ap[C / 32][3];
+    {
+        const int64_t tl = tile_ok ? tile : 0;
+        const unsigned char* src = planes + (tl >> 1) * (int64_t)(G::NS1 * 3072) + (int)(tl & 1) * 3072 + 16 * lane;
+#pragma unroll
+        for (int b = 0; b < C / 32; ++b)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) ap[b][pl] = *reinterpret_cast<const bf16x8*>(src + (2 * b * 3 + pl) * 1024);
+    }
+    // activation parameters of the lane's 8 hidden channels per tile (pair P = hidden half P >> 1, register pair P & 1: channels
+    // 32 nt + 16 (P >> 1) + 4 lg + 2 (P & 1), + 1) in act_stage's table order, and the pw_conv1 bias the accumulators start at
+    alignas(16) float tab[S::GH][4][8];
+    f32x4_t b1v[S::GH][2];
+#pragma unroll
+    for (int g = 0; g < S::GH; ++g) {
+#pragma unroll
+        for (int P = 0; P < 4; ++P) {
+            const int ch = 32 * (nt0 + g) + 16 * (P >> 1) + 4 * lg + 2 * (P & 1);
+            const float2 al = *reinterpret_cast<const float2*>(w.alpha + ch), ia = *reinterpret_cast<const float2*>(w.inv_alpha + ch);
+            const float2 ga = *reinterpret_cast<const float2*>(w.gamma + ch), be = *reinterpret_cast<const float2*>(w.beta + ch);
+            tab[g][P][0] = al.x, tab[g][P][1] = al.y, tab[g][P][2] = ia.x, tab[g][P][3] = ia.y;
+            tab[g][P][4] = ga.x, tab[g][P][5] = ga.y, tab[g][P][6] = be.x, tab[g][P][7] = be.y;
+        }
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) b1v[g][hh] = *reinterpret_cast<const f32x4_t*>(w.b1 + 32 * (nt0 + g) + 16 * hh + 4 * lg);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < S::GH; ++g) {
+        f32x4_t q[2] = {b1v[g][0], b1v[g][1]};
+        const unsigned char* wl = smem_wide + g * S::T1 + 16 * lane;
+        static_for<S::PIECES>([&](auto pc_) {
+            constexpr int piece = decltype(pc_)::value;  // (k block piece >> 1, hidden half piece & 1)
+            bf16x8 fb[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) fb[pl] = *reinterpret_cast<const bf16x8*>(wl + piece * 3072 + pl * 1024);
+            static_for<6>([&](auto m_) { q[piece & 1] = mfma_plane<decltype(m_)::value>(fb, ap[piece >> 1], q[piece & 1]); });
+        });
+        ActPair ast[4];
+        unsigned out[3][4];
+        static_for<4 * ACT_STAGES>([&](auto st_) {
+            constexpr int ST = decltype(st_)::value, P = ST / ACT_STAGES, T = ST % ACT_STAGES, E = 2 * (P & 1);
+            act_stage<T>(ast[P], tab[g][P], q[P >> 1][E], q[P >> 1][E + 1], out[0][P], out[1][P], out[2][P]);
+        });
+        if (tile_ok) {
+            unsigned char* dst = hid + ((int64_t)(nt0 + g) * tiles_pad + tile) * 3072 + 16 * lane;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dst + pl * 1024) = u32x4{out[pl][0], out[pl][1], out[pl][2], out[pl][3]};
+        }
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(256, 1) void wide_sliced_out_kernel(const ConvUnitW w, const unsigned char* __restrict__ hid, const float* __restrict__ x,
+                                                                 float* __restrict__ y, const int64_t rows, const int64_t tiles16, const int64_t tiles_pad) {
+    using G = WGeo<C>;
+    using S = SGeo<C>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_wide[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ln = lane & 15, lg = lane >> 4;
+    constexpr int RP = G::RT / 2;
+    const int rp = (int)(blockIdx.x % (unsigned)RP);
+    const int64_t fp = blockIdx.x / (unsigned)RP;
+    const int ft = wave & 1, rg = wave >> 1;  // this wave's frame tile and output row tile of the workgroup's 2 x 2
+    const int64_t tile = 2 * fp + ft;
+    const bool tile_ok = tile < tiles16;
+    const int rt = 2 * rp + rg;
+    const int64_t row = tile * 16 + ln;
+    const bool row_ok = tile_ok && row < rows;
+    // the residual: this lane's four channels of its frame (a plain load, older than every copy below: the counted waits cover it)
+    const f32x4_t xres = *reinterpret_cast<const f32x4_t*>(x + (row_ok ? row : 0) * C + 16 * rt + 4 * lg);
+    // the pw_conv2 bias the accumulator starts at, by scalar loads (a vector load here would sit in front of the counted waits)
+    f32x4_t yacc;
+    {
+        const float* b2t = w.b2 + 16 * rt;  // wave-uniform
+        unsigned sv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sv[i] = __builtin_bit_cast(unsigned, b2t[i]);
+        // (bit masks, not ?: chains: hipcc turned those into nested branches)
+        const unsigned m0 = 0u - (unsigned)(lg == 0), m1 = 0u - (unsigned)(lg == 1), m2 = 0u - (unsigned)(lg == 2), m3 = 0u - (unsigned)(lg == 3);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) yacc[i] = __builtin_bit_cast(float, (sv[i] & m0) | (sv[4 + i] & m1) | (sv[8 + i] & m2) | (sv[12 + i] & m3));
+    }
+    // this wave's 3 KB of every slot: waves 0, 1 = the two W2 pieces, waves 2, 3 = the two hidden blocks
+    const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_wide;
+    const unsigned char* const src0 = wave < 2 ? w.wide_img + (int64_t)(2 * rp + wave) * 3072 : hid + (2 * fp + (wave - 2)) * 3072;
+    const int64_t hid_stride = tiles_pad * 3072;
+    auto issue = [&](auto nt_) __attribute__((always_inline)) {
+        constexpr int nt = decltype(nt_)::value;
+        const unsigned char* src = src0 + (wave < 2 ? S::w2_off(nt) : (int64_t)nt * hid_stride);
+        dma_slot_quarter<3>(src, 16u * (unsigned)lane, ring_lds + (unsigned)((nt % S::RING) * S::SLOT + 3072 * wave));
+    };
+    static_for<S::PF>([&](auto j_) { issue(j_); });
+    // fragments one hidden tile ahead: fw = this wave's W2 piece (A operand), fx = its frame tile's hidden block (B operand)
+    bf16x8 fw[2][3], fx[2][3];
+    auto fetch = [&](auto nt_) __attribute__((always_inline)) {
+        constexpr int nt = decltype(nt_)::value;
+        const unsigned char* slot = smem_wide + (nt % S::RING) * S::SLOT + 16 * lane;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            fw[nt & 1][pl] = *reinterpret_cast<const bf16x8*>(slot + rg * 3072 + pl * 1024);
+            fx[nt & 1][pl] = *reinterpret_cast<const bf16x8*>(slot + (2 + ft) * 3072 + pl * 1024);
+        }
+    };
+    // slot nt has landed for every wave, and every wave's reads of the slot before it are complete: `issued` slots requested so far
+    auto landed = [&](auto nt_, auto issued_) __attribute__((always_inline)) {
+        constexpr int after = decltype(issued_)::value - 1 - decltype(nt_)::value;  // slots requested after slot nt
+        static_assert(after >= 0 && 3 * after <= 63, "counted wait out of range");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * after) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    landed(std::integral_constant<int, 0>{}, std::integral_constant<int, S::PF>{});
+    fetch(std::integral_constant<int, 0>{});
+    static_for<G::NT>([&](auto nt_) {
+        constexpr int nt = decltype(nt_)::value;
+        if constexpr (nt + S::PF < G::NT) issue(std::integral_constant<int, nt + S::PF>{});  // into the position of slot nt - 1
+        if constexpr (nt + 1 < G::NT) {
+            constexpr int issued = nt + S::PF + 1 < G::NT ? nt + S::PF + 1 : G::NT;
+            landed(std::integral_constant<int, nt + 1>{}, std::integral_constant<int, issued>{});
+            fetch(std::integral_constant<int, nt + 1>{});
+        }
+        static_for<6>([&](auto m_) { yacc = mfma_plane<decltype(m_)::value>(fw[nt & 1], fx[nt & 1], yacc); });
+    });
+    // residual + store (xtract/nn/layers.py:59-62): the lane's 16 B of its frame
+    if (row_ok) *reinterpret_cast<f32x4_t*>(y + row * C + 16 * rt + 4 * lg) = xres + yacc;
+}
+
+// frame tiles of 16 up to which the sliced form exists (its hidden image is part of the scratch: 24 C bytes per frame) and up to which
+// it is taken by default (measured against the half-tile form: tools/wide_bench.py, profiles/r05/wide_sliced.md)
+constexpr int64_t SLICED_MAX_TILES = 256, SLICED_AUTO_TILES = 256;
+__host__ constexpr size_t wide_planes_bytes(int c, int64_t rows) { return (size_t)((rows + 31) / 32) * 32 * (size_t)c * 6; }
+__host__ constexpr int64_t sliced_tiles_pad(int64_t rows) { return ((rows + 15) / 16 + 3) / 4 * 4; }
+__host__ constexpr bool sliced_exists(int c, int64_t rows) { return c >= 128 && (rows + 15) / 16 <= SLICED_MAX_TILES; }
+__host__ constexpr size_t sliced_hidden_bytes(int c, int64_t rows) { return (size_t)(4 * c / 32) * (size_t)sliced_tiles_pad(rows) * 3072; }
+
+template <int C>
+int launch_wide(hipStream_t s, const ConvUnitW& w, const float* x, float* y, unsigned char* planes, int64_t rows, int frames, int sliced_mode) {
     using G = WGeo<C>;
     static PerDeviceOnce configured;
     if (configured.first()) {
@@ -862,18 +1056,46 @@ int launch_wide(hipStream_t s, const ConvUnitW& w, const float* x, float* y, uns
                                            hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
         L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_unit_wide_kernel<C, 1>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+        if constexpr (!G::FRONT) {
+            L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wide_sliced_hidden_kernel<C>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, SGeo<C>::LDS1));
+            L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wide_sliced_out_kernel<C>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, SGeo<C>::LDS2));
+        }
         configured.done();
     }
+    char name[64];
     if constexpr (!G::FRONT) {
-        ProfScope prof(s, name_front, (double)rows * 30.0 * C, (double)rows * 10.0 * C);
+        std::snprintf(name, sizeof(name), "dwconv_ln_split_kernel<%d>", C);
+        ProfScope prof(s, name, (double)rows * 30.0 * C, (double)rows * 10.0 * C);
         constexpr int IMG = (C / 16) * 3072;
         hipLaunchKernelGGL((dwconv_ln_split_kernel<C>), dim3((unsigned)ceil_div64(rows, 32)), dim3(256), IMG, s, w, x, planes, rows, frames);
         L3AC_LAUNCH_CHECK();
+        const int64_t tiles16 = ceil_div64(rows, 16);
+        if (sliced_exists(C, rows) && (sliced_mode == 2 || (sliced_mode == 1 && tiles16 <= SLICED_AUTO_TILES))) {
+            using S = SGeo<C>;
+            const int64_t tiles_pad = sliced_tiles_pad(rows);
+            unsigned char* hid = planes + (wide_planes_bytes(C, rows) + 255) / 256 * 256;
+            {
+                std::snprintf(name, sizeof(name), "wide_sliced_hidden_kernel<%d>", C);
+                ProfScope p1(s, name, (double)rows * 8.0 * C * C, (double)rows * 30.0 * C);
+                hipLaunchKernelGGL((wide_sliced_hidden_kernel<C>), dim3((unsigned)(tiles_pad / 4 * (G::NT / S::GH))), dim3(256), S::LDS1, s, w, planes, hid,
+                                   tiles16, tiles_pad);
+                L3AC_LAUNCH_CHECK();
+            }
+            std::snprintf(name, sizeof(name), "wide_sliced_out_kernel<%d>", C);
+            ProfScope p2(s, name, (double)rows * 8.0 * C * C, (double)rows * 32.0 * C);
+            hipLaunchKernelGGL((wide_sliced_out_kernel<C>), dim3((unsigned)(ceil_div64(tiles16, 2) * (G::RT / 2))), dim3(256), S::LDS2, s, w, hid, x, y, rows,
+                               tiles16, tiles_pad);
+            L3AC_LAUNCH_CHECK();
+            return L3AC_OK;
+        }
     }
     const int64_t tiles = ceil_div64(rows, 32);
     int64_t blocks = ceil_div64(tiles, 4);
     const int cus = l3ac_device_cu_count();
     const bool half = 2 * blocks <= (int64_t)cus * G::WG_PER_CU;  // half tiles while twice the workgroups still fit one pass
+    std::snprintf(name, sizeof(name), "conv_unit_wide_kernel<%d>", C);
     ProfScope prof(s, name, (double)rows * (16.0 * C * C + (G::FRONT ? 30.0 * C : 0.0)), (double)rows * (G::FRONT ? 8.0 : 14.0) * C);
     if (half) {
         blocks = ceil_div64(2 * tiles, 4);
@@ -896,22 +1118,27 @@ int launch_wide(hipStream_t s, const ConvUnitW& w, const float* x, float* y, uns
 
 
 bool conv_unit_wide_supported(int c) { return c == 96 || c == 128 || c == 192 || c == 256; }
-// scratch the pair of kernels needs: the split LayerNorm output of `rows` frames (whole 32-frame tiles), 6 bytes per element
-size_t conv_unit_wide_scratch_bytes(int c, int64_t rows) { return (size_t)ceil_div64(rows, 32) * 32 * (size_t)c * 6; }
+// scratch the kernels need: the split LayerNorm output of `rows` frames (whole 32-frame tiles), 6 bytes per element, and — for row
+// counts at which the sliced form exists — its hidden image behind it
+size_t conv_unit_wide_scratch_bytes(int c, int64_t rows) {
+    const size_t planes = wide_planes_bytes(c, rows);
+    return sliced_exists(c, rows) ? (planes + 255) / 256 * 256 + sliced_hidden_bytes(c, rows) : planes;
+}
 
-// x must not alias y; `planes` = at least conv_unit_wide_scratch_bytes(c, batch * frames) bytes of scratch (checked)
+// x must not alias y; `planes` = at least conv_unit_wide_scratch_bytes(c, batch * frames) bytes of scratch (checked).
+// sliced_mode (context option "wide_sliced"): 0 the fused kernel always, 1 the sliced form for few frames (default), 2 wherever it exists
 int launch_conv_unit_wide(hipStream_t s, const ConvUnitW& w, const float* x, float* y, unsigned char* planes, size_t planes_bytes, int batch,
-                          int frames) {
+                          int frames, int sliced_mode) {
     L3AC_REQUIRE(x != y && w.wide_img && planes && batch > 0 && frames > 0, "conv_unit_wide: bad arguments");
     const int64_t rows = (int64_t)batch * frames;
     L3AC_REQUIRE(planes_bytes >= conv_unit_wide_scratch_bytes(w.c, rows), "conv_unit_wide: scratch of %zu bytes, %zu needed (C=%d, %lld rows)",
                  planes_bytes, conv_unit_wide_scratch_bytes(w.c, rows), w.c, (long long)rows);
     L3AC_REQUIRE(ceil_div64(rows, 4) < ((int64_t)1 << 31), "conv_unit_wide: too many rows");
     switch (w.c) {
-        case 96: return launch_wide<96>(s, w, x, y, planes, rows, frames, "conv_unit_wide_kernel<96>", "dwconv_ln_split_kernel<96>");
-        case 128: return launch_wide<128>(s, w, x, y, planes, rows, frames, "conv_unit_wide_kernel<128>", "dwconv_ln_split_kernel<128>");
-        case 192: return launch_wide<192>(s, w, x, y, planes, rows, frames, "conv_unit_wide_kernel<192>", "dwconv_ln_split_kernel<192>");
-        case 256: return launch_wide<256>(s, w, x, y, planes, rows, frames, "conv_unit_wide_kernel<256>", "dwconv_ln_split_kernel<256>");
+        case 96: return launch_wide<96>(s, w, x, y, planes, rows, frames, sliced_mode);
+        case 128: return launch_wide<128>(s, w, x, y, planes, rows, frames, sliced_mode);
+        case 192: return launch_wide<192>(s, w, x, y, planes, rows, frames, sliced_mode);
+        case 256: return launch_wide<256>(s, w, x, y, planes, rows, frames, sliced_mode);
         default:
             l3ac_set_error("conv_unit_wide: C=%d not supported", w.c);
             return L3AC_EINVAL;

@@ -628,7 +628,7 @@ static bool use_wide(const l3ac_ctx* ctx, const ConvUnitW& w) {
 
 int conv_unit_step(l3ac_ctx* ctx, hipStream_t s, const ConvUnitW& w, float** cur, float** alt, int batch, int frames) {
     if (use_wide(ctx, w)) {
-        L3AC_TRY(launch_conv_unit_wide(s, w, *cur, *alt, reinterpret_cast<unsigned char*>(ctx->ws.h), ctx->ws.h_cap * sizeof(float), batch, frames));
+        L3AC_TRY(launch_conv_unit_wide(s, w, *cur, *alt, reinterpret_cast<unsigned char*>(ctx->ws.h), ctx->ws.h_cap * sizeof(float), batch, frames, ctx->wide_sliced));
         float* t = *cur;
         *cur = *alt;
         *alt = t;
@@ -689,7 +689,7 @@ int run_conv_units(l3ac_ctx* ctx, hipStream_t s, const std::vector<ConvUnitW>& u
 
 int run_conv_unit(l3ac_ctx* ctx, hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames) {
     if (x != y && use_wide(ctx, w))
-        return launch_conv_unit_wide(s, w, x, y, reinterpret_cast<unsigned char*>(ctx->ws.h), ctx->ws.h_cap * sizeof(float), batch, frames);
+        return launch_conv_unit_wide(s, w, x, y, reinterpret_cast<unsigned char*>(ctx->ws.h), ctx->ws.h_cap * sizeof(float), batch, frames, ctx->wide_sliced);
     if (!ctx->cfg.grn_exact && x != y && conv_unit_fused_supported(w.c)) return launch_conv_unit_fused(s, w, x, y, batch, frames, ctx->gemm_split, ctx->narrow_ring);
     const int group = conv_unit_group(ctx, w, batch, frames);
     for (int b0 = 0; b0 < batch; b0 += group) {

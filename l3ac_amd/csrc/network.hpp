@@ -98,6 +98,9 @@ struct l3ac_ctx {
     bool gemm_split = true, head_pretanh = false;
     // which fused kernel takes the narrow ConvUnits (C <= 48) on the split route: conv_unit_ring_kernel (16 frames per wave, LDS-DMA
     // weight ring) or conv_unit_split_kernel (32 frames per wave, chunk barriers); l3ac_ctx_set_option(ctx, "narrow_ring", 0 / 1)
+    // the wide ConvUnits (C = 128 .. 256) of FEW frames — a streaming chunk — as two launches over (frame tiles x channel slices) instead of
+    // the fused kernel, whose waves own their frames end to end (conv_unit_wide.hip, 'the SLICED form'; the same bits)
+    int wide_sliced = 1;  // 0: never, 1: where it is faster (up to 256 frame tiles of 16: measured), 2: wherever the form exists (the same today; tests)
     int narrow_ring = 1;  // 0: conv_unit_split_kernel everywhere, 1: the ring kernel where it is faster (C = 48), 2: wherever it exists (C = 24 too)
     // encoder down layers 24 -> 48 and 48 -> 96 (Conv1d(k = stride) + ChannelNorm) in one kernel on the bf16x3 route (the DOWN form of
     // up_fused_kernel) instead of a small-N fp32-MFMA GEMM + row kernel: option "down_fused" / env L3AC_DOWN_FUSED.  Default 0: it is
@@ -168,7 +171,7 @@ std::vector<unsigned char> conv_unit_w2_image(const float* w2, int c);  // w2 [c
 bool conv_unit_wide_supported(int c);
 size_t conv_unit_wide_scratch_bytes(int c, int64_t rows);
 int launch_conv_unit_wide(hipStream_t s, const ConvUnitW& w, const float* x, float* y, unsigned char* planes, size_t planes_bytes, int batch,
-                          int frames);
+                          int frames, int sliced_mode);
 std::vector<unsigned char> conv_unit_wide_image(const float* w1, const float* w2, int c);  // w1 [4c][c], w2 [c][4c]
 // one LocalTrans stack per launch, one workgroup per clip (kernels/trans_stack.hip); x [batch][frames][128] in place
 bool trans_stack_supported(int dim, int dim_head, int heads, int ff_inner, int frames, int window, int n_layers);

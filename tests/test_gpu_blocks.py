@@ -340,6 +340,46 @@ def test_conv_units_wide_fused(full):
     assert float(e_f.max()) <= 2.0 * float(e_u.max()) + 1e-7
 
 
+def test_conv_units_wide_sliced_form_returns_the_same_bits(full):
+    """The SLICED form of the wide ConvUnits (round 5: two launches over frame tiles x channel slices for few frames — the streaming
+    chunk) against the fused kernel on the same input: every output bit equal, for whole and ragged tiles, odd tile counts (an idle
+    wave in the last workgroup of either launch), one frame, several clips (the front end's clip boundaries), at C = 256 / 192 and
+    at C = 128 (the reference's default geometry); then against the oracle."""
+    codec, mc, w = full
+    codec128 = l3ac_amd.get_model(GOLDEN / "refdefault.toml", synthetic_seed=5)
+    codec128.network.to(device="cuda").eval()
+    w128 = W.folded_weights(codec128.network.state_dicts())
+    cases = [(codec, w, "decoder.blocks.4.1.module", 256, 1, 900), (codec, w, "decoder.blocks.4.0.module", 256, 1, 901),
+             (codec, w, "decoder.blocks.4.2.module", 256, 3, 333), (codec, w, "decoder.blocks.4.2.module", 256, 1, 1),
+             (codec, w, "decoder.blocks.4.0.module", 256, 4, 1024), (codec, w, "encoder.blocks.7.0.module", 192, 1, 178),
+             (codec, w, "encoder.blocks.7.1.module", 192, 5, 37), (codec, w, "encoder.blocks.7.1.module", 192, 2, 16),
+             (codec, w, "encoder.blocks.7.0.module", 192, 22, 178), (codec128, w128, "decoder.blocks.4.0.module", 128, 1, 1000),
+             (codec128, w128, "decoder.blocks.4.1.module", 128, 3, 47)]
+    for cdc, ww, block, c, b, t in cases:
+        ctx = cdc.network.context()
+        x = _rand((b, c, t), 4000 + c + t)
+        xf = G.to_frames(x)
+        outs = {}
+        for mode in (0, 2):
+            ctx.set_option("wide_sliced", mode)
+            try:
+                with _capi.profile() as prof:
+                    outs[mode] = G.op_block(ctx, "l3ac_op_conv_unit", block, xf, (b, t, c))
+            finally:
+                ctx.set_option("wide_sliced", 1)
+            names = [e["name"] for e in prof.entries]
+            assert any(n.startswith("wide_sliced_out_kernel") for n in names) == (mode == 2), names
+            assert any(n.startswith("conv_unit_wide_kernel") for n in names) == (mode == 0), names
+        assert torch.equal(outs[0], outs[2]), f"{block} C={c} B={b} T={t}: the sliced form differs from the fused kernel"
+        _close(f"sliced {block} B={b} T={t}", G.from_frames(outs[2]), O.conv_unit(ww, block, x), atol=5e-5, rtol=5e-5)
+    # by default a single clip takes the sliced form, a large batch the fused one
+    ctx = codec.network.context()
+    for b, want in ((1, "wide_sliced_out_kernel<256>"), (40, "conv_unit_wide_kernel<256>")):
+        with _capi.profile() as prof:
+            G.op_block(ctx, "l3ac_op_conv_unit", "decoder.blocks.4.1.module", G.to_frames(_rand((b, 256, 900), 7)), (b, 900, 256))
+        assert want in [e["name"] for e in prof.entries]
+
+
 def test_conv_units_wide_scratch_on_a_fresh_context():
     """The wide ConvUnit's front end writes bf16x3 planes of WHOLE 32-frame tiles (conv_unit_wide_scratch_bytes) into the
     hidden scratch: more than the 4C floats per row that scratch is otherwise sized by when batch * frames < 12.  On a
