@@ -1066,11 +1066,13 @@ int launch_wide(hipStream_t s, const ConvUnitW& w, const float* x, float* y, uns
     }
     char name[64];
     if constexpr (!G::FRONT) {
-        std::snprintf(name, sizeof(name), "dwconv_ln_split_kernel<%d>", C);
-        ProfScope prof(s, name, (double)rows * 30.0 * C, (double)rows * 10.0 * C);
-        constexpr int IMG = (C / 16) * 3072;
-        hipLaunchKernelGGL((dwconv_ln_split_kernel<C>), dim3((unsigned)ceil_div64(rows, 32)), dim3(256), IMG, s, w, x, planes, rows, frames);
-        L3AC_LAUNCH_CHECK();
+        {
+            std::snprintf(name, sizeof(name), "dwconv_ln_split_kernel<%d>", C);
+            ProfScope prof(s, name, (double)rows * 30.0 * C, (double)rows * 10.0 * C);
+            constexpr int IMG = (C / 16) * 3072;
+            hipLaunchKernelGGL((dwconv_ln_split_kernel<C>), dim3((unsigned)ceil_div64(rows, 32)), dim3(256), IMG, s, w, x, planes, rows, frames);
+            L3AC_LAUNCH_CHECK();
+        }
         const int64_t tiles16 = ceil_div64(rows, 16);
         if (sliced_exists(C, rows) && (sliced_mode == 2 || (sliced_mode == 1 && tiles16 <= SLICED_AUTO_TILES))) {
             using S = SGeo<C>;

@@ -480,6 +480,141 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_split_kernel_slices(const Gem
     gemm_epilogue16<1, 2>(p, acc, m0, n0, wave, lane);
 }
 
+// ---- a single clip's products, STREAMED (round 5): every global read of the loop is an LDS-DMA copy, 8 k tiles in flight ---------------
+// The slices form keeps four k tiles in flight in registers and pays ~0.47 us per k tile whatever it multiplies (36 us for 180 x 512 x
+// 2048): one memory latency per four tiles.  Here a workgroup owns 32 rows x 64 columns — wave (rs, cg) = row strip rs of 16, column
+// group cg of 32: the slices form's accumulators — and a k tile is one 16-KB ring slot, copied by global_load_lds_dwordx4 with nothing in
+// registers: wave 0 the A rows (fp32, in FRAGMENT order: lane (row m, k group g) of block (rs, j) fetches the 16 B it will read back,
+// k = 8 g + 4 j .. + 3 of row 16 rs + m), waves 1-3 one plane each of the workgroup's 64 rows of the W tile (verbatim: the image's XOR
+// swizzle only depends on row / 4 mod 4).  PF = 7 or 8 slots stay in flight behind counted waits (four copies per wave and slot), the
+// fragments of tile kt + 1 are read while tile kt multiplies.  Same k order, same six plane products per accumulator in the same order
+// as every other form of this GEMM: same bits.
+__device__ __forceinline__ void dma_1k(const unsigned char* base, unsigned lane_off, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(lane_off), "s"(base), "s"(lds_dst)
+        : "memory");
+}
+template <int N, class F, int I = 0>
+__device__ __forceinline__ void tail_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        tail_for<N, F, I + 1>(static_cast<F&&>(f));
+    }
+}
+constexpr int ST_SLOT = 16384, ST_RING = 9;  // A 4 KB | W plane 0 | plane 1 | plane 2 (4 KB each: 64 rows x 64 B)
+template <int PF>
+__global__ __launch_bounds__(THREADS, 1) void gemm_split_kernel_stream(const GemmArgs p) {
+    static_assert(PF + 1 <= ST_RING && 4 * (PF - 1) <= 63, "ring / counted wait");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_split[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ln = lane & 15, lg = lane >> 4;
+    const int rs = wave & 1, cg = wave >> 1;
+    const int n_blocks = (p.n + 63) / 64;
+    const int64_t m0 = (int64_t)(blockIdx.x / (unsigned)n_blocks) * 32;
+    const int nb = (int)(blockIdx.x % (unsigned)n_blocks);
+    const int n_tiles = p.k / BK;  // (whole k tiles, at least PF of them: the launcher)
+    // this wave's four copies of a slot: global base (wave-uniform), two lane offsets, LDS offset inside the slot
+    const unsigned char* src;
+    int64_t src_step;          // per k tile
+    unsigned lo[2];            // lane offsets of blocks 0-1 and 2-3
+    int blk_step;              // global bytes from a block to the next of the same pair
+    if (wave == 0) {
+        src = reinterpret_cast<const unsigned char*>(p.a);
+        src_step = BK * 4;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int64_t row = m0 + 16 * r + ln;
+            lo[r] = (unsigned)(((row < p.m ? row : 0) * p.lda + 8 * lg) * 4);  // rows past the edge: row 0, never stored
+        }
+        blk_step = 16;  // j = 0, 1: the two 16-B halves of the lane's 32 B
+    } else {
+        src = p.w_img + (int64_t)(nb / 2) * n_tiles * W_TILE + (wave - 1) * W_PLANE + (nb & 1) * 4096;
+        src_step = W_TILE;
+        lo[0] = 16u * (unsigned)lane;
+        lo[1] = 16u * (unsigned)lane + 2048u;
+        blk_step = 1024;
+    }
+    const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_split;
+    auto issue = [&](int kt) __attribute__((always_inline)) {
+        const unsigned char* g = src + (int64_t)kt * src_step;
+        const unsigned dst = ring_lds + (unsigned)((kt % ST_RING) * ST_SLOT + 4096 * wave);
+        dma_1k(g, lo[0], dst);
+        dma_1k(g + blk_step, lo[0], dst + 1024);
+        dma_1k(g, lo[1], dst + 2048);
+        dma_1k(g + blk_step, lo[1], dst + 3072);
+    };
+    float4 fa[2][2];
+    bf16x8 fw[2][2][3];
+    auto fetch = [&](int kt, auto par_) __attribute__((always_inline)) {
+        constexpr int P = decltype(par_)::value;
+        const unsigned char* slot = smem_split + (kt % ST_RING) * ST_SLOT;
+        fa[P][0] = *reinterpret_cast<const float4*>(slot + rs * 2048 + 16 * lane);
+        fa[P][1] = *reinterpret_cast<const float4*>(slot + rs * 2048 + 1024 + 16 * lane);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int pl = 2; pl >= 0; --pl)
+                fw[P][u][pl] = *reinterpret_cast<const bf16x8*>(slot + 4096 + pl * 4096 + tile_off(32 * cg + 16 * u + ln, lg));
+    };
+    f32x4a acc[1][2] = {{f32x4a{0.f, 0.f, 0.f, 0.f}, f32x4a{0.f, 0.f, 0.f, 0.f}}};
+    auto multiply = [&](auto par_) __attribute__((always_inline)) {
+        constexpr int P = decltype(par_)::value;
+        unsigned x0, x1, x2, y0, y1, y2, z0, z1, z2, u0, u1, u2;
+        split2(fa[P][0].x, fa[P][0].y, x0, x1, x2);
+        split2(fa[P][0].z, fa[P][0].w, y0, y1, y2);
+        split2(fa[P][1].x, fa[P][1].y, z0, z1, z2);
+        split2(fa[P][1].z, fa[P][1].w, u0, u1, u2);
+        const u32x4 af[3] = {u32x4{x0, y0, z0, u0}, u32x4{x1, y1, z1, u1}, u32x4{x2, y2, z2, u2}};
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                acc[0][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[PA[q]]), fw[P][u][PB[q]], acc[0][u], 0, 0, 0);
+    };
+    // this wave's copies of slot kt have landed when at most 4 x `after` newer ones are outstanding; then everybody's have, and
+    // everybody's reads of the slot before it are complete (its ring position is the next one to be overwritten)
+    auto landed = [&](auto after_) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * decltype(after_)::value) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+#pragma unroll
+    for (int j = 0; j < PF; ++j) issue(j);
+    landed(std::integral_constant<int, PF - 1>{});
+    fetch(0, P0{});
+    const int main_steps = n_tiles - PF;  // even (the launcher picks PF)
+    for (int kt = 0; kt < main_steps; kt += 2) {
+        issue(kt + PF);
+        landed(std::integral_constant<int, PF - 1>{});
+        fetch(kt + 1, P1{});
+        multiply(P0{});
+        issue(kt + 1 + PF);
+        landed(std::integral_constant<int, PF - 1>{});
+        fetch(kt + 2, P0{});
+        multiply(P1{});
+    }
+    // the last PF tiles: nothing left to request, the counted waits shrink
+    tail_for<PF>([&](auto j_) {
+        constexpr int J = decltype(j_)::value;
+        if constexpr (J + 1 < PF) {
+            landed(std::integral_constant<int, PF - 2 - J>{});
+            fetch(main_steps + J + 1, std::integral_constant<int, (J + 1) & 1>{});
+        }
+        multiply(std::integral_constant<int, J & 1>{});
+    });
+    gemm_epilogue16<1, 2>(p, acc, m0 + 16 * rs, 64 * nb + 32 * cg, 0, lane);
+}
+
 // (The body is written for RG row groups of 16 per wave; RG = 4, i.e. 256-row blocks at two per CU, halves the LDS reads
 // and the W traffic per MFMA and was measured: +3 % on the K = 2048 shapes, -17 % on the K = 512 ones, whose epilogue it doubles.)
 template <bool KTAIL>
@@ -572,6 +707,19 @@ int launch_gemm_split(hipStream_t s, const GemmArgs& g) {
                                2 * W_TILE, s, g, gp);
         else
             hipLaunchKernelGGL(gemm_split_conv_kernel, dim3((unsigned)blocks), dim3(THREADS), 2 * W_TILE, s, g, gp);
+    } else if (g.epi != EPI_GEGLU && !tail && g.k / BK >= 8 && g.lda * g.m < ((int64_t)1 << 29) && ceil_div64(g.m, BM / 2) * ceil_div64(g.n, BN) <= cus / 4) {
+        // a single clip, whole k tiles: the streamed form (32 rows x 64 columns per block); PF of the same parity as the k tiles
+        static PerDeviceOnce configured;
+        if (configured.first()) {
+            L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel_stream<8>), hipFuncAttributeMaxDynamicSharedMemorySize, ST_RING * ST_SLOT));
+            L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel_stream<7>), hipFuncAttributeMaxDynamicSharedMemorySize, ST_RING * ST_SLOT));
+            configured.done();
+        }
+        const unsigned grid = (unsigned)(ceil_div64(g.m, 32) * ceil_div64(g.n, 64));
+        if ((g.k / BK) % 2 == 0)
+            hipLaunchKernelGGL((gemm_split_kernel_stream<8>), dim3(grid), dim3(THREADS), ST_RING * ST_SLOT, s, g);
+        else
+            hipLaunchKernelGGL((gemm_split_kernel_stream<7>), dim3(grid), dim3(THREADS), ST_RING * ST_SLOT, s, g);
     } else if (g.epi != EPI_GEGLU && ceil_div64(g.m, BM / 2) * ceil_div64(g.n, BN) <= cus / 4) {
         // a single clip: column slices (64 rows x 32 columns per block)
         const unsigned grid = (unsigned)(ceil_div64(g.m, 64) * ceil_div64(g.n, 32));

@@ -87,12 +87,14 @@ def test_gemm_split_accuracy():
 
 
 def test_gemm_split_forms_return_the_same_bits():
-    """The bf16x3 GEMM has three launch forms by grid size — 128 x 128 blocks, 64 x 128 blocks with W two k tiles ahead (few blocks),
-    64 x 32 column slices with W and A four k tiles ahead (a single clip's rows) — and a clip's results must not depend on the batch
-    it arrives in: the same rows through a large call and through calls of 180 / 60 / 1 rows, bit for bit (also k % 32 != 0, n not a
-    multiple of 128 or 32)."""
+    """The bf16x3 GEMM has four launch forms by grid size and shape — 128 x 128 blocks, 64 x 128 blocks with W two k tiles ahead (few
+    blocks), and for a single clip's rows 32 x 64 blocks whose operands stream through an LDS-DMA ring (round 5: whole k tiles, at
+    least eight of them; seven or eight in flight by the parity of their number) or 64 x 32 column slices with W and A four k tiles
+    ahead in registers (the rest) — and a clip's results must not depend on the batch it arrives in: the same rows through a large
+    call and through calls of 180 / 60 / 1 rows, bit for bit (also k % 32 != 0, n not a multiple of 128 or 32, odd and even numbers of
+    k tiles, exactly eight k tiles)."""
     g = torch.Generator().manual_seed(41)
-    for n, k in ((512, 2048), (2048, 512), (256, 512), (192, 96), (200, 40), (128 * 3, 1032)):
+    for n, k in ((512, 2048), (2048, 512), (256, 512), (192, 96), (200, 40), (128 * 3, 1032), (192, 288), (320, 352), (200, 256), (256, 544)):
         m_big = 128 * 2 * (256 // max(1, n // 128) + 1)   # more 128 x 128 blocks than the chip has CUs
         a = torch.randn(m_big, k, generator=g)
         w = torch.randn(n, k, generator=g) * 0.1
