@@ -615,6 +615,100 @@ __global__ __launch_bounds__(THREADS, 1) void gemm_split_kernel_stream(const Gem
     gemm_epilogue16<1, 2>(p, acc, m0 + 16 * rs, 64 * nb + 32 * cg, 0, lane);
 }
 
+// The NARROW streamed form: 32 rows x 16 columns per workgroup, for products whose 32 x 64 grid would leave most of the chip idle while
+// each workgroup pulls a megabyte through its CU (180 x 512 x 2048: 48 workgroups, 23 us at the ~45 GB/s a CU's LDS-DMA copies land at;
+// here 192 workgroups of 448 KB).  A ring slot is FOUR k tiles (28 KB: per k tile the A rows as above and the 16 rows of each W plane,
+// 1 KB each); wave v copies k tile v of every slot (seven copies), waves 0 and 1 multiply (row strip = wave, one accumulator tile, the
+// six plane products of a k tile in the usual order, k tiles in order: same bits), one barrier per four k tiles.  Bias / residual epilogues.
+constexpr int SN_KT = 7168, SN_SLOT = 4 * SN_KT, SN_RING = 5, SN_PF = SN_RING - 1;
+__global__ __launch_bounds__(THREADS, 1) void gemm_split_kernel_stream_narrow(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_split[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ln = lane & 15, lg = lane >> 4;
+    const int n_blocks = (p.n + 15) / 16;
+    const int64_t m0 = (int64_t)(blockIdx.x / (unsigned)n_blocks) * 32;
+    const int nb = (int)(blockIdx.x % (unsigned)n_blocks);
+    const int n_tiles = p.k / BK, n_slots = n_tiles / 4;  // (whole slots, at least SN_PF of them: the launcher)
+    unsigned lo[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int64_t row = m0 + 16 * r + ln;
+        lo[r] = (unsigned)(((row < p.m ? row : 0) * p.lda + 8 * lg) * 4);  // rows past the edge: row 0, never stored
+    }
+    const unsigned char* const a_src = reinterpret_cast<const unsigned char*>(p.a) + (int64_t)wave * (BK * 4);
+    const unsigned char* const w_src = p.w_img + ((int64_t)(nb / 8) * n_tiles + wave) * W_TILE + (nb & 7) * 1024;
+    const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_split;
+    auto issue = [&](int q) __attribute__((always_inline)) {  // this wave's k tile 4 q + wave of slot q
+        const unsigned char* ga = a_src + (int64_t)q * (4 * BK * 4);
+        const unsigned char* gw = w_src + (int64_t)q * (4 * W_TILE);
+        const unsigned dst = ring_lds + (unsigned)((q % SN_RING) * SN_SLOT + SN_KT * wave);
+        dma_1k(ga, lo[0], dst);
+        dma_1k(ga + 16, lo[0], dst + 1024);
+        dma_1k(ga, lo[1], dst + 2048);
+        dma_1k(ga + 16, lo[1], dst + 3072);
+        dma_1k(gw, 16u * (unsigned)lane, dst + 4096);
+        dma_1k(gw + W_PLANE, 16u * (unsigned)lane, dst + 5120);
+        dma_1k(gw + 2 * W_PLANE, 16u * (unsigned)lane, dst + 6144);
+    };
+    f32x4a acc = {0.f, 0.f, 0.f, 0.f};
+    auto multiply = [&](int q) __attribute__((always_inline)) {
+        if (wave >= 2) return;
+        const unsigned char* slot = smem_split + (q % SN_RING) * SN_SLOT;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const unsigned char* t = slot + kk * SN_KT;
+            const float4 f0 = *reinterpret_cast<const float4*>(t + wave * 2048 + 16 * lane);
+            const float4 f1 = *reinterpret_cast<const float4*>(t + wave * 2048 + 1024 + 16 * lane);
+            bf16x8 fw[3];
+#pragma unroll
+            for (int pl = 2; pl >= 0; --pl) fw[pl] = *reinterpret_cast<const bf16x8*>(t + 4096 + pl * 1024 + tile_off(ln, lg));
+            unsigned x0, x1, x2, y0, y1, y2, z0, z1, z2, u0, u1, u2;
+            split2(f0.x, f0.y, x0, x1, x2);
+            split2(f0.z, f0.w, y0, y1, y2);
+            split2(f1.x, f1.y, z0, z1, z2);
+            split2(f1.z, f1.w, u0, u1, u2);
+            const u32x4 af[3] = {u32x4{x0, y0, z0, u0}, u32x4{x1, y1, z1, u1}, u32x4{x2, y2, z2, u2}};
+            constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+            for (int m = 0; m < 6; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[PA[m]]), fw[PB[m]], acc, 0, 0, 0);
+        }
+    };
+    // slot q has landed for this wave when at most 7 x `after` newer copies are outstanding; then for everybody — and everybody's
+    // reads of slot q - 1, whose ring position the next request overwrites, are complete
+    auto landed = [&](auto after_) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(7 * decltype(after_)::value) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+#pragma unroll
+    for (int j = 0; j < SN_PF; ++j) issue(j);
+    const int main_steps = n_slots - SN_PF;
+    for (int q = 0; q < main_steps; ++q) {
+        landed(std::integral_constant<int, SN_PF - 1>{});
+        issue(q + SN_PF);
+        multiply(q);
+    }
+    tail_for<SN_PF>([&](auto j_) {
+        constexpr int J = decltype(j_)::value;
+        landed(std::integral_constant<int, SN_PF - 1 - J>{});
+        multiply(main_steps + J);
+    });
+    if (wave >= 2) return;
+    const int col = 16 * nb + ln;
+    if (col >= p.n) return;
+    const float bias = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t m = m0 + 16 * wave + 4 * lg + i;
+        if (m >= p.m) continue;
+        float v = acc[i] + bias;
+        if (p.epi == EPI_BIAS_RES) v = p.res[m * p.ldres + col] + v;
+        c_store(p.c + m * p.ldc + col, v);
+    }
+}
+
 // (The body is written for RG row groups of 16 per wave; RG = 4, i.e. 256-row blocks at two per CU, halves the LDS reads
 // and the W traffic per MFMA and was measured: +3 % on the K = 2048 shapes, -17 % on the K = 512 ones, whose epilogue it doubles.)
 template <bool KTAIL>
@@ -713,10 +807,13 @@ int launch_gemm_split(hipStream_t s, const GemmArgs& g) {
         if (configured.first()) {
             L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel_stream<8>), hipFuncAttributeMaxDynamicSharedMemorySize, ST_RING * ST_SLOT));
             L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel_stream<7>), hipFuncAttributeMaxDynamicSharedMemorySize, ST_RING * ST_SLOT));
+            L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel_stream_narrow), hipFuncAttributeMaxDynamicSharedMemorySize, SN_RING * SN_SLOT));
             configured.done();
         }
         const unsigned grid = (unsigned)(ceil_div64(g.m, 32) * ceil_div64(g.n, 64));
-        if ((g.k / BK) % 2 == 0)
+        if ((g.epi == EPI_BIAS || g.epi == EPI_BIAS_RES) && g.k % (4 * BK) == 0 && g.k / (4 * BK) >= SN_PF && 2 * grid <= (unsigned)cus)
+            hipLaunchKernelGGL(gemm_split_kernel_stream_narrow, dim3((unsigned)(ceil_div64(g.m, 32) * ceil_div64(g.n, 16))), dim3(THREADS), SN_RING * SN_SLOT, s, g);
+        else if ((g.k / BK) % 2 == 0)
             hipLaunchKernelGGL((gemm_split_kernel_stream<8>), dim3(grid), dim3(THREADS), ST_RING * ST_SLOT, s, g);
         else
             hipLaunchKernelGGL((gemm_split_kernel_stream<7>), dim3(grid), dim3(THREADS), ST_RING * ST_SLOT, s, g);
