@@ -352,12 +352,15 @@ void trans_stack_kernel(const TransStackArgs p) {
         for (int t = 0; t < 8; ++t) yacc[t] = index == 0 ? tacc[t] : yacc[t] + tacc[t];
     };
     auto coop_combine = [&]() __attribute__((always_inline)) {  // KS > 1: tacc (this workgroup's partial) -> yacc (the sum of all six)
-        // byte offset of this lane's 16 B of tile t in partial k of the phase's slab: + 64 t + k * 192 * 512
-        const unsigned slab_off = (unsigned)(coop_phase & 1) * (unsigned)(TS_KS * 192 * TS_DIM * 4) + (unsigned)(frame_ok ? frame : 0) * (TS_DIM * 4) + 16u * (unsigned)lg;
+        // byte offset of this lane's 16 B of tile t in partial k of the phase's slab: + 192 * 64 t + k * 192 * 512.  A partial is laid out
+        // [tile 8][frame 192][64 B]: one wave instruction (16 frames x 4 groups x 16 B) then covers 1 KB of whole 128-B lines; in the
+        // tensor's own [frame][128] order it touched 16 half lines, and the exchange is bound by the line requests of these
+        // L1-bypassing accesses, not by where the lines are
+        const unsigned slab_off = (unsigned)(coop_phase & 1) * (unsigned)(TS_KS * 192 * TS_DIM * 4) + (unsigned)(frame_ok ? frame : 0) * 64u + 16u * (unsigned)lg;
         if (frame_ok) {
 #pragma unroll
             for (int t = 0; t < 8; ++t)  // write-through (sc1) 16-byte stores: the bytes are in memory when the wait below returns
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, tacc[t]), slab_rsrc, slab_off + (unsigned)part * (192 * TS_DIM * 4) + 64 * t, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, tacc[t]), slab_rsrc, slab_off + (unsigned)part * (192 * TS_DIM * 4) + (192 * 64) * t, 0, 16);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (also drains this wave's LDS-DMAs: the ring refills behind the exchange)
         __builtin_amdgcn_s_barrier();                      // every wave's stores have left
@@ -399,7 +402,7 @@ void trans_stack_kernel(const TransStackArgs p) {
                 for (int k = 0; k < TS_KS; ++k)
 #pragma unroll
                     for (int tt = 0; tt < TB; ++tt)
-                        v[k][tt] = __builtin_amdgcn_raw_buffer_load_b128(slab_rsrc, slab_off + (unsigned)k * (192 * TS_DIM * 4) + 64 * (tb + tt), 0, 16);
+                        v[k][tt] = __builtin_amdgcn_raw_buffer_load_b128(slab_rsrc, slab_off + (unsigned)k * (192 * TS_DIM * 4) + (192 * 64) * (tb + tt), 0, 16);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int tt = 0; tt < TB; ++tt) {
