@@ -160,7 +160,9 @@ void trans_stack_kernel(const TransStackArgs p) {
     float* const xtrue = xclip + (int64_t)(frame_ok ? frame : 0) * TS_DIM + 4 * lg;  // + 16 t: this lane's 4 channels of tile t
     // where this workgroup keeps the residual stream between sub-layers: the tensor itself, or (cooperative form: six workgroups
     // hold the same stream and none may see another's update early) a private copy
-    float* const xlane = COOP ? p.coop_x + ((int64_t)clip * TS_KS + part) * (192 * TS_DIM) + (int64_t)(frame_ok ? frame : 0) * TS_DIM + 4 * lg : xtrue;
+    // (the private copy is laid out [tile 8][frame 192][16]: a wave instruction covers 1 KB of whole lines, as for the slabs below)
+    constexpr int XT = COOP ? 192 * 16 : 16;  // floats from tile t to tile t + 1 of this lane's frame
+    float* const xlane = COOP ? p.coop_x + ((int64_t)clip * TS_KS + part) * (192 * TS_DIM) + (int64_t)(frame_ok ? frame : 0) * 16 + 4 * lg : xtrue;
     float* const bias_s = reinterpret_cast<float*>(smem_ts + L::OFF_BIAS);
     float* const ln_s = reinterpret_cast<float*>(smem_ts + L::OFF_LN);
 
@@ -173,7 +175,7 @@ void trans_stack_kernel(const TransStackArgs p) {
     for (int t = 0; t < 8; ++t) {
         xr[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         if (frame_ok) xr[t] = *reinterpret_cast<const f32x4_t*>(xtrue + 16 * t);
-        if (COOP && frame_ok) *reinterpret_cast<f32x4_t*>(xlane + 16 * t) = xr[t];
+        if (COOP && frame_ok) *reinterpret_cast<f32x4_t*>(xlane + XT * t) = xr[t];
     }
     // distance bias (distances 0 .. frames - 1 of every head) and the stack's LayerNorm parameters
     for (int i = tid; i < TS_HEADS * TS_MAX_FRAMES; i += blockDim.x) {
@@ -423,9 +425,9 @@ void trans_stack_kernel(const TransStackArgs p) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             f32x4_t xv = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            if (frame_ok) xv = *reinterpret_cast<const f32x4_t*>(xlane + 16 * t);
+            if (frame_ok) xv = *reinterpret_cast<const f32x4_t*>(xlane + XT * t);
             xr[t] = xv + yacc[t];
-            if (frame_ok) *reinterpret_cast<f32x4_t*>(xlane + 16 * t) = xr[t];
+            if (frame_ok) *reinterpret_cast<f32x4_t*>(xlane + XT * t) = xr[t];
         }
     };
 
