@@ -214,6 +214,163 @@ __global__ __launch_bounds__(THREADS, BK == 16 ? 3 : 2) void gemm_f32_kernel(con
     gemm_epilogue<NT>(p, acc, m0, n0, wave, li, lh);
 }
 
+// ---- a single clip's products (a streaming chunk: 2-43 blocks of the kernel above) --------------------------------------------------
+// v_mfma_f32_32x32x2_f32 retires two k per 64 cycles into ONE accumulator: a wave's chain over K = 576 is 288 dependent instructions =
+// 18 k cycles, 9 us, whatever feeds it (180 x 128 x 576 on 8 workgroups: 23 us).  v_mfma_f32_16x16x4_f32 is the same arithmetic — per
+// output element the k-ordered chain of fused multiply-adds, its four k in lane-group order (tools/probes/mfma_f32_order_probe.hip:
+// 0 of 204 800 outputs differ from the fmaf chain, for either instruction) — at four k per 32 cycles.  Here: 64 x (32 NT) blocks, wave w =
+// rows 16 w .. 16 w + 15, two 16-column accumulators per 32 columns (independent chains: back-to-back issue), the k tiles FOUR ahead
+// through four register sets (nothing else covers a fetch with one wave per SIMD), the same LDS tiles and swizzle as above.  The k
+// sequence of the kernel above is kept — inside a group of 8: 0, 4, 1, 5, 2, 6, 3, 7 — by giving lane group g of instruction j the
+// element k = 8 q + 4 (g & 1) + (g >> 1) + 2 j of the 16 B it reads: same bits (tested against the large-grid form).
+typedef float f32x4acc __attribute__((ext_vector_type(4)));
+template <int NT, bool CONV, bool FULLK>
+__global__ __launch_bounds__(THREADS, 1) void gemm_f32_small_kernel(const GemmArgs p) {
+    constexpr int BK = 32, BMS = 64, BN = 32 * NT, D = 4;
+    constexpr int CPR = BK / 4, RP = THREADS / CPR, AP = BMS / RP, WP = (BN + RP - 1) / RP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                  // [2][BMS * BK]
+    float* Ws = smem + 2 * BMS * BK;   // [2][BN * BK]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_blocks = (p.n + BN - 1) / BN;
+    const int64_t m0 = (int64_t)(blockIdx.x / (unsigned)n_blocks) * BMS;
+    const int n0 = (int)(blockIdx.x % (unsigned)n_blocks) * BN;
+    const int cc = tid % CPR;
+    const int r0 = tid / CPR;
+    const float* a_row[AP];
+    int a_t[AP];
+    bool a_ok[AP];
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+        const int64_t m = m0 + r0 + RP * i;
+        a_ok[i] = m < p.m;
+        const int64_t mm = a_ok[i] ? m : 0;
+        a_t[i] = CONV ? (int)((unsigned)mm % (unsigned)p.frames) : 0;
+        a_row[i] = p.a + mm * p.lda;
+    }
+    const float* w_row[WP];
+    bool w_ok[WP];
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+        const int nl = r0 + RP * i;
+        const int n = n0 + nl;
+        w_ok[i] = nl < BN && n < p.n;
+        w_row[i] = p.w + (int64_t)(w_ok[i] ? n : 0) * p.ldw;
+    }
+    int tap = 0, ch = 4 * cc;
+    if (CONV) {
+        while (ch >= p.cin) { ch -= p.cin; ++tap; }
+    }
+    const int half = p.taps >> 1;
+    float4 a_regs[D][AP], w_regs[D][WP];
+    auto load_tile = [&](int k_tile, auto set_) __attribute__((always_inline)) {  // (requested in order: the conv's (tap, channel) bookkeeping advances)
+        float4 (&a_reg)[AP] = a_regs[decltype(set_)::value];
+        float4 (&w_reg)[WP] = w_regs[decltype(set_)::value];
+        const int k = k_tile + 4 * cc;
+        const bool k_ok = k < p.k;
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (CONV) {
+                const int ts = a_t[i] + (tap - half) * p.dil;
+                if (a_ok[i] && k_ok && ts >= 0 && ts < p.frames)
+                    v = *reinterpret_cast<const float4*>(a_row[i] + (int64_t)(tap - half) * p.dil * p.lda + ch);
+            } else if (FULLK) {
+                v = *reinterpret_cast<const float4*>(a_row[i] + k);
+            } else {
+                if (a_ok[i] && k_ok) v = *reinterpret_cast<const float4*>(a_row[i] + k);
+            }
+            a_reg[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < WP; ++i) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (FULLK) {
+                v = *reinterpret_cast<const float4*>(w_row[i] + k);
+            } else if (w_ok[i] && k_ok) {
+                v = *reinterpret_cast<const float4*>(w_row[i] + k);
+            }
+            w_reg[i] = v;
+        }
+        if (CONV) {
+            ch += BK;
+            while (ch >= p.cin) { ch -= p.cin; ++tap; }
+        }
+    };
+    auto store_tile = [&](int buf, auto set_) __attribute__((always_inline)) {
+        const float4 (&a_reg)[AP] = a_regs[decltype(set_)::value];
+        const float4 (&w_reg)[WP] = w_regs[decltype(set_)::value];
+        float* as = As + buf * BMS * BK;
+        float* ws = Ws + buf * BN * BK;
+#pragma unroll
+        for (int i = 0; i < AP; ++i) *reinterpret_cast<float4*>(as + lds_off<BK>(r0 + RP * i, cc)) = a_reg[i];
+#pragma unroll
+        for (int i = 0; i < WP; ++i)
+            if (r0 + RP * i < BN) *reinterpret_cast<float4*>(ws + lds_off<BK>(r0 + RP * i, cc)) = w_reg[i];
+    };
+    f32x4acc acc[2 * NT];
+#pragma unroll
+    for (int i = 0; i < 2 * NT; ++i) acc[i] = f32x4acc{0.f, 0.f, 0.f, 0.f};
+    const int li = lane & 15, lg = lane >> 4;
+    const int lh = lg & 1;         // which 16-B half of a group of 8 this lane reads
+    const bool odd = (lg >> 1) != 0;  // elements 1, 3 of it (else 0, 2)
+    const int n_tiles = (p.k + BK - 1) / BK;
+    auto step = [&](int kt, auto set_) __attribute__((always_inline)) {
+        constexpr int set = decltype(set_)::value;
+        using Next = std::integral_constant<int, (set + 1) % D>;
+        const int buf = kt & 1;
+        const bool more = kt + 1 < n_tiles;
+        if (kt + D < n_tiles) load_tile((kt + D) * BK, set_);
+        const float* as = As + buf * BMS * BK;
+        const float* ws = Ws + buf * BN * BK;
+#pragma unroll
+        for (int q = 0; q < BK / 8; ++q) {
+            const int chunk = 2 * q + lh;
+            const float4 af = *reinterpret_cast<const float4*>(as + lds_off<BK>(16 * wave + li, chunk));
+            const float a0 = odd ? af.y : af.x, a1 = odd ? af.w : af.z;
+#pragma unroll
+            for (int ct = 0; ct < 2 * NT; ++ct) {
+                const float4 bf = *reinterpret_cast<const float4*>(ws + lds_off<BK>(16 * ct + li, chunk));
+                const float b0 = odd ? bf.y : bf.x, b1 = odd ? bf.w : bf.z;
+                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[ct], 0, 0, 0);
+                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[ct], 0, 0, 0);
+            }
+            if (q == BK / 16 - 1 && more) store_tile(buf ^ 1, Next{});
+        }
+        __syncthreads();
+    };
+    using S0 = std::integral_constant<int, 0>;
+    load_tile(0, S0{});
+    store_tile(0, S0{});
+    if (1 < n_tiles) load_tile(1 * BK, std::integral_constant<int, 1>{});
+    if (2 < n_tiles) load_tile(2 * BK, std::integral_constant<int, 2>{});
+    if (3 < n_tiles) load_tile(3 * BK, std::integral_constant<int, 3>{});
+    __syncthreads();
+    for (int kt = 0; kt < n_tiles; kt += 4) {
+        step(kt, S0{});
+        if (kt + 1 < n_tiles) step(kt + 1, std::integral_constant<int, 1>{});
+        if (kt + 2 < n_tiles) step(kt + 2, std::integral_constant<int, 2>{});
+        if (kt + 3 < n_tiles) step(kt + 3, std::integral_constant<int, 3>{});
+    }
+    // acc[ct][r] = c[m0 + 16 wave + 4 lg + r][n0 + 16 ct + li]; bias / residual epilogues (the others stay with the kernel above)
+#pragma unroll
+    for (int ct = 0; ct < 2 * NT; ++ct) {
+        const int n = n0 + 16 * ct + li;
+        if (n >= p.n) continue;
+        const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t m = m0 + 16 * wave + 4 * lg + r;
+            if (m >= p.m) continue;
+            float v = acc[ct][r] + bias;
+            if (p.epi == EPI_BIAS_RES) v = p.res[m * p.ldres + n] + v;
+            p.c[m * p.ldc + n] = v;
+        }
+    }
+}
+
 // (An LDS-DMA staged variant — global_load_lds, three LDS stages — was measured equal to the register-staged kernel in round 2 and
 // retired in round 5: git show 782323b:l3ac_amd/csrc/kernels/gemm_f32.hip.)
 template <int NT, bool CONV, int BK>
@@ -235,6 +392,17 @@ int launch_one(hipStream_t s, const GemmArgs& g) {
         if (g.gate_yi) {
             L3AC_REQUIRE(fullk, "gemm: the gated A operand needs k %% 16 == 0 (k=%d)", g.k);
             hipLaunchKernelGGL((gemm_f32_kernel<NT, false, 16, true, true>), dim3((unsigned)blocks), dim3(THREADS), lds, s, g);
+            L3AC_LAUNCH_CHECK();
+            return L3AC_OK;
+        }
+    }
+    if constexpr (BK == 32) {
+        // a single clip (at most a block per four CUs) with a bias / residual epilogue: the 16x16x4 form (same bits)
+        if ((g.epi == EPI_BIAS || g.epi == EPI_BIAS_RES) && 4 * blocks <= l3ac_device_cu_count()) {
+            const unsigned grid = (unsigned)(ceil_div64(g.m, 64) * ceil_div64(g.n, BN));
+            const size_t lds_s = (size_t)2 * (64 + BN) * 32 * sizeof(float);
+            if (fullk) hipLaunchKernelGGL((gemm_f32_small_kernel<NT, false, true>), dim3(grid), dim3(THREADS), lds_s, s, g);
+            else hipLaunchKernelGGL((gemm_f32_small_kernel<NT, CONV, false>), dim3(grid), dim3(THREADS), lds_s, s, g);
             L3AC_LAUNCH_CHECK();
             return L3AC_OK;
         }

@@ -105,6 +105,27 @@ def test_gemm_split_forms_return_the_same_bits():
             assert torch.equal(small, big[:rows]), f"n={n} k={k}: {rows} rows alone differ from the same rows of a {m_big}-row call"
 
 
+def test_gemm_f32_forms_return_the_same_bits():
+    """The exact-fp32 GEMM has two instruction forms — v_mfma_f32_32x32x2_f32 on 128-row blocks, and for a single clip's rows
+    v_mfma_f32_16x16x4_f32 on 64-row blocks with the k tiles four ahead (round 5) — that must return the same bits: both are per output
+    the k-ordered chain of fused multiply-adds, fed the same k sequence (tools/probes/mfma_f32_order_probe.hip).  The same rows through a
+    large call and through calls of a single clip's size, for the shapes of the streaming chunk's down convs (k % 32 != 0 among them),
+    with mixed magnitudes so that every rounding step shows; and against the fp64 product."""
+    g = torch.Generator().manual_seed(43)
+    for n, k in ((128, 576), (48, 144), (96, 240), (128, 384), (32, 36), (100, 72)):
+        m_big = 128 * (1100 // max(1, -(-n // 32)))   # more blocks than a quarter of the chip's CUs: the large-grid form
+        a = torch.randn(m_big, k, generator=g) * torch.pow(10.0, torch.randint(-3, 3, (m_big, k), generator=g).float())
+        w = torch.randn(n, k, generator=g) * 0.1
+        b = torch.randn(n, generator=g)
+        big = G.gemm(a.cuda(), w.cuda(), b.cuda()).cpu()
+        for rows in (180, 60, 1, 540, 65):
+            small = G.gemm(a[:rows].contiguous().cuda(), w.cuda(), b.cuda()).cpu()
+            assert torch.equal(small, big[:rows]), f"n={n} k={k}: {rows} rows alone differ from the same rows of a {m_big}-row call"
+        ref = a[:540].double() @ w.double().T + b.double()
+        mag = a[:540].abs().double() @ w.abs().double().T + b.abs().double()
+        assert float(((big[:540].double() - ref).abs() / mag).max()) < 2.0 ** -20
+
+
 def test_gemm_split_cancellation_and_underflow():
     """Adversarial operands for the bf16x3 split GEMM, with an ABSOLUTE bound per output: |err| <= 2^-20 * sum|a.w|.  (2^-23 was
     asked for; measured on these K = 1024 shapes the k-ordered fp32 MFMA chain itself — the kernel the split route replaces —
