@@ -353,7 +353,13 @@ void trans_stack_kernel(const TransStackArgs p) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) yacc[t] = index == 0 ? tacc[t] : yacc[t] + tacc[t];
     };
+    constexpr bool XPRE = COOP && MAXW <= 8;  // (at 12 waves — 168 registers — the eight rows spill)
+    f32x4_t xpre[XPRE ? 8 : 1];  // cooperative form: the residual rows, requested before the exchange and added after it
     auto coop_combine = [&]() __attribute__((always_inline)) {  // KS > 1: tacc (this workgroup's partial) -> yacc (the sum of all six)
+        if constexpr (XPRE) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) xpre[t] = frame_ok ? *reinterpret_cast<const f32x4_t*>(xlane + XT * t) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
         // byte offset of this lane's 16 B of tile t in partial k of the phase's slab: + 192 * 64 t + k * 192 * 512.  A partial is laid out
         // [tile 8][frame 192][64 B]: one wave instruction (16 frames x 4 groups x 16 B) then covers 1 KB of whole 128-B lines; in the
         // tensor's own [frame][128] order it touched 16 half lines, and the exchange is bound by the line requests of these
@@ -425,7 +431,11 @@ void trans_stack_kernel(const TransStackArgs p) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             f32x4_t xv = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            if (frame_ok) xv = *reinterpret_cast<const f32x4_t*>(xlane + XT * t);
+            if constexpr (XPRE) {
+                xv = xpre[t];
+            } else {
+                if (frame_ok) xv = *reinterpret_cast<const f32x4_t*>(xlane + XT * t);
+            }
             xr[t] = xv + yacc[t];
             if (frame_ok) *reinterpret_cast<f32x4_t*>(xlane + XT * t) = xr[t];
         }
