@@ -563,8 +563,8 @@ def fsq_microbench(codec, dev, n_tokens=1 << 22, window=20, rounds=5, min_warm_s
         cgbs = to_gbs(cms)
         out["copy_ceiling"] = {"achieved": cgbs, "unit": "GB/s", "frac_of_peak": cgbs / PEAK_HBM_GBS, "ms": cms,
                                "rounds_gbs": [round(to_gbs(v), 1) for v in c_ms],
-                               "what": "fsq_copy_ceiling_kernel: fsq_kernel's grid (3 workgroups per CU), token order and per-lane "
-                                       "non-temporal loads / stores incl. the 4-B and 24-B side outputs, no arithmetic"}
+                               "what": "fsq_copy_ceiling_kernel: the grid and residency of the kernel it is measured beside (fsq_forward128_kernel), "
+                                       "its token order and per-lane non-temporal loads / stores incl. the 4-B and 24-B side outputs, no arithmetic"}
         out["frac_of_copy_ceiling"] = statistics.median([c / k for k, c in zip(k_ms, c_ms)])
         out["frac_of_copy_ceiling_rounds"] = [round(c / k, 4) for k, c in zip(k_ms, c_ms)]
     return out
