@@ -273,7 +273,7 @@ int l3ac_ctx_set_gemm_split(l3ac_ctx* ctx, int32_t enable);
  * "coop_test_fault" (test hook, default 0): j + 1 makes workgroup j of every clip withhold its first arrival.
  * "down_fused" (default 0): the encoder down layers 24 -> 48 and 48 -> 96 (Conv1d(k = stride) + ChannelNorm) in one kernel on the
  * bf16x3 route instead of an fp32-MFMA GEMM + row kernel: faster, equally accurate, a different rounding of those layers.
- * "wide_sliced" (default 1): the wide ConvUnits (C = 128 .. 256) of few frames — up to 256 tiles of 16, a streaming chunk — as two
+ * "wide_sliced" (default 1): the wide ConvUnits (C = 96 .. 256) of few frames — up to 256 tiles of 16, a streaming chunk — as two
  * launches over frame tiles x channel slices instead of the fused kernel whose waves own their frames end to end; 0 never, 2 wherever
  * the form exists.  The same bits either way.
  * Unknown names return L3AC_EINVAL. */

@@ -870,11 +870,12 @@ struct SGeo {
     using G = WGeo<C>;
     static constexpr int PIECES = C / 16;        // pieces of W1(nt) (k block b, hidden half hh) / of W2(nt) (output row tile rt)
     static constexpr int T1 = PIECES * 3072;     // bytes of W1(nt) = bytes of W2(nt)
-    static constexpr int GH = C >= 256 ? 2 : 1;  // hidden tiles per workgroup of the first kernel
+    static constexpr int GH = C >= 256 ? 2 : C <= 96 ? 4 : 1;  // hidden tiles per workgroup of the first kernel (C = 96: its front end is
+                                                                // computed by every workgroup of a frame group — three of them)
     static constexpr int LDS1 = GH * T1;
     static constexpr int RING = 12, PF = RING - 1, SLOT = 4 * 3072;
     static constexpr int LDS2 = RING * SLOT;
-    static_assert(T1 % (4 * 3072) == 0 && G::NT % GH == 0 && G::RT % 2 == 0 && LDS1 <= 160 * 1024 && LDS2 <= 160 * 1024, "bad geometry");
+    static_assert(G::NT % GH == 0 && G::RT % 2 == 0 && G::NT >= RING && LDS1 <= 160 * 1024 && LDS2 <= 160 * 1024, "bad geometry");
     // byte offsets inside conv_unit_wide_image: W1(0) | W1(1) W2(0) | ... | W1(NT-1) W2(NT-2) | W2(NT-1)
     __host__ __device__ static constexpr int64_t w1_off(int nt) { return nt == 0 ? 0 : (int64_t)T1 * (2 * nt - 1); }
     __host__ __device__ static constexpr int64_t w2_off(int nt) { return nt == G::NT - 1 ? (int64_t)T1 * (2 * G::NT - 1) : (int64_t)T1 * 2 * (nt + 1); }
@@ -882,9 +883,11 @@ struct SGeo {
 
 // hid: [hidden tile nt][frame tile of 16][plane][1 KB]: lane (frame n = lane & 15, k group g = lane >> 4) owns 16 B = the hidden channels
 // 32 nt + sigma(g, j) of its frame, the B operand of the second product (conv_unit_wide_image, W2)
+// (WGeo::FRONT, C = 96: no plane image — the front end runs here, wide_front as in the fused kernel's pass prologue: x / rows / frames)
 template <int C>
 __global__ __launch_bounds__(256, 1) void wide_sliced_hidden_kernel(const ConvUnitW w, const unsigned char* __restrict__ planes,
-                                                                    unsigned char* __restrict__ hid, const int64_t tiles16, const int64_t tiles_pad) {
+                                                                    unsigned char* __restrict__ hid, const int64_t tiles16, const int64_t tiles_pad,
+                                                                    const float* __restrict__ x, const int64_t rows, const int frames) {
     using G = WGeo<C>;
     using S = SGeo<C>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_wide[];
@@ -896,20 +899,23 @@ __global__ __launch_bounds__(256, 1) void wide_sliced_hidden_kernel(const ConvUn
     const int nt0 = (int)(blockIdx.x % (unsigned)HG) * S::GH;
     const int64_t tile = (int64_t)(blockIdx.x / (unsigned)HG) * 4 + wave;
     const bool tile_ok = tile < tiles16;
-    // the weights of this workgroup's hidden tiles, all in flight at once: wave v copies bytes [T1 / 4 v, T1 / 4 (v + 1)) of each
+    // the weights of this workgroup's hidden tiles, all in flight at once: the 3-KB pieces of every tile dealt round-robin to the waves
     {
         const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_wide;
-        constexpr int Q = S::T1 / 4;
 #pragma unroll
         for (int g = 0; g < S::GH; ++g)
 #pragma unroll
-            for (int j = 0; j < Q / 3072; ++j)
-                dma_slot_quarter<3>(w.wide_img + S::w1_off(nt0 + g) + Q * wave + 3072 * j, 16u * (unsigned)lane,
-                                    lds0 + (unsigned)(g * S::T1 + Q * wave + 3072 * j));
+            for (int j = 0; j < (S::PIECES + 3) / 4; ++j) {
+                const int piece = wave + 4 * j;  // (wave-uniform)
+                if (S::PIECES % 4 == 0 || piece < S::PIECES)
+                    dma_slot_quarter<3>(w.wide_img + S::w1_off(nt0 + g) + 3072 * piece, 16u * (unsigned)lane, lds0 + (unsigned)(g * S::T1 + 3072 * piece));
+            }
     }
     // LayerNorm(dw_conv7(x)) of this wave's 16 frames, split (dwconv_ln_split_kernel): k block b, plane p = one 1-KB block
     bf16x8 ap[C / 32][3];
-    {
+    if constexpr (G::FRONT) {
+        wide_front<C, 1>(w, x, rows, frames, tile * 16, tile_ok, lane & 15, lg, ap);
+    } else {
         const int64_t tl = tile_ok ? tile : 0;
         const unsigned char* src = planes + (tl >> 1) * (int64_t)(G::NS1 * 3072) + (int)(tl & 1) * 3072 + 16 * lane;
 #pragma unroll
@@ -1044,7 +1050,7 @@ __global__ __launch_bounds__(256, 1) void wide_sliced_out_kernel(const ConvUnitW
 constexpr int64_t SLICED_MAX_TILES = 256, SLICED_AUTO_TILES = 256;
 __host__ constexpr size_t wide_planes_bytes(int c, int64_t rows) { return (size_t)((rows + 31) / 32) * 32 * (size_t)c * 6; }
 __host__ constexpr int64_t sliced_tiles_pad(int64_t rows) { return ((rows + 15) / 16 + 3) / 4 * 4; }
-__host__ constexpr bool sliced_exists(int c, int64_t rows) { return c >= 128 && (rows + 15) / 16 <= SLICED_MAX_TILES; }
+__host__ constexpr bool sliced_exists(int c, int64_t rows) { return (rows + 15) / 16 <= SLICED_MAX_TILES; }
 __host__ constexpr size_t sliced_hidden_bytes(int c, int64_t rows) { return (size_t)(4 * c / 32) * (size_t)sliced_tiles_pad(rows) * 3072; }
 
 template <int C>
@@ -1056,42 +1062,39 @@ int launch_wide(hipStream_t s, const ConvUnitW& w, const float* x, float* y, uns
                                            hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
         L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_unit_wide_kernel<C, 1>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
-        if constexpr (!G::FRONT) {
-            L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wide_sliced_hidden_kernel<C>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, SGeo<C>::LDS1));
-            L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wide_sliced_out_kernel<C>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, SGeo<C>::LDS2));
-        }
+        L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wide_sliced_hidden_kernel<C>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SGeo<C>::LDS1));
+        L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wide_sliced_out_kernel<C>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SGeo<C>::LDS2));
         configured.done();
     }
     char name[64];
+    const int64_t tiles16 = ceil_div64(rows, 16);
+    const bool sliced = sliced_exists(C, rows) && (sliced_mode == 2 || (sliced_mode == 1 && tiles16 <= SLICED_AUTO_TILES));
     if constexpr (!G::FRONT) {
+        std::snprintf(name, sizeof(name), "dwconv_ln_split_kernel<%d>", C);
+        ProfScope prof(s, name, (double)rows * 30.0 * C, (double)rows * 10.0 * C);
+        constexpr int IMG = (C / 16) * 3072;
+        hipLaunchKernelGGL((dwconv_ln_split_kernel<C>), dim3((unsigned)ceil_div64(rows, 32)), dim3(256), IMG, s, w, x, planes, rows, frames);
+        L3AC_LAUNCH_CHECK();
+    }
+    if (sliced) {
+        using S = SGeo<C>;
+        const int64_t tiles_pad = sliced_tiles_pad(rows);
+        unsigned char* hid = planes + (wide_planes_bytes(C, rows) + 255) / 256 * 256;
         {
-            std::snprintf(name, sizeof(name), "dwconv_ln_split_kernel<%d>", C);
-            ProfScope prof(s, name, (double)rows * 30.0 * C, (double)rows * 10.0 * C);
-            constexpr int IMG = (C / 16) * 3072;
-            hipLaunchKernelGGL((dwconv_ln_split_kernel<C>), dim3((unsigned)ceil_div64(rows, 32)), dim3(256), IMG, s, w, x, planes, rows, frames);
+            std::snprintf(name, sizeof(name), "wide_sliced_hidden_kernel<%d>", C);
+            ProfScope p1(s, name, (double)rows * (8.0 * C * C + (G::FRONT ? 30.0 * C * (G::NT / S::GH) : 0.0)), (double)rows * 30.0 * C);
+            hipLaunchKernelGGL((wide_sliced_hidden_kernel<C>), dim3((unsigned)(tiles_pad / 4 * (G::NT / S::GH))), dim3(256), S::LDS1, s, w, planes, hid,
+                               tiles16, tiles_pad, x, rows, frames);
             L3AC_LAUNCH_CHECK();
         }
-        const int64_t tiles16 = ceil_div64(rows, 16);
-        if (sliced_exists(C, rows) && (sliced_mode == 2 || (sliced_mode == 1 && tiles16 <= SLICED_AUTO_TILES))) {
-            using S = SGeo<C>;
-            const int64_t tiles_pad = sliced_tiles_pad(rows);
-            unsigned char* hid = planes + (wide_planes_bytes(C, rows) + 255) / 256 * 256;
-            {
-                std::snprintf(name, sizeof(name), "wide_sliced_hidden_kernel<%d>", C);
-                ProfScope p1(s, name, (double)rows * 8.0 * C * C, (double)rows * 30.0 * C);
-                hipLaunchKernelGGL((wide_sliced_hidden_kernel<C>), dim3((unsigned)(tiles_pad / 4 * (G::NT / S::GH))), dim3(256), S::LDS1, s, w, planes, hid,
-                                   tiles16, tiles_pad);
-                L3AC_LAUNCH_CHECK();
-            }
-            std::snprintf(name, sizeof(name), "wide_sliced_out_kernel<%d>", C);
-            ProfScope p2(s, name, (double)rows * 8.0 * C * C, (double)rows * 32.0 * C);
-            hipLaunchKernelGGL((wide_sliced_out_kernel<C>), dim3((unsigned)(ceil_div64(tiles16, 2) * (G::RT / 2))), dim3(256), S::LDS2, s, w, hid, x, y, rows,
-                               tiles16, tiles_pad);
-            L3AC_LAUNCH_CHECK();
-            return L3AC_OK;
-        }
+        std::snprintf(name, sizeof(name), "wide_sliced_out_kernel<%d>", C);
+        ProfScope p2(s, name, (double)rows * 8.0 * C * C, (double)rows * 32.0 * C);
+        hipLaunchKernelGGL((wide_sliced_out_kernel<C>), dim3((unsigned)(ceil_div64(tiles16, 2) * (G::RT / 2))), dim3(256), S::LDS2, s, w, hid, x, y, rows,
+                           tiles16, tiles_pad);
+        L3AC_LAUNCH_CHECK();
+        return L3AC_OK;
     }
     const int64_t tiles = ceil_div64(rows, 32);
     int64_t blocks = ceil_div64(tiles, 4);

@@ -98,7 +98,7 @@ struct l3ac_ctx {
     bool gemm_split = true, head_pretanh = false;
     // which fused kernel takes the narrow ConvUnits (C <= 48) on the split route: conv_unit_ring_kernel (16 frames per wave, LDS-DMA
     // weight ring) or conv_unit_split_kernel (32 frames per wave, chunk barriers); l3ac_ctx_set_option(ctx, "narrow_ring", 0 / 1)
-    // the wide ConvUnits (C = 128 .. 256) of FEW frames — a streaming chunk — as two launches over (frame tiles x channel slices) instead of
+    // the wide ConvUnits (C = 96 .. 256) of FEW frames — a streaming chunk — as two launches over (frame tiles x channel slices) instead of
     // the fused kernel, whose waves own their frames end to end (conv_unit_wide.hip, 'the SLICED form'; the same bits)
     int wide_sliced = 1;  // 0: never, 1: where it is faster (up to 256 frame tiles of 16: measured), 2: wherever the form exists (the same today; tests)
     int narrow_ring = 1;  // 0: conv_unit_split_kernel everywhere, 1: the ring kernel where it is faster (C = 48), 2: wherever it exists (C = 24 too)

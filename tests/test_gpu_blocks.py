@@ -377,7 +377,11 @@ def test_conv_units_wide_sliced_form_returns_the_same_bits(full):
              (codec, w, "decoder.blocks.4.0.module", 256, 4, 1024), (codec, w, "encoder.blocks.7.0.module", 192, 1, 178),
              (codec, w, "encoder.blocks.7.1.module", 192, 5, 37), (codec, w, "encoder.blocks.7.1.module", 192, 2, 16),
              (codec, w, "encoder.blocks.7.0.module", 192, 22, 178), (codec128, w128, "decoder.blocks.4.0.module", 128, 1, 1000),
-             (codec128, w128, "decoder.blocks.4.1.module", 128, 3, 47)]
+             (codec128, w128, "decoder.blocks.4.1.module", 128, 3, 47),
+             # C = 96: the front end (dw-conv + LayerNorm + split) runs inside the first launch, as in the fused kernel's pass prologue
+             (codec, w, "decoder.blocks.7.0.module", 96, 1, 2700), (codec, w, "decoder.blocks.7.1.module", 96, 1, 2701),
+             (codec, w, "encoder.blocks.5.0.module", 96, 1, 534), (codec, w, "encoder.blocks.5.0.module", 96, 5, 37),
+             (codec, w, "decoder.blocks.7.1.module", 96, 3, 1), (codec, w, "decoder.blocks.7.0.module", 96, 7, 585)]
     for cdc, ww, block, c, b, t in cases:
         ctx = cdc.network.context()
         x = _rand((b, c, t), 4000 + c + t)
