@@ -82,8 +82,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void up_fused_kernel(const U
     float* const gws = reinterpret_cast<float*>(smem_uf + G::OFF_GW);
     float* const gbs = gws + 4 * G::CINP;
     const int tid = threadIdx.x;
-    for (int i = tid; i < G::RT * G::K1 * 3072 / 16; i += 64 * WAVES)
-        reinterpret_cast<u32x4*>(smem_uf)[i] = reinterpret_cast<const u32x4*>(p.img)[i];
+    {
+        // the weight pieces by LDS-DMA, every 1-KB block of a wave in flight at once (through registers the fill was a chain of load ->
+        // store round trips: most of the 24 us the 256 -> 96 layer took for a single clip, whose four workgroups do little else)
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_uf;
+        for (int blk = wv; blk < G::RT * G::K1 * 3; blk += WAVES) ring_dma_1k(p.img + 1024 * blk, 16u * (unsigned)(tid & 63), lds0 + 1024u * (unsigned)blk);
+    }
     for (int i = tid; i < G::CP; i += 64 * WAVES) {
         par[i] = i < COUT ? p.bias[i] : 0.f;
         par[G::CP + i] = i < COUT ? p.nw[i] : 0.f;
@@ -96,6 +101,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void up_fused_kernel(const U
             gbs[i] = i < CIN ? p.gate_b[i] : 0.f;
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const int lane = tid & 63;
