@@ -125,9 +125,13 @@ __global__ __launch_bounds__(64 * G::WAVES, G::WAVES * G::PER_CU / 4) void conv_
             asm volatile("" ::: "memory");
         }
     };
-    if constexpr (G::RESIDENT) {  // the whole stream, once
-        for (int o = 16 * tid; o < G::RSLOTS * G::SLOT; o += 16 * 64 * G::WAVES)
-            *reinterpret_cast<u32x4*>(smem_ring + o) = *reinterpret_cast<const u32x4*>(w.ring_img + o);
+    if constexpr (G::RESIDENT) {  // the whole stream, once: by LDS-DMA, every 1-KB block of a wave in flight at once (through registers the
+                                  // fill was a chain of load -> store round trips, most of what a single clip's workgroups did)
+        static_assert((G::RSLOTS * G::SLOT) % 1024 == 0, "whole DMA blocks");
+        const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_ring;
+        for (int blk = __builtin_amdgcn_readfirstlane(tid >> 6); blk < G::RSLOTS * G::SLOT / 1024; blk += G::WAVES)
+            ring_dma_1k(w.ring_img + 1024 * blk, 16u * (unsigned)(tid & 63), lds0 + 1024u * (unsigned)blk);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     } else {
 #pragma unroll
