@@ -870,8 +870,8 @@ struct SGeo {
     using G = WGeo<C>;
     static constexpr int PIECES = C / 16;        // pieces of W1(nt) (k block b, hidden half hh) / of W2(nt) (output row tile rt)
     static constexpr int T1 = PIECES * 3072;     // bytes of W1(nt) = bytes of W2(nt)
-    static constexpr int GH = C >= 256 ? 2 : C <= 96 ? 4 : 1;  // hidden tiles per workgroup of the first kernel (C = 96: its front end is
-                                                                // computed by every workgroup of a frame group — three of them)
+    static constexpr int GH = C >= 256 ? 2 : C <= 96 ? 2 : 1;  // hidden tiles per workgroup of the first kernel (C = 96: its front end is
+                                                                // computed by every workgroup of a frame group — six of them: − 2 us against four hidden tiles each)
     static constexpr int LDS1 = GH * T1;
     static constexpr int RING = 12, PF = RING - 1, SLOT = 4 * 3072;
     static constexpr int LDS2 = RING * SLOT;
