@@ -209,6 +209,12 @@ def test_full_batch_properties_1kbps():
     assert wave.shape == (256, 16200) and torch.isfinite(wave).all() and float(wave.abs().max()) <= 1.0
     for b in (3, 200):
         assert torch.equal(codec.decode_audio(indices=idx[b:b + 1]), wave[b:b + 1])
+    # ... and so do the small batches in between, which take other launch forms stage by stage (round 5: the wide ConvUnits' sliced form
+    # up to 256 frame tiles — 4 clips at C = 256, 23 at C = 192 —, the streamed GEMMs, the stem's split form, the cooperative stacks)
+    for lo, n in ((10, 2), (40, 4), (90, 5), (120, 13), (200, 24)):
+        qn, indn = codec.encode_audio(audio[lo:lo + n])
+        assert torch.equal(indn["indices"], idx[lo:lo + n]) and torch.equal(qn, q[lo:lo + n]), f"{n} clips from {lo}"
+        assert torch.equal(codec.decode_audio(indices=idx[lo:lo + n]), wave[lo:lo + n]), f"{n} clips from {lo}: waveform"
     # deterministic
     q2, ind2 = codec.encode_audio(audio)
     assert torch.equal(ind2["indices"], idx) and torch.equal(q2, q)
