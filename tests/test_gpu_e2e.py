@@ -427,6 +427,9 @@ def test_batch_invariance_3kbps_256():
         assert torch.equal(codec.decode_audio(q1), wave[b:b + 1])
     q64, ind64 = codec.encode_audio(audio[64:128])
     assert torch.equal(ind64["indices"], idx[64:128]) and torch.equal(codec.decode_audio(q64), wave[64:128])
+    for lo, n in ((7, 2), (33, 5), (140, 12)):  # the few-clip launch forms of round 5 (sliced wide units, streamed GEMMs) at this geometry
+        qn, indn = codec.encode_audio(audio[lo:lo + n])
+        assert torch.equal(indn["indices"], idx[lo:lo + n]) and torch.equal(codec.decode_audio(qn), wave[lo:lo + n]), f"{n} clips from {lo}"
 
 
 @pytest.mark.parametrize("tag", ["0k75bps", "1k5bps"])
@@ -448,6 +451,9 @@ def test_batch_invariance_and_agreement_other_configs_256(tag):
         q1, ind1 = codec.encode_audio(audio[b:b + 1].cuda())
         assert torch.equal(ind1["indices"], idx[b:b + 1]) and torch.equal(q1, q[b:b + 1])
         assert torch.equal(codec.decode_audio(q1), wave[b:b + 1])
+    for lo, n in ((20, 3), (100, 9)):
+        qn, indn = codec.encode_audio(audio[lo:lo + n].cuda())
+        assert torch.equal(indn["indices"], idx[lo:lo + n]) and torch.equal(codec.decode_audio(qn), wave[lo:lo + n]), f"{n} clips from {lo}"
     idx_ref, lat_ref = _oracle_indices(w, mc, audio[:32])
     rep = index_agreement(idx[:32].cpu().numpy(), idx_ref.numpy(), lat_ref.numpy(), mc.levels)
     print(f"[index agreement {tag} b256, first 32 clips] {rep}")
