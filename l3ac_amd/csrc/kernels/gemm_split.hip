@@ -507,7 +507,10 @@ __device__ __forceinline__ void tail_for(F&& f) {
     }
 }
 constexpr int ST_SLOT = 16384, ST_RING = 9;  // A 4 KB | W plane 0 | plane 1 | plane 2 (4 KB each: 64 rows x 64 B)
-template <int PF>
+// CONV (three taps): the A rows of k tile kt are those of frame t + (tap - 1) dil, tap = kt / (cin / 32).  A copy cannot write zeros, so
+// the copying lane fetches a CLAMPED row (any valid address) and the multiplying wave zeroes the fragment of a frame whose tap falls outside
+// its clip before the split — the values gemm_split_conv_kernel's masked loads produce: same bits.
+template <int PF, bool CONV = false>
 __global__ __launch_bounds__(THREADS, 1) void gemm_split_kernel_stream(const GemmArgs p) {
     static_assert(PF + 1 <= ST_RING && 4 * (PF - 1) <= 63, "ring / counted wait");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_split[];
@@ -524,14 +527,27 @@ __global__ __launch_bounds__(THREADS, 1) void gemm_split_kernel_stream(const Gem
     const unsigned char* src;
     int64_t src_step;          // per k tile
     unsigned lo[2];            // lane offsets of blocks 0-1 and 2-3
+    unsigned lt0[2] = {0u, 0u}, lt1[2] = {0u, 0u}, lt2[2] = {0u, 0u};  // CONV, wave 0: the same for the rows of tap 0 / 1 / 2
     int blk_step;              // global bytes from a block to the next of the same pair
+    const int tiles_per_tap = CONV ? p.cin / BK : 1;
     if (wave == 0) {
         src = reinterpret_cast<const unsigned char*>(p.a);
         src_step = BK * 4;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int64_t row = m0 + 16 * r + ln;
-            lo[r] = (unsigned)(((row < p.m ? row : 0) * p.lda + 8 * lg) * 4);  // rows past the edge: row 0, never stored
+            const int64_t rr = row < p.m ? row : 0;  // rows past the edge: row 0, never stored
+            lo[r] = (unsigned)((rr * p.lda + 8 * lg) * 4);
+            if constexpr (CONV) {
+                // (a row outside the clip is zeroed by the consumer; outside the tensor: clamped)
+                auto off = [&](int64_t rt) __attribute__((always_inline)) {
+                    rt = rt < 0 ? 0 : (rt >= p.m ? p.m - 1 : rt);
+                    return (unsigned)((rt * p.lda + 8 * lg) * 4);
+                };
+                lt0[r] = off(rr - p.dil);
+                lt1[r] = off(rr);
+                lt2[r] = off(rr + p.dil);
+            }
         }
         blk_step = 16;  // j = 0, 1: the two 16-B halves of the lane's 32 B
     } else {
@@ -544,12 +560,37 @@ __global__ __launch_bounds__(THREADS, 1) void gemm_split_kernel_stream(const Gem
     const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_split;
     auto issue = [&](int kt) __attribute__((always_inline)) {
         const unsigned char* g = src + (int64_t)kt * src_step;
-        const unsigned dst = ring_lds + (unsigned)((kt % ST_RING) * ST_SLOT + 4096 * wave);
-        dma_1k(g, lo[0], dst);
-        dma_1k(g + blk_step, lo[0], dst + 1024);
-        dma_1k(g, lo[1], dst + 2048);
-        dma_1k(g + blk_step, lo[1], dst + 3072);
+        unsigned l0 = lo[0], l1 = lo[1];
+        if constexpr (CONV) {
+            if (wave == 0) {  // (wave-uniform) channel block kt % tiles_per_tap of the rows of tap kt / tiles_per_tap
+                const int tap = kt / tiles_per_tap;
+                g = src + (int64_t)(kt - tap * tiles_per_tap) * src_step;
+                // (sums of masked differences: as a chain of selects hipcc built a table of the three offsets in scratch memory and indexed it)
+                l0 = lt1[0] + (tap == 0 ? lt0[0] - lt1[0] : 0u) + (tap == 2 ? lt2[0] - lt1[0] : 0u);
+                l1 = lt1[1] + (tap == 0 ? lt0[1] - lt1[1] : 0u) + (tap == 2 ? lt2[1] - lt1[1] : 0u);
+            }
+        }
+        // (wave-uniform by construction; said so, or a k tile index that also feeds vector arithmetic — CONV's tap test — lands these in VGPRs)
+        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(ring_lds + (unsigned)((kt % ST_RING) * ST_SLOT + 4096 * wave)));
+        auto uni = [](const unsigned char* q) __attribute__((always_inline)) {
+            const uint64_t a = (uint64_t)q;
+            return reinterpret_cast<const unsigned char*>(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                                                          (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a));
+        };
+        const unsigned char* const g0 = uni(g);
+        const unsigned char* const g1 = uni(g + blk_step);
+        dma_1k(g0, l0, dst);
+        dma_1k(g1, l0, dst + 1024);
+        dma_1k(g0, l1, dst + 2048);
+        dma_1k(g1, l1, dst + 3072);
     };
+    // CONV: which taps of this lane's frame (the row strip this wave multiplies) fall outside its clip: bit tap
+    unsigned oob_taps = 0u;
+    if constexpr (CONV) {
+        const int64_t row = m0 + 16 * rs + ln;
+        const int t = (int)((unsigned)(row < p.m ? row : 0) % (unsigned)p.frames);
+        oob_taps = (t - p.dil < 0 ? 1u : 0u) | (t + p.dil >= (int)p.frames ? 4u : 0u);
+    }
     float4 fa[2][2];
     bf16x8 fw[2][2][3];
     auto fetch = [&](int kt, auto par_) __attribute__((always_inline)) {
@@ -557,6 +598,11 @@ __global__ __launch_bounds__(THREADS, 1) void gemm_split_kernel_stream(const Gem
         const unsigned char* slot = smem_split + (kt % ST_RING) * ST_SLOT;
         fa[P][0] = *reinterpret_cast<const float4*>(slot + rs * 2048 + 16 * lane);
         fa[P][1] = *reinterpret_cast<const float4*>(slot + rs * 2048 + 1024 + 16 * lane);
+        if constexpr (CONV) {  // the conv's zero padding: the rows of a tap outside the clip count as zeros
+            const bool oob = ((oob_taps >> (unsigned)(kt / tiles_per_tap)) & 1u) != 0u;
+            fa[P][0] = oob ? make_float4(0.f, 0.f, 0.f, 0.f) : fa[P][0];
+            fa[P][1] = oob ? make_float4(0.f, 0.f, 0.f, 0.f) : fa[P][1];
+        }
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -604,7 +650,7 @@ __global__ __launch_bounds__(THREADS, 1) void gemm_split_kernel_stream(const Gem
         multiply(P1{});
     }
     // the last PF tiles: nothing left to request, the counted waits shrink
-    tail_for<PF>([&](auto j_) {
+    tail_for<PF>([&](auto j_) __attribute__((always_inline)) {
         constexpr int J = decltype(j_)::value;
         if constexpr (J + 1 < PF) {
             landed(std::integral_constant<int, PF - 2 - J>{});
@@ -690,7 +736,7 @@ __global__ __launch_bounds__(THREADS, 1) void gemm_split_kernel_stream_narrow(co
         issue(q + SN_PF);
         multiply(q);
     }
-    tail_for<SN_PF>([&](auto j_) {
+    tail_for<SN_PF>([&](auto j_) __attribute__((always_inline)) {
         constexpr int J = decltype(j_)::value;
         landed(std::integral_constant<int, SN_PF - 1 - J>{});
         multiply(main_steps + J);
@@ -795,7 +841,20 @@ int launch_gemm_split(hipStream_t s, const GemmArgs& g) {
     const int gp = 8;  // row panels per group of the XCD-aware tile order (a multiple of the 8 XCDs)
     const bool tail = g.k % BK != 0;
     const int cus = l3ac_device_cu_count();
-    if (conv) {  // (whole k tiles: no tail; the 16x16x32 form only)
+    if (conv && g.taps == 3 && g.k / BK >= 8 && g.lda * g.m < ((int64_t)1 << 29) && ceil_div64(g.m, BM / 2) * ceil_div64(g.n, BN) <= cus / 4) {
+        // a single clip's k3 conv: the streamed form (32 x 64 blocks), its A rows by tap
+        static PerDeviceOnce configured;
+        if (configured.first()) {
+            L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel_stream<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ST_RING * ST_SLOT));
+            L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel_stream<7, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ST_RING * ST_SLOT));
+            configured.done();
+        }
+        const unsigned grid = (unsigned)(ceil_div64(g.m, 32) * ceil_div64(g.n, 64));
+        if ((g.k / BK) % 2 == 0)
+            hipLaunchKernelGGL((gemm_split_kernel_stream<8, true>), dim3(grid), dim3(THREADS), ST_RING * ST_SLOT, s, g);
+        else
+            hipLaunchKernelGGL((gemm_split_kernel_stream<7, true>), dim3(grid), dim3(THREADS), ST_RING * ST_SLOT, s, g);
+    } else if (conv) {  // (whole k tiles: no tail; the 16x16x32 form only)
         if (blocks <= cus)
             hipLaunchKernelGGL(gemm_split_conv_kernel_few_blocks, dim3((unsigned)(ceil_div64(g.m, BM / 2) * ceil_div64(g.n, BN))), dim3(THREADS),
                                2 * W_TILE, s, g, gp);
