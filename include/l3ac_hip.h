@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define L3AC_ABI_VERSION 4
+#define L3AC_ABI_VERSION 5
 #define L3AC_MAX_STAGES 8
 #define L3AC_MAX_LEVELS 8
 
@@ -49,7 +49,11 @@ enum {
     L3AC_EHIP = -3,      /* HIP runtime error */
     L3AC_ENOMEM = -4,    /* workspace too small while stream capture forbids growing it */
     L3AC_ECOOP = -5,     /* an EARLIER call's cooperative transformer launch timed out: that call's outputs are invalid
-                            (see l3ac_coop_timeout_count); reported once, by the next call on the context */
+                            (see l3ac_coop_timeout_count).  Reported once, by the first call ENTERED after the failure has been
+                            counted — the failure word is read at enqueue time without synchronising, so on an asynchronous stream
+                            that is one or more calls after the failing one; the message bounds the suspects.  Only a
+                            synchronising check (l3ac_coop_timeout_pending / _count, validate=True in the Python surface) is
+                            authoritative for the calls issued so far */
 };
 
 /* Network geometry: the [network_config] table of the reference's TOML files
@@ -105,8 +109,14 @@ int l3ac_bad_index_count(l3ac_ctx* ctx, int32_t reset, int64_t* out);
  * are ever not co-resident (another PROCESS filling the device, a CU mask, a debugger) an arrival poll expires after
  * "coop_timeout_ms" (default 250 ms; every workgroup then stops waiting, so the launch ends within about one time limit), the kernel
  * counts it in host-visible memory and the outputs of that call are INVALID.  The host is told in two ways:
- *   - the next encode / decode / op call on the context returns L3AC_ECOOP (once) before doing anything;
- *   - this call synchronises the device and writes the number of expired polls since the last reset to *out.
+ *   - an encode / decode / op call ENTERED after the failing launch has run returns L3AC_ECOOP (once) before doing anything.  The
+ *     entry check reads host memory and does not synchronise: calls enqueued on an asynchronous stream before the failing launch
+ *     ran are not stopped (they ran the cooperative form too and are suspect), and a program that ends first is never told.  The
+ *     error text says how many calls were entered since the last synchronising check: the invalid call is one of them;
+ *   - AUTHORITATIVE: l3ac_coop_timeout_pending / l3ac_coop_timeout_count synchronise the device first.  _count writes the number
+ *     of expired polls since the last reset to *out and acts on them (the report is then considered delivered: no L3AC_ECOOP
+ *     follows); _pending writes the number NOT yet acted on and leaves the state alone — read before and after a call it attributes
+ *     a failure to that call without hiding an earlier one (what validate=True of the Python surface does).
  * Either way the context then leaves the cooperative form (trans_coop = 0: same bits, one workgroup per clip) and its arrival
  * counters are zeroed again, so the repeated call is correct.  Inside ONE process cooperative launches cannot starve each other:
  * every context claims the CUs its launches need in a per-device registry and a launch that does not fit runs in the
@@ -114,6 +124,7 @@ int l3ac_bad_index_count(l3ac_ctx* ctx, int32_t reset, int64_t* out);
  * A hipGraph captured from a context must not be replayed concurrently with itself or with other work of the same context
  * (the slabs and counters are per context, like the workspace). */
 int l3ac_coop_timeout_count(l3ac_ctx* ctx, int32_t reset, int64_t* out);
+int l3ac_coop_timeout_pending(l3ac_ctx* ctx, int64_t* out);
 /* CUs of `device` that live contexts of this process have claimed for cooperative launches (the registry above); -1 for a bad
  * ordinal.  No device call. */
 int32_t l3ac_coop_claimed_cus(int32_t device);

@@ -203,9 +203,22 @@ class L3AC:
         return ctx
 
     @staticmethod
-    def _raise_on_coop_timeout(ctx, before: int, what: str):
-        lost = ctx.coop_timeout_count() - before  # (synchronises; the context has fallen back to the one-workgroup form by now)
+    def _coop_check_before(ctx, what: str):
+        """validate=True, before the call: an EARLIER call's expired polls that nobody has been told about must not disappear into this
+        call's baseline (they would: l3ac_coop_timeout_count acknowledges what it reports).  Synchronises."""
+        earlier = ctx.coop_timeout_pending()
+        if earlier:
+            ctx.coop_timeout_count()  # delivered by the exception below: fall back, re-zero the arrival counters
+            raise _capi.L3acError(
+                f"{what}(validate=True): an EARLIER call on this context lost {earlier} arrival poll(s) of the cooperative transformer "
+                "kernel to its time limit; that call's outputs are invalid (every call since the last validated one is suspect). "
+                "Nothing was run. The context now runs the one-workgroup form (same bits): repeat those calls")
+
+    @staticmethod
+    def _raise_on_coop_timeout(ctx, what: str):
+        lost = ctx.coop_timeout_pending()  # (synchronises)
         if lost:
+            ctx.coop_timeout_count()  # delivered here: the context falls back to the one-workgroup form, counters re-zeroed
             raise _capi.L3acError(
                 f"{what}: the cooperative transformer kernel lost {lost} arrival poll(s) to its time limit (its six workgroups per "
                 "clip were not co-resident: another process or a CU mask on the device?); this call's outputs are invalid. The "
@@ -215,8 +228,10 @@ class L3AC:
     def encode_audio(self, audio_data: torch.Tensor, validate: bool = False):
         """audio (B, T) fp32 -> (q_feature (B, T_tok, C) fp32, {"indices": int32 (B, T_tok),
         "level_indices": fp32 (B, T_tok, D)}); the zero right-padding to a hop multiple happens in-kernel.
-        ``validate=True`` synchronises and raises if a cooperative transformer launch of this call timed out (without it the
-        NEXT call on the context raises; include/l3ac_hip.h, l3ac_coop_timeout_count)."""
+        ``validate=True`` synchronises before and after the call: it raises — without running anything — if an EARLIER, unvalidated
+        call on the context lost a cooperative transformer launch to its time limit, and raises if a launch of THIS call did.  Without
+        it a later call on the context returns L3AC_ECOOP once, after the fact and possibly several calls late (the entry check does
+        not synchronise: include/l3ac_hip.h, L3AC_ECOOP / l3ac_coop_timeout_pending)."""
         ctx = self._check_input(audio_data, "audio_data")
         if audio_data.dim() != 2:
             raise ValueError(f"audio_data must be (batch, samples), got {tuple(audio_data.shape)}")
@@ -234,11 +249,12 @@ class L3AC:
         level_indices = torch.empty((b, n_tok, len(mc.levels)), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
-            lost_before = ctx.coop_timeout_count() if validate else 0
+            if validate:
+                self._coop_check_before(ctx, "encode_audio")
             _capi.check(ctx.lib.l3ac_encode(ctx.handle, audio.data_ptr(), b, t, audio.stride(0) if b > 1 else t,
                                             q_feature.data_ptr(), indices.data_ptr(), level_indices.data_ptr(), stream))
             if validate:
-                self._raise_on_coop_timeout(ctx, lost_before, "encode_audio")
+                self._raise_on_coop_timeout(ctx, "encode_audio")
         return q_feature, {"indices": indices, "level_indices": level_indices}
 
     @torch.no_grad()
@@ -271,10 +287,11 @@ class L3AC:
         with torch.cuda.device(src.device):
             stream = torch.cuda.current_stream(src.device).cuda_stream
             before = ctx.bad_index_count() if validate and i_ptr is not None else 0  # cumulative counter: read, never reset here
-            lost_before = ctx.coop_timeout_count() if validate else 0
+            if validate:
+                self._coop_check_before(ctx, "decode_audio")
             _capi.check(ctx.lib.l3ac_decode(ctx.handle, f_ptr, i_ptr, b, n_tok, audio.data_ptr(), stream))
             if validate:
-                self._raise_on_coop_timeout(ctx, lost_before, "decode_audio")
+                self._raise_on_coop_timeout(ctx, "decode_audio")
             if validate and i_ptr is not None:
                 bad = ctx.bad_index_count() - before
                 if bad:

@@ -9,7 +9,7 @@ import os
 
 # L3AC_LIB_PATH: load another build of the same library (experiment builds); default in-tree
 LIB_PATH = Path(os.environ.get("L3AC_LIB_PATH") or Path(__file__).resolve().parent / "libl3ac_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_STAGES = 8
 MAX_LEVELS = 8
 
@@ -55,6 +55,7 @@ SIGNATURES = {
     "l3ac_grn_min_norm": (C.c_int, [_P, _I32, C.POINTER(C.c_float)]),
     "l3ac_bad_index_count": (C.c_int, [_P, _I32, C.POINTER(_I64)]),
     "l3ac_coop_timeout_count": (C.c_int, [_P, _I32, C.POINTER(_I64)]),
+    "l3ac_coop_timeout_pending": (C.c_int, [_P, C.POINTER(_I64)]),
     "l3ac_coop_claimed_cus": (_I32, [_I32]),
     "l3ac_hop_length": (_I32, [_P]),
     "l3ac_encode": (C.c_int, [_P, _P, _I32, _I32, _I64, _P, _P, _P, _P]),
@@ -223,6 +224,13 @@ class Context:
         the context has then fallen back to the one-workgroup form).  Synchronises."""
         out = _I64(0)
         check(self.lib.l3ac_coop_timeout_count(self.handle, int(reset), C.byref(out)))
+        return int(out.value)
+
+    def coop_timeout_pending(self) -> int:
+        """Expired arrival polls that have NOT been reported yet (no L3AC_ECOOP returned for them, no coop_timeout_count call since).
+        Synchronises; changes nothing: the next call on the context still reports them."""
+        out = _I64(0)
+        check(self.lib.l3ac_coop_timeout_pending(self.handle, C.byref(out)))
         return int(out.value)
 
     def grn_min_norm(self, reset: bool = False) -> float:

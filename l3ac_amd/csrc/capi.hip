@@ -111,11 +111,21 @@ int coop_check_on_entry(l3ac_ctx* ctx, hipStream_t s) {
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (s) (void)hipStreamIsCapturing(s, &st);
     const unsigned fresh = coop_acknowledge(ctx, st == hipStreamCaptureStatusNone);
-    if (fresh == 0) return L3AC_OK;
+    if (fresh == 0) {
+        ++ctx->coop.calls_since_check;
+        return L3AC_OK;
+    }
+    // The failure word is read HERE, at enqueue time, with no synchronisation: on an asynchronous stream the failing launch may have run
+    // any number of calls after it was enqueued, so the report can only bound the affected calls — every cooperative call entered since
+    // the last synchronising check that found nothing (l3ac_coop_timeout_pending / _count, validate = True) is suspect.
+    const unsigned suspects = ctx->coop.calls_since_check;
+    ctx->coop.calls_since_check = 0;
     l3ac_set_error("an earlier call on this context lost %u arrival poll(s) of the cooperative transformer kernel to the time limit "
-                   "(its six workgroups per clip were not co-resident: another process or a CU mask on the device?): that call's "
-                   "outputs are INVALID; the context now runs the one-workgroup form (option trans_coop = 0) — repeat the call",
-                   fresh);
+                   "(its six workgroups per clip were not co-resident: another process or a CU mask on the device?): the outputs of "
+                   "that call are INVALID — it is one of the last %u call(s) on this context (all entered since the last synchronising "
+                   "check; calls still queued behind it ran the cooperative form too and are suspect as well); the context now runs "
+                   "the one-workgroup form (option trans_coop = 0) — repeat those calls",
+                   fresh, suspects);
     return L3AC_ECOOP;
 }
 
@@ -214,8 +224,23 @@ int l3ac_coop_timeout_count(l3ac_ctx* ctx, int32_t reset, int64_t* out) {
     TransCoopState& st = ctx->coop;
     const unsigned now = st.fail_host ? *(volatile unsigned*)st.fail_host : 0u;
     *out = (int64_t)(unsigned)(now - st.count_base);
+    st.calls_since_check = 0;  // (drained: whatever happened has been counted, and is reported by this call)
     (void)coop_acknowledge(ctx, true);  // the caller has been told: fall back, re-zero the counters, no second report on the next call
     if (reset) st.count_base = now;
+    return L3AC_OK;
+}
+
+// Expired polls the host has NOT yet acted on, after draining the device — and without acting on them: the context's state is left as
+// it is, so the next entry point (or l3ac_coop_timeout_count) still reports them.  What a caller that wants to attribute a failure to
+// ONE call reads before and after it (encode_audio / decode_audio(validate=True)).
+int l3ac_coop_timeout_pending(l3ac_ctx* ctx, int64_t* out) {
+    L3AC_ENTER(ctx);
+    L3AC_REQUIRE(out != nullptr, "coop_timeout_pending: null output");
+    L3AC_HIP_CHECK(hipDeviceSynchronize());
+    TransCoopState& st = ctx->coop;
+    const unsigned now = st.fail_host ? *(volatile unsigned*)st.fail_host : 0u;
+    *out = (int64_t)(unsigned)(now - st.seen);
+    if (now == st.seen) st.calls_since_check = 0;  // a synchronising check that found nothing: every call so far is good
     return L3AC_OK;
 }
 

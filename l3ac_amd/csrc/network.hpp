@@ -74,6 +74,8 @@ struct TransCoopState {
     int fault_part = -1;            // option "coop_test_fault" (test hook): workgroup that withholds its first arrival, -1 = none
     unsigned seen = 0;              // value of *fail_host the host has already acted on (fallback + report)
     unsigned count_base = 0;        // value of *fail_host at the last l3ac_coop_timeout_count(reset = 1)
+    unsigned calls_since_check = 0; // workspace-using calls entered since the last SYNCHRONISING check that found nothing (bounds which
+                                    // calls an L3AC_ECOOP report can refer to: the failure word is read at enqueue time, without a sync)
 };
 
 struct Workspace {

@@ -640,7 +640,8 @@ def test_cooperative_stack_reports_a_lost_arrival():
     """A cooperative launch whose six workgroups per clip are not all there (here: a test hook makes workgroup 3 of every clip
     withhold its first arrival, and the time limit is 5 ms) must not return wrong tokens silently: the kernel counts the expired
     polls in host-visible memory, every workgroup stops waiting (the launch ends at once), and the host hears it — through
-    encode_audio(validate=True), through l3ac_coop_timeout_count, and (without either) as L3AC_ECOOP from the NEXT call.  The context
+    encode_audio(validate=True), through l3ac_coop_timeout_count / _pending, and (without either) as L3AC_ECOOP from a LATER call (the
+    next one entered after the failing launch has run: here the stream is drained in between).  The context
     then runs the one-workgroup form and the repeated call returns the right tokens."""
     ref_codec = l3ac_amd.get_model("1kbps", synthetic_seed=0)
     ref_codec.network.to(device="cuda").eval()
@@ -685,6 +686,25 @@ def test_cooperative_stack_reports_a_lost_arrival():
     with pytest.raises(_capi.L3acError, match="decode_audio.*cooperative"):
         codec.decode_audio(indices=want, validate=True)
     assert torch.equal(codec.decode_audio(indices=want, validate=True), want_wave)
+    # (4) ADVICE r5: an UNVALIDATED failing call followed by a validated one.  The validated call must not take the earlier failure
+    # into its own baseline (round 5 did: count-before acknowledged it, count-after minus count-before was 0 and the invalid tokens
+    # were decoded without a word): it raises before running anything, names the earlier call, and the context is good afterwards
+    codec, ctx = fresh()
+    bad = codec.encode_audio(audio)[1]["indices"]            # loses its cooperative launch; nobody asked
+    assert ctx.coop_timeout_pending() > 0                    # (synchronises; reading it changes nothing:)
+    assert ctx.coop_timeout_pending() > 0
+    with pytest.raises(_capi.L3acError, match="(?s)EARLIER call.*invalid.*Nothing was run"):
+        codec.decode_audio(indices=bad, validate=True)
+    assert ctx.coop_timeout_pending() == 0                   # delivered by that exception: no second report
+    got = codec.encode_audio(audio, validate=True)[1]["indices"]
+    assert torch.equal(got, want)
+    assert torch.equal(codec.decode_audio(indices=got, validate=True), want_wave)
+    # the unsynchronised entry check bounds its report: "one of the last N call(s)"
+    codec, ctx = fresh()
+    codec.encode_audio(audio)
+    torch.cuda.synchronize()
+    with pytest.raises(_capi.L3acError, match=r"(?s)one of the last 1 call\(s\)"):
+        codec.encode_audio(audio)
 
 
 def test_cooperative_stacks_of_two_contexts_cannot_starve_each_other():
