@@ -27,6 +27,7 @@ SOURCES = [
     "network.hip",
     "kernels/gemm_f32.hip",
     "kernels/gemm_split.hip",
+    "kernels/gemm_split_w256.hip",
     "kernels/rows.hip",
     "kernels/first_block.hip",
     "kernels/enhance.hip",
@@ -76,6 +77,7 @@ def _depfile_newest(dep: Path) -> float:
 # issue slot beside an MFMA (MI355X_MICROARCH.md, 'price of one filler beside MFMAs').
 PER_FILE_FLAGS = {
     "kernels/conv_unit_wide.hip": ["-fno-slp-vectorize"],
+    "kernels/gemm_split_w256.hip": ["-fno-slp-vectorize"],  # the same for its in-loop operand split
     # vq_screen_kernel reduces every MFMA result on the vector unit at once: results in VGPRs, not AGPRs + 16 v_accvgpr_read
     "kernels/fsq.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
 }

@@ -64,6 +64,8 @@ int64_t gemm_split_image_bytes(int n, int k);
 void gemm_split_image_host(const float* w, int64_t ldw, int n, int k, unsigned char* img);  // img: host buffer
 int launch_gemm_split_image(hipStream_t s, const float* w, int64_t ldw, int n, int k, unsigned char* img);  // device
 int launch_gemm_split(hipStream_t s, const GemmArgs& g);
+bool gemm_split_w256_ok(const GemmArgs& g);
+int launch_gemm_split_w256(hipStream_t s, const GemmArgs& g);  // gemm_split_w256.hip: a batch's rows, n % 256 == 0, an even number of whole k tiles
 
 // ------------------------------------------------------------------------------------------------
 // row kernels: one output row = one frame (all channels), optional per-row normalisation

@@ -52,3 +52,20 @@ extern "C" int l3ac_debug_wide_stamps(unsigned long long* out, int n) {
 #define WIDE_STAMP(slot) do { } while (0)
 #endif
 #endif
+
+// ---- gemm_split_kernel_w256: wave 0 of every workgroup: start | loop entry | loop exit | end (needs `lane`, `wave` in scope) ------------
+#ifdef L3AC_DIAG_UNIT_GEMM_W256
+#ifdef L3AC_W256_STAMPS
+__device__ unsigned long long g_w256_stamps[4096 * 4];
+#define W256_STAMP(slot)                                                                             \
+    do {                                                                                             \
+        if (lane == 0 && wave == 0 && blockIdx.x < 4096)                                             \
+            g_w256_stamps[(size_t)blockIdx.x * 4 + (slot)] = __builtin_amdgcn_s_memtime();           \
+    } while (0)
+extern "C" int l3ac_debug_w256_stamps(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_w256_stamps), (size_t)n * sizeof(unsigned long long));
+}
+#else
+#define W256_STAMP(slot) do { } while (0)
+#endif
+#endif
