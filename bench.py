@@ -33,7 +33,7 @@ PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA (same guide: ~2.5 PFLOP/s)
 # fp32-equivalent FLOPs is the bf16 peak / 6
 PEAK_SPLIT_TFLOPS = PEAK_BF16_TFLOPS / 6.0
 PEAK_HBM_GBS = 8000.0    # HBM3E spec
-SPLIT_KERNELS = ("gemm_split_kernel", "gemm_split_conv_kernel", "conv_unit_wide_kernel", "conv_unit_split_kernel", "legacy_unit_split_kernel")
+SPLIT_KERNELS = ("gemm_split_kernel", "gemm_split_kernel_w256", "gemm_split_conv_kernel", "conv_unit_wide_kernel", "conv_unit_split_kernel", "legacy_unit_split_kernel")
 
 
 def algorithmic_gflop_per_clip_second(mc):
@@ -459,6 +459,11 @@ def main():
             if ind_exact is not None:
                 routes["exact"] = ind_exact
             out["cpu_baseline"] = cpu_baseline(codec, audio, args.cpu_batch, routes, args.cpu_threads, args.agreement_clips)
+        if roof is not None and fsq_line is not None:  # the north_star's one numeric target (>= 0.60 of the HBM peak on the quantiser kernel)
+            roof["north_star_kernel"] = {"kernel": "fsq_forward128_kernel", "bound": "hbm", "frac": round(fsq_line["frac"], 4),
+                                         "achieved": round(fsq_line["achieved"], 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                         "frac_of_copy_ceiling": round(fsq_line.get("frac_of_copy_ceiling", float("nan")), 4), "target": 0.60}
+        out["summary"] = summary_of(out)  # LAST key, <= 400 characters: survives a record that keeps only the tail of the line
         try:  # RCCL writes a version banner through C stdio: flush it first so that the JSON line is the last line of stdout
             import ctypes
             ctypes.CDLL(None).fflush(None)
@@ -469,6 +474,24 @@ def main():
         dist.barrier()
     if world > 1 or force_dist:
         dist.destroy_process_group()
+
+
+def summary_of(out):
+    """The figures a round is about, compact and LAST in the line (the driver's record keeps a 2 000-character tail)."""
+    r3 = lambda v: None if v is None else round(float(v), 3)
+    fsq = out.get("fsq_kernel") or {}
+    cfgs = out.get("configs") or {}
+    stream = cfgs.get("stream_1s_graph") or {}
+    agree = (out.get("cpu_baseline") or {}).get("index_agreement") or {}
+    roof = out.get("roofline") or {}
+    gemm = [k for k in out.get("kernels", []) if k["name"].startswith("gemm_split_kernel")]
+    return {"ms_per_step": r3(out.get("ms_per_step")), "fsq_frac": r3(fsq.get("frac")), "fsq_frac_of_copy_ceiling": r3(fsq.get("frac_of_copy_ceiling")),
+            "fsq_copy_ceiling_frac": r3((fsq.get("copy_ceiling_best_residency") or fsq.get("copy_ceiling") or {}).get("frac_of_peak")),
+            "chunk_ms": r3(stream.get("ms_per_chunk")), "chunk_pipelined_ms": r3((stream.get("pipelined_encode_decode") or {}).get("ms_per_chunk")),
+            "ms_3kbps": r3((cfgs.get("3kbps_b256") or {}).get("ms_per_step")), "exact_route_ms": r3((out.get("exact_f32_mfma_route") or {}).get("ms_per_step")),
+            "index_mismatches": {k: v.get("mismatches") for k, v in agree.items()} or None,
+            "roofline_kernel": roof.get("kernel"), "roofline_frac": r3(roof.get("frac")),
+            "gemm_split_ms": r3(sum(k["ms"] for k in gemm)) if gemm else None}
 
 
 def _sysfs_clocks():
@@ -519,6 +542,7 @@ def fsq_microbench(codec, dev, n_tokens=1 << 22, window=20, rounds=5, min_warm_s
                                                     li.data_ptr(), None, s))
     with_copy = feat == 128 and d == 6  # the same grid and access pattern with no arithmetic: what this box's HBM gives that pattern
     copy = lambda: _capi.check(lib.l3ac_fsq_copy_ceiling(x.data_ptr(), n_tokens, q.data_ptr(), idx.data_ptr(), li.data_ptr(), s))
+    copy_at = lambda r: (lambda: _capi.check(lib.l3ac_fsq_copy_ceiling_at(x.data_ptr(), n_tokens, q.data_ptr(), idx.data_ptr(), li.data_ptr(), r, s)))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     def timed(fn, lead=3):  # one window: ms per launch (the first `lead` launches after a change of kernel are not timed)
@@ -540,13 +564,20 @@ def fsq_microbench(codec, dev, n_tokens=1 << 22, window=20, rounds=5, min_warm_s
         if (prev is not None and abs(ms - prev) <= 0.01 * prev and waited >= min_warm_s) or waited >= max_warm_s:
             break
         prev = ms
+    best_res, by_res = 0, {}
     if with_copy:
         timed(copy)
-    k_ms, c_ms = [], []
+        # the copy kernel needs no LDS and few registers, so ITS best residency is not the quantiser's (2 workgroups per CU):
+        # one window per residency, the fastest one is measured beside the kernel in every round below and is the ratio's denominator
+        for r in (3, 4, 6, 8):
+            by_res[r] = timed(copy_at(r))
+        best_res = min(by_res, key=by_res.get)
+    k_ms, c_ms, cb_ms = [], [], []
     for _ in range(rounds):
         k_ms.append(timed(call))
         if with_copy:
             c_ms.append(timed(copy))
+            cb_ms.append(timed(copy_at(best_res)))
     bytes_per_token = 4 * feat * 2 + 4 + 4 * d
     to_gbs = lambda ms: n_tokens * bytes_per_token / ms / 1e6
     ms = statistics.median(k_ms)
@@ -565,8 +596,16 @@ def fsq_microbench(codec, dev, n_tokens=1 << 22, window=20, rounds=5, min_warm_s
                                "rounds_gbs": [round(to_gbs(v), 1) for v in c_ms],
                                "what": "fsq_copy_ceiling_kernel: the grid and residency of the kernel it is measured beside (fsq_forward128_kernel), "
                                        "its token order and per-lane non-temporal loads / stores incl. the 4-B and 24-B side outputs, no arithmetic"}
-        out["frac_of_copy_ceiling"] = statistics.median([c / k for k, c in zip(k_ms, c_ms)])
-        out["frac_of_copy_ceiling_rounds"] = [round(c / k, 4) for k, c in zip(k_ms, c_ms)]
+        out["frac_of_copy_ceiling_matched_residency"] = statistics.median([c / k for k, c in zip(k_ms, c_ms)])
+        best = [min(c, cb) for c, cb in zip(c_ms, cb_ms)]  # per round: the faster of the two residencies
+        bgbs = to_gbs(statistics.median(best))
+        out["copy_ceiling_best_residency"] = {"achieved": bgbs, "unit": "GB/s", "frac_of_peak": bgbs / PEAK_HBM_GBS, "workgroups_per_cu": best_res,
+                                              "ms_by_workgroups_per_cu": {str(k): round(v, 4) for k, v in by_res.items()},
+                                              "rounds_gbs": [round(to_gbs(v), 1) for v in cb_ms],
+                                              "what": "the same copy kernel at ITS OWN best residency (no LDS, few registers: more workgroups per CU "
+                                                      "than the quantiser can hold); frac_of_copy_ceiling divides by the faster of the two per round"}
+        out["frac_of_copy_ceiling"] = statistics.median([c / k for k, c in zip(k_ms, best)])
+        out["frac_of_copy_ceiling_rounds"] = [round(c / k, 4) for k, c in zip(k_ms, best)]
     return out
 
 

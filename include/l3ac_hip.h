@@ -174,6 +174,10 @@ int l3ac_fsq_decode(const int32_t* indices, int64_t n, int32_t feat, const int32
  * — 512 B read, 512 + 4 + 24 B written per token — with no arithmetic: the HBM rate this access pattern can reach on the
  * box, printed beside the quantiser's own rate by bench.py (`fsq_kernel.copy_ceiling`). */
 int l3ac_fsq_copy_ceiling(const float* x, int64_t n, float* q_feature, int32_t* indices, float* level_indices, void* stream);
+/* The same copy at a given residency (workgroups per CU, 1 .. 8; 0 = as above: the quantiser kernel's own residency).  The copy kernel uses
+ * no LDS and few registers, so its best rate is at a higher residency than the quantiser's: bench.py measures both and divides by the best. */
+int l3ac_fsq_copy_ceiling_at(const float* x, int64_t n, float* q_feature, int32_t* indices, float* level_indices, int32_t blocks_per_cu,
+                             void* stream);
 
 /* Explicit-codebook nearest neighbour (the search FSQ is the closed form of):
  * queries [n][dim] (= tanh(latents)), codebook [k][dim] (= indices_to_codes(arange(k)), vq/fsq.py:80-81);

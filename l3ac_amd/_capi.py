@@ -64,6 +64,7 @@ SIGNATURES = {
     "l3ac_fsq_quantize_act": (C.c_int, [_P, _I64, _I32, C.POINTER(_I32), _I32, _P, _P, _P, _P, _P, _P]),
     "l3ac_fsq_decode": (C.c_int, [_P, _I64, _I32, C.POINTER(_I32), _I32, _P, _P, _P, _P]),
     "l3ac_fsq_copy_ceiling": (C.c_int, [_P, _I64, _P, _P, _P, _P]),
+    "l3ac_fsq_copy_ceiling_at": (C.c_int, [_P, _I64, _P, _P, _P, _I32, _P]),
     "l3ac_vq_argmin_scratch_bytes": (_I64, [_I64, _I32, _I32]),
     "l3ac_vq_argmin": (C.c_int, [_P, _I64, _P, _I32, _I32, _P, _P, _I64, _I32, _P]),
     "l3ac_op_first_block": (C.c_int, [_P, _P, _I32, _I32, _P, _P]),

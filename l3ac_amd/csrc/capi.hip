@@ -347,6 +347,9 @@ int l3ac_fsq_decode(const int32_t* indices, int64_t n, int32_t feat, const int32
 int l3ac_fsq_copy_ceiling(const float* x, int64_t n, float* q_feature, int32_t* indices, float* level_indices, void* stream) {
     return launch_fsq_copy_ceiling((hipStream_t)stream, x, n, q_feature, indices, level_indices);
 }
+int l3ac_fsq_copy_ceiling_at(const float* x, int64_t n, float* q_feature, int32_t* indices, float* level_indices, int32_t blocks_per_cu, void* stream) {
+    return launch_fsq_copy_ceiling((hipStream_t)stream, x, n, q_feature, indices, level_indices, blocks_per_cu);
+}
 
 int64_t l3ac_vq_argmin_scratch_bytes(int64_t n, int32_t k, int32_t form) {
     return (n > 0 && k > 0) ? (int64_t)vq_argmin_scratch_bytes(n, k, form) : 0;

@@ -160,7 +160,7 @@ struct FsqArgs {
 };
 int launch_fsq(hipStream_t s, const FsqArgs& a);
 // measurement aid: fsq_kernel's grid and access pattern (feat 128, 6 levels) with no arithmetic — its achievable HBM ceiling
-int launch_fsq_copy_ceiling(hipStream_t s, const float* x, int64_t n, float* q, int32_t* idx, float* li);
+int launch_fsq_copy_ceiling(hipStream_t s, const float* x, int64_t n, float* q, int32_t* idx, float* li, int blocks_per_cu = 0);
 // token bit stream (kernels/bitpack.hip)
 int launch_pack_indices(hipStream_t s, const int32_t* idx, int batch, int n_tok, int bits, uint32_t* out, int words_per_clip);
 int launch_unpack_indices(hipStream_t s, const uint32_t* in, int batch, int n_tok, int bits, int words_per_clip, int32_t* idx);

@@ -1129,11 +1129,13 @@ int launch_fsq(hipStream_t s, const FsqArgs& a) {
     }
 }
 
-int launch_fsq_copy_ceiling(hipStream_t s, const float* x, int64_t n, float* q, int32_t* idx, float* li) {
-    L3AC_REQUIRE(x && q && idx && li && n > 0, "fsq_copy_ceiling: bad arguments");
+int launch_fsq_copy_ceiling(hipStream_t s, const float* x, int64_t n, float* q, int32_t* idx, float* li, int blocks_per_cu) {
+    L3AC_REQUIRE(x && q && idx && li && n > 0 && blocks_per_cu >= 0 && blocks_per_cu <= 8, "fsq_copy_ceiling: bad arguments");
     int64_t blocks = ceil_div64(n, THREADS / 8);
-    // the quantiser kernel's own residency (register-bound): the ceiling of ITS launch shape
-    const int per_cu = fsq_resident(reinterpret_cast<const void*>(fsq_forward128_kernel<6>), (size_t)(2 * 6 + 1) * 128 * sizeof(float), 2);
+    // blocks_per_cu = 0: the quantiser kernel's own residency (register-bound) — the ceiling of ITS launch shape; otherwise the given
+    // residency (the copy kernel needs neither LDS nor many registers: its own best residency is higher, and so is its rate)
+    const int per_cu = blocks_per_cu > 0 ? blocks_per_cu
+                                         : fsq_resident(reinterpret_cast<const void*>(fsq_forward128_kernel<6>), (size_t)(2 * 6 + 1) * 128 * sizeof(float), 2);
     const int64_t places = (int64_t)l3ac_device_cu_count() * per_cu;
     if (blocks > places) blocks = places;
     ProfScope prof(s, "fsq_copy_ceiling_kernel", 0.0, (double)n * 1052.0);

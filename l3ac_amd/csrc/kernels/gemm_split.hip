@@ -718,14 +718,21 @@ int launch_gemm_split(hipStream_t s, const GemmArgs& g) {
     const int64_t blocks = ceil_div64(g.m, BM) * ceil_div64(g.n, BN);
     if (blocks <= 0) return L3AC_OK;
     L3AC_REQUIRE(blocks < (int64_t)1 << 31, "split gemm: grid too large (m=%lld n=%d)", (long long)g.m, g.n);
+    const int cus = l3ac_device_cu_count();
+    // a batch's rows, 256-column blocks, long K, a light epilogue (the C = 512 stage's second product): one wave per SIMD, 192 x 256 per
+    // workgroup (gemm_split_w256.hip).  Measured inside the 256-clip step (profiles/r06/gemm_w256.md): 24480 x 512 x 2048 0.242 -> 0.221 ms;
+    // the first product (K = 512, snake + GRN epilogue: four tiles per CU, each with an exposed 38 k-cycle epilogue) 0.246 -> 0.258,
+    // 46080 x 256 x 512 0.063 -> 0.066: those stay on gemm_split_kernel (L3AC_GEMM_W256=2 sends them here too: same bits)
+    const bool use_w256 = !conv && w256_enabled() && gemm_split_w256_ok(g) && blocks > cus &&
+                          (w256_enabled() > 1 || (g.k >= 1024 && (g.epi == EPI_BIAS || g.epi == EPI_BIAS_RES)));
     char name[64];
-    std::snprintf(name, sizeof(name), "%s %lldx%dx%d e%d", conv ? "gemm_split_conv_kernel" : "gemm_split_kernel", (long long)g.m, g.n, g.k, g.epi);
+    std::snprintf(name, sizeof(name), "%s %lldx%dx%d e%d", conv ? "gemm_split_conv_kernel" : use_w256 ? "gemm_split_kernel_w256" : "gemm_split_kernel",
+                  (long long)g.m, g.n, g.k, g.epi);
     const double c_cols = g.epi == EPI_GEGLU ? (double)g.ldc : (double)g.n;
     ProfScope prof(s, name, 2.0 * (double)g.m * g.n * g.k,
                    4.0 * ((double)g.m * g.k + (double)g.m * c_cols * (g.epi == EPI_BIAS_RES ? 2.0 : 1.0)) + 6.0 * (double)g.n * g.k);
     const int gp = 8;  // row panels per group of the XCD-aware tile order (a multiple of the 8 XCDs)
     const bool tail = g.k % BK != 0;
-    const int cus = l3ac_device_cu_count();
     if (conv && g.taps == 3 && g.k / BK >= 8 && g.lda * g.m < ((int64_t)1 << 29) && ceil_div64(g.m, BM / 2) * ceil_div64(g.n, BN) <= cus / 4) {
         // a single clip's k3 conv: the streamed form (32 x 64 blocks), its A rows by tap
         static PerDeviceOnce configured;
@@ -768,11 +775,7 @@ int launch_gemm_split(hipStream_t s, const GemmArgs& g) {
             hipLaunchKernelGGL((gemm_split_kernel_slices<true>), dim3(grid), dim3(THREADS), 2 * W_TILE, s, g);
         else
             hipLaunchKernelGGL((gemm_split_kernel_slices<false>), dim3(grid), dim3(THREADS), 2 * W_TILE, s, g);
-    } else if (w256_enabled() && gemm_split_w256_ok(g) && blocks > cus && (w256_enabled() > 1 || (g.k >= 1024 && (g.epi == EPI_BIAS || g.epi == EPI_BIAS_RES)))) {
-        // a batch's rows, 256-column blocks, long K, a light epilogue (the C = 512 stage's second product): one wave per SIMD, 192 x 256 per
-        // workgroup (gemm_split_w256.hip).  Measured inside the 256-clip step (profiles/r06/gemm_w256.md): 24480 x 512 x 2048 0.242 -> 0.221 ms;
-        // the first product (K = 512, snake + GRN epilogue: four tiles per CU, each with an exposed 38 k-cycle epilogue) 0.246 -> 0.258,
-        // 46080 x 256 x 512 0.063 -> 0.066: those stay on gemm_split_kernel (L3AC_GEMM_W256=2 sends them here too: same bits)
+    } else if (use_w256) {
         L3AC_TRY(launch_gemm_split_w256(s, g));
     } else if (blocks <= cus) {
         const unsigned few = (unsigned)(ceil_div64(g.m, BM / 2) * ceil_div64(g.n, BN));

@@ -124,7 +124,8 @@ def index_agreement(idx, idx_ref, latents_ref, levels):
     # how close the batch's latents come to a boundary at all (context for the mismatch count)
     scaled = (np.tanh(lat) + 1) / 2 * (lv - 1)
     margins = np.abs(np.abs(scaled - np.floor(scaled)) - 0.5)
-    return {"tokens": int(idx.size), "mismatches": int(bad.size), "max_margin_of_mismatches": max_margin,
+    return {"tokens": int(idx.size), "mismatches": int(bad.size), "mismatch_positions": [int(r) for r in bad[:8]],  # flat token numbers (clip * tokens + token)
+            "max_margin_of_mismatches": max_margin,
             "single_step": bool(single), "decisions_within_1e-4": int((margins < 1e-4).sum()),
             "decisions_within_1e-5": int((margins < 1e-5).sum()), "min_margin": float(margins.min())}
 
@@ -200,10 +201,12 @@ def _digest(*tensors):
     return h.hexdigest()
 
 
-def oracle_indices(w, mc, audio):
+def oracle_indices(w, mc, audio, use_cache=True):
     """Oracle tokens + latents of `audio` [B, T] (CPU), in chunks of ORACLE_CHUNK clips.  Several tests compare the same seeded
     batches (or a prefix of one) with the oracle: each chunk of clips is encoded once per session, keyed by the bytes of the chunk's
-    audio and a fingerprint of the weights (every tensor's sum and the bytes of the quantiser's projection)."""
+    audio and a fingerprint of the weights (every tensor's sum and the bytes of the quantiser's projection).
+    ``use_cache=False``: encode now, whatever the session already holds — for a caller that has hooked the oracle (a counting snake)
+    and needs the evaluation to actually happen, in any test order; the results still go into the cache."""
     from oracle import l3ac_oracle as O
     wkey = (tuple(mc.levels), mc.hop_length, _digest(w["quantizer.project_in.weight"], w["quantizer.project_out.weight"]),
             round(float(sum(float(v.double().sum()) for v in w.values())), 6))
@@ -211,7 +214,7 @@ def oracle_indices(w, mc, audio):
     for b0 in range(0, audio.shape[0], ORACLE_CHUNK):
         chunk = audio[b0:b0 + ORACLE_CHUNK]
         key = (wkey, tuple(chunk.shape), _digest(chunk))
-        if key not in _ORACLE_ENCODE_CACHE:
+        if not use_cache or key not in _ORACLE_ENCODE_CACHE:
             taps = {}
             _, ind = O.encode_audio(w, mc, chunk, taps=taps)
             _ORACLE_ENCODE_CACHE[key] = (ind["indices"], taps["latents"])

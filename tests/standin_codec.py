@@ -21,3 +21,35 @@ def make_codec():
             return O.decode_audio(w, mc, audio_feature=audio_feature, indices=indices)
 
     return Codec()
+
+
+def make_shape_codec():
+    """BASELINE config 4 at its REAL shape on CPU ranks: the 1kbps geometry (hop 270 -> 60 tokens and 16 200 output samples per 1 s clip,
+    128 features, the shipped levels) with trivial arithmetic in place of the network — a deterministic token per hop window and a
+    waveform that repeats it — so that 8 gloo ranks x 256 clips run in seconds.  What it exercises is bench.py's N-rank plumbing at the
+    sizes the 8-GPU run will have (gathers of [2048, 60] int32 and [2048, 16200] fp32); no number it produces means anything."""
+    import math
+
+    import torch
+
+    from l3ac_amd.config import L3ACConfig, resolve_config_file
+    mc = L3ACConfig(config_file=resolve_config_file("1kbps")).network_config
+    hop, feat, k = mc.hop_length, mc.feature_dim, mc.codebook_size
+
+    class Codec:
+        network = types.SimpleNamespace(mc=mc)
+        config = types.SimpleNamespace(sample_rate=16000)
+
+        def encode_audio(self, audio):
+            b, t = audio.shape
+            n_tok = math.ceil(t / hop)
+            x = torch.nn.functional.pad(audio, (0, n_tok * hop - t)).view(b, n_tok, hop)
+            idx = (x.abs().sum(-1) * 1000.0).to(torch.int64).remainder(k).to(torch.int32)
+            q = (idx.to(torch.float32) / k).unsqueeze(-1).expand(b, n_tok, feat).contiguous()
+            return q, {"indices": idx, "level_indices": torch.zeros(b, n_tok, len(mc.levels))}
+
+        def decode_audio(self, audio_feature=None, indices=None):
+            src = audio_feature[..., 0] if audio_feature is not None else indices.to(torch.float32) / k
+            return src.repeat_interleave(hop, dim=1).contiguous()
+
+    return Codec()

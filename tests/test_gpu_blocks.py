@@ -774,9 +774,8 @@ def test_fsq_known_answers_and_exactness():
         q, idx, li, _ = G.fsq_forward(None, levels, None, None, w_out, b_out, latents_in=z.cuda())
         n_bad, ok = index_mismatch_report(idx.cpu().numpy(), kat[f"{tag}_indices"], z.numpy(), levels, tau=1e-6)
         print(f"[fsq {tag}] {n_bad} of {z.shape[0]} indices differ from the reference (1-ulp tanh boundary cases)")
-        assert ok and n_bad <= 1
-        if n_bad == 0:
-            np.testing.assert_array_equal(li.cpu().numpy(), kat[f"{tag}_level_indices"])
+        assert ok and n_bad == 0  # the reference's own known-answer vectors: bit for bit (observed: 0 on every set; round 5 allowed 1)
+        np.testing.assert_array_equal(li.cpu().numpy(), kat[f"{tag}_level_indices"])
         # decode path == reference indices_to_codes followed by project_out
         sel = torch.from_numpy(kat[f"{tag}_dec_idx"])
         codes = torch.from_numpy(kat[f"{tag}_dec_codes"])

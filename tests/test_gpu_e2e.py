@@ -144,7 +144,7 @@ def test_against_committed_reference_vectors(tag, gemm_mode):
     lat = O.encode_audio(w, mc, audio, taps=(taps := {})) and taps["latents"]
     n_bad, ok = index_mismatch_report(ind["indices"].cpu().numpy(), e2e["indices"], lat.numpy(), mc.levels, TAU)
     print(f"[{tag}] index mismatches vs reference vectors: {n_bad}/{e2e['indices'].size}")
-    assert ok and n_bad <= 1  # observed: 0
+    assert ok and n_bad == 0  # the metric says "indices bit-exact": against the COMMITTED reference vectors a flipped token is a regression (observed: 0)
     wave = codec.decode_audio(indices=torch.from_numpy(e2e["indices"]).cuda()).cpu()
     if tag == "tiny":
         assert _max_err(f"{tag} {gemm_mode} wave vs reference e2e vector", wave.numpy(), e2e["wave"]) < WAVE_ATOL
@@ -231,7 +231,7 @@ def test_full_batch_properties_1kbps():
     taps = {}
     _, ind_ref = O.encode_audio(w, mc, audio[sel].cpu(), taps=taps)
     n_bad, ok = index_mismatch_report(idx[sel].cpu().numpy(), ind_ref["indices"].numpy(), taps["latents"].numpy(), mc.levels, TAU)
-    assert ok and n_bad <= 1  # observed: 0
+    assert ok and n_bad == 0  # the BASELINE batch: strict (observed: 0)
 
 
 from tests.helpers import ORACLE_CHUNK, oracle_indices as _oracle_indices  # (each chunk of clips encoded once per session)
@@ -244,8 +244,8 @@ OBSERVED_FULL_BATCH_MISMATCHES = {"1kbps": 0, "3kbps": 0}
 @pytest.mark.parametrize("tag", ["1kbps", "3kbps"])
 def test_index_agreement_full_batch(tag):
     """Every token of the BASELINE batches (config 2: 1kbps 256 x 1 s = 15 360 tokens; config 3: 3kbps 256 x 1 s = 42 752
-    tokens) against the oracle, on both GEMM routes.  A mismatch is tolerated only as a single-level flip of a latent within
-    TAU = 1e-4 level units of its rounding boundary, and the count may not exceed the observed one by more than 1."""
+    tokens) against the oracle, on both GEMM routes.  These are the batches the headline metric ("indices bit-exact") is quoted on: the
+    count must EQUAL the observed one — 0 — and a flipped token fails the test (round 5 allowed observed + 1)."""
     codec = _codec(tag, 0)
     mc = codec.network.mc
     w = W.folded_weights(codec.network.state_dicts())
@@ -260,7 +260,7 @@ def test_index_agreement_full_batch(tag):
             print(f"[index agreement {tag} {'split' if route else 'exact'}] {rep}")
             assert rep["tokens"] == 256 * (-(-16000 // mc.hop_length))
             assert rep["single_step"] and rep["max_margin_of_mismatches"] < TAU
-            assert rep["mismatches"] <= OBSERVED_FULL_BATCH_MISMATCHES[tag] + 1
+            assert rep["mismatches"] == OBSERVED_FULL_BATCH_MISMATCHES[tag]
     finally:
         codec.network.set_gemm_split(before)
 
@@ -296,7 +296,9 @@ def test_parity_under_trained_weight_statistics(tag):
         return orig_snake(x, alpha)
     O.snake = counting_snake
     try:
-        idx_ref, lat_ref = _oracle_indices(w, mc, audio)
+        idx_ref, lat_ref = _oracle_indices(w, mc, audio, use_cache=False)  # (the counting hook must see the ENCODER run, in any test order)
+        enc_evals = seen["n"]
+        assert enc_evals > 0, "the oracle's encoder did not run under the counting snake"
         wave_ref = torch.cat([O.decode_audio(w, mc, indices=idx_ref[b0:b0 + ORACLE_CHUNK]) for b0 in range(0, len(idx_ref), ORACLE_CHUNK)])
     finally:
         O.snake = orig_snake
@@ -336,8 +338,8 @@ def test_parity_under_trained_weight_statistics(tag):
     assert g_min >= 0.25 and torch.equal(ind_x["indices"], ind_f["indices"])
 
 
-# (after the stress test: that one counts the snake arguments the oracle's ENCODER sees, so it has to be the one that fills the
-# session cache of oracle outputs for the stress batch)
+# (round 5 needed this test to run after the stress test, which had to be the one to fill the session cache; round 6: the stress test
+# bypasses the cache for its hooked evaluation, so the order no longer matters)
 # option "down_fused" (default off): observed mismatches with the narrow encoder down layers in their one-kernel bf16x3 form
 OBSERVED_DOWN_FUSED_MISMATCHES = {"1kbps": 0, "stress_3kbps": 1}
 
@@ -369,8 +371,11 @@ def test_index_agreement_with_fused_down_layers(tag):
     assert rep["mismatches"] <= OBSERVED_DOWN_FUSED_MISMATCHES[tag] + 1
 
 
-# mismatches observed on the MI355X per (config, input set), both GEMM routes (round 3; every one a +-1 flip within TAU)
-OBSERVED_WIDE_MISMATCHES = {}
+# mismatches observed on the MI355X per (config, input set), both GEMM routes (round 3; every one a +-1 flip within TAU).  The one entry
+# is an exact tie: the latent lies 9.4e-9 level units from its rounding boundary, below fp32 resolution of the scaled value; its flat token
+# number (clip * tokens per clip + token) is asserted below, so a DIFFERENT flipped token cannot hide behind the count.
+OBSERVED_WIDE_MISMATCHES = {("3kbps", "noise seed 2"): 1}
+KNOWN_TIES = {("3kbps", "noise seed 2"): 9694}  # clip 58, token 8 (167 tokens per clip), both routes
 OBSERVED_WIDE_WAVE_ERR = 1.4e-3  # structured set, 64 clips, both routes: observed <= 7.2e-4 (x ~2, see WAVE_ATOL)
 
 
@@ -397,7 +402,12 @@ def test_index_agreement_other_seeds_and_structured_inputs(tag):
                 rep = index_agreement(ind["indices"].cpu().numpy(), idx_ref.numpy(), lat_ref.numpy(), mc.levels)
                 print(f"[index agreement {tag} {name} {'split' if route else 'exact'}] {rep}")
                 assert rep["single_step"] and rep["max_margin_of_mismatches"] < TAU
+                # random-seed / structured sweeps: the observed count + 1 (a tie may fall either way on another summation order) ...
                 assert rep["mismatches"] <= OBSERVED_WIDE_MISMATCHES.get((tag, name), 0) + 1
+                # ... but the known tie must be THE flipped token when it is the only one
+                known = KNOWN_TIES.get((tag, name))
+                if known is not None and rep["mismatches"] == 1:
+                    assert rep["mismatch_positions"] == [known], f"a different token flipped: {rep['mismatch_positions']} (known tie: {known})"
                 if name == "structured":
                     wave = codec.decode_audio(indices=idx_ref.cuda()).cpu()
                     wave_ref = torch.cat([O.decode_audio(w, mc, indices=idx_ref[b0:b0 + ORACLE_CHUNK]) for b0 in range(0, len(idx_ref), ORACLE_CHUNK)])

@@ -344,3 +344,29 @@ def test_bench_rank_path_runs_at_world_2_on_cpu():
     for extra in (["--dry-run-cpu"], ["--codec-factory", "tests.standin_codec:make_codec"]):
         r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2"] + extra, capture_output=True, text=True, env=env, timeout=300)
         assert r.returncode != 0
+
+
+def test_bench_rank_path_runs_at_world_8_at_config_4_shape():
+    """BASELINE config 4 (2048 clips sharded over 8 ranks, outputs gathered) through bench.py's N-rank path with EIGHT real processes on
+    CPU (gloo), 256 clips x 1 s per rank at the 1kbps geometry (tests/standin_codec.py::make_shape_codec: the real shapes, trivial
+    arithmetic): the launcher's rendezvous, 8 barriers, async gathers of [2048, 60] tokens and [2048, 16200] samples retired one step
+    late, per-rank times, max over ranks, the relayed JSON line.  The first real 8-GPU run can then only fail on RCCL, not on plumbing."""
+    import json
+    import os
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--dry-run-cpu",
+                        "--codec-factory", "tests.standin_codec:make_shape_codec"],
+                       capture_output=True, text=True, env=env, timeout=600, cwd=str(REPO))
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["dry_run_cpu"] is True and line["metric"].startswith("DRY RUN") and line["collective_backend"] == "gloo"
+    assert line["n_gpus"] == 8 and line["rccl_ranks"] == 8 and line["scaling"] == "weak"   # (rccl_ranks: an all-reduce of ones over the group — gloo here)
+    assert line["config"]["batch_per_gpu"] == 256 and line["config"]["samples_per_clip"] == 16000
+    assert line["gathered_shapes"] == [[2048, 60], [2048, 16200]]
+    assert len(line["per_rank_ms_per_step"]) == 8 and all(t > 0 for t in line["per_rank_ms_per_step"])
+    assert abs(line["ms_per_step"] - max(line["per_rank_ms_per_step"])) < 1e-6
+    assert abs(line["value"] - 8 * 256 * 16000 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]
+    assert "summary" in line and list(line)[-1] == "summary"   # the compact summary is the LAST key of the line
