@@ -33,7 +33,7 @@ PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA (same guide: ~2.5 PFLOP/s)
 # fp32-equivalent FLOPs is the bf16 peak / 6
 PEAK_SPLIT_TFLOPS = PEAK_BF16_TFLOPS / 6.0
 PEAK_HBM_GBS = 8000.0    # HBM3E spec
-SPLIT_KERNELS = ("gemm_split_kernel", "gemm_split_kernel_w256", "gemm_split_kernel_w256d", "gemm_split_conv_kernel", "conv_unit_wide_kernel", "conv_unit_split_kernel", "legacy_unit_split_kernel")
+SPLIT_KERNELS = ("gemm_split_kernel", "gemm_split_kernel_w256", "gemm_split_conv_kernel", "conv_unit_wide_kernel", "conv_unit_split_kernel", "legacy_unit_split_kernel")
 
 
 def algorithmic_gflop_per_clip_second(mc):

@@ -65,8 +65,6 @@ void gemm_split_image_host(const float* w, int64_t ldw, int n, int k, unsigned c
 int launch_gemm_split_image(hipStream_t s, const float* w, int64_t ldw, int n, int k, unsigned char* img);  // device
 int launch_gemm_split(hipStream_t s, const GemmArgs& g);
 bool gemm_split_w256_ok(const GemmArgs& g);
-bool gemm_split_w256d_ok(const GemmArgs& g);   // ... its deferred-epilogue form: K = 512, snake + GRN epilogue (the C = 512 stage's first product)
-int launch_gemm_split_w256d(hipStream_t s, const GemmArgs& g);
 int launch_gemm_split_w256(hipStream_t s, const GemmArgs& g);  // gemm_split_w256.hip: a batch's rows, n % 256 == 0, an even number of whole k tiles
 
 // ------------------------------------------------------------------------------------------------

@@ -665,13 +665,12 @@ bool gemm_split_conv_ok(const GemmArgs& g) {
     return g.cin > 0 && g.cin % BK == 0 && g.k == g.taps * g.cin && g.frames > 0 && g.m % g.frames == 0 && g.m < ((int64_t)1 << 31) && g.lda == g.cin;
 }
 
-// L3AC_GEMM_W256 (bits; A/B measurements — same bits either way): 0 the batch products of 256-column weights stay on gemm_split_kernel |
-// 1 the light-epilogue long-K products on gemm_split_kernel_w256 | 2 every eligible shape there | 4 the K = 512 snake + GRN product on the
-// deferred-epilogue form gemm_split_kernel_w256d
+// L3AC_GEMM_W256 (A/B measurements — same bits either way): 0 the batch products of 256-column weights stay on gemm_split_kernel |
+// 1 (default) the light-epilogue long-K products on gemm_split_kernel_w256 | 2 every eligible shape there
 static int w256_enabled() {
     static const int on = [] {
         const char* e = std::getenv("L3AC_GEMM_W256");
-        return e ? std::atoi(e) : 5;
+        return e ? std::atoi(e) : 1;
     }();
     return on;
 }
@@ -722,14 +721,13 @@ int launch_gemm_split(hipStream_t s, const GemmArgs& g) {
     const int cus = l3ac_device_cu_count();
     // a batch's rows, 256-column blocks, long K, a light epilogue (the C = 512 stage's second product): one wave per SIMD, 192 x 256 per
     // workgroup (gemm_split_w256.hip).  Measured inside the 256-clip step (profiles/r06/gemm_w256.md): 24480 x 512 x 2048 0.242 -> 0.221 ms;
-    // the first product (K = 512, snake + GRN epilogue: four tiles per CU, each with an exposed 38 k-cycle epilogue) 0.246 -> 0.258,
+    // the first product (K = 512, snake + GRN epilogue: four tiles per CU, each with an exposed 38 k-cycle epilogue) 0.246 -> 0.258 — and
+    // 0.265 in a persistent form that runs a tile's epilogue inside the next tile's k loop (tools/patches/gemm_split_w256d.patch) —,
     // 46080 x 256 x 512 0.063 -> 0.066: those stay on gemm_split_kernel (L3AC_GEMM_W256=2 sends them here too: same bits)
-    const int w256 = conv ? 0 : w256_enabled();  // bit 0: the light-epilogue products | bit 1: every eligible shape | bit 2: the deferred-epilogue form
-    const bool use_w256d = (w256 & 4) && gemm_split_w256d_ok(g) && blocks > cus;
-    const bool use_w256 = !use_w256d && w256 && gemm_split_w256_ok(g) && blocks > cus &&
-                          ((w256 & 2) || ((w256 & 1) && g.k >= 1024 && (g.epi == EPI_BIAS || g.epi == EPI_BIAS_RES)));
+    const int w256 = conv ? 0 : w256_enabled();  // 1: the light-epilogue long-K products | 2: every eligible shape
+    const bool use_w256 = w256 && gemm_split_w256_ok(g) && blocks > cus && (w256 >= 2 || (g.k >= 1024 && (g.epi == EPI_BIAS || g.epi == EPI_BIAS_RES)));
     char name[64];
-    std::snprintf(name, sizeof(name), "%s %lldx%dx%d e%d", conv ? "gemm_split_conv_kernel" : use_w256d ? "gemm_split_kernel_w256d" : use_w256 ? "gemm_split_kernel_w256" : "gemm_split_kernel",
+    std::snprintf(name, sizeof(name), "%s %lldx%dx%d e%d", conv ? "gemm_split_conv_kernel" : use_w256 ? "gemm_split_kernel_w256" : "gemm_split_kernel",
                   (long long)g.m, g.n, g.k, g.epi);
     const double c_cols = g.epi == EPI_GEGLU ? (double)g.ldc : (double)g.n;
     ProfScope prof(s, name, 2.0 * (double)g.m * g.n * g.k,
@@ -778,8 +776,6 @@ int launch_gemm_split(hipStream_t s, const GemmArgs& g) {
             hipLaunchKernelGGL((gemm_split_kernel_slices<true>), dim3(grid), dim3(THREADS), 2 * W_TILE, s, g);
         else
             hipLaunchKernelGGL((gemm_split_kernel_slices<false>), dim3(grid), dim3(THREADS), 2 * W_TILE, s, g);
-    } else if (use_w256d) {
-        L3AC_TRY(launch_gemm_split_w256d(s, g));
     } else if (use_w256) {
         L3AC_TRY(launch_gemm_split_w256(s, g));
     } else if (blocks <= cus) {

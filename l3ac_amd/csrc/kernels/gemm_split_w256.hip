@@ -1,8 +1,6 @@
 // The bf16x3 GEMM of gemm_split.hip for a BATCH's rows and weights of 256-column blocks (the C = 512 stage: 2048 x 512 and 512 x 2048),
 // at ONE wave per SIMD with a hand-placed instruction stream.  Built with -fno-slp-vectorize (l3ac_amd/build.py): the split's per-element
 // subtractions must stay single-issue instructions beside the MFMAs (packed fp32 costs several times its issue slot there).
-#include <algorithm>
-
 #include "gemm_split_common.hpp"
 #define L3AC_DIAG_UNIT_GEMM_W256
 #include "diag.hpp"
@@ -142,16 +140,6 @@ __global__ __launch_bounds__(THREADS, 1) void gemm_split_kernel_w256(const GemmA
     const int last = n_tiles - 1;
 
     W256_STAMP(0);
-#ifdef W256_STAGGER
-    // Tiles are uniform, so every CU reaches its epilogue at the same moment and 50 MB of stores meet: 20 k cycles of a tile's 38 k-cycle
-    // epilogue are that wait.  The first workgroup of every CU starts up to three steps late (by blockIdx / 8: evenly inside every XCD);
-    // the workgroups that follow on the CU inherit the phase.
-    if (blockIdx.x < 256u) {
-        const long long delay = (long long)((blockIdx.x >> 3) & 3) * W256_STAGGER;
-        const long long t0 = (long long)__builtin_amdgcn_s_memtime();
-        while ((long long)__builtin_amdgcn_s_memtime() - t0 < delay) __builtin_amdgcn_s_sleep(8);
-    }
-#endif
     const float* a_row[RG];
 #pragma unroll
     for (int h = 0; h < RG; ++h) {
@@ -326,309 +314,6 @@ __global__ __launch_bounds__(THREADS, 1) void gemm_split_kernel_w256(const GemmA
 }
 
 
-// ---- the FIRST product of the C = 512 stage (46080 x 2048 x 512, snake + GRN epilogue): the epilogue of tile i inside the k loop of tile i + 1 ----
-// K = 512 is 16 k tiles: a 192 x 256 tile of gemm_split_kernel_w256 spends 91 k cycles in its k loop and then 38 k cycles on an epilogue
-// that nothing covers at one wave per SIMD — 17 k of vector instructions (snake + GRN on 192 values per lane, 4 cycles each for a lone
-// wave) and 20 k of waiting for 50 MB that every CU stores at the same moment.  Here the workgroup is PERSISTENT (one per CU, tiles
-// b, b + grid, ...), a wave owns 32 rows x 256 columns (RG = 2: 128 accumulator registers), and the finished accumulators of a tile stay
-// in 128 further AGPRs while the NEXT tile's k loop runs: each of its 16 k-tile steps post-processes one sixteenth of them — a half strip
-// of 16 rows x 32 columns — in the gaps behind its MFMAs:
-//   * before the step (the only part outside the hand-placed stream: the accumulator registers are named by the step number, a switch):
-//     8 values per lane -> 2 KB of LDS of this wave (v_accvgpr_read + ds_write_b32); on even steps the five parameter rows of the column
-//     group are read from LDS (the tile's 5 x 256 parameters are put there by the prologue);
-//   * inside the stream: two ds_read_b128 bring the half strip back row-major (lane = row lane >> 3 (+ 8), four columns 4 (lane & 7));
-//     bias, snake and GRN run as 84 stage slots of two single-issue instructions (snake_stage: device_math.hpp's snake_act2 / sin_squared2
-//     and GRN with normaliser 1, operation for operation: same bits as the packed form), two value pairs in flight; two 16-B buffer stores
-//     (rows past the end and the tile without a predecessor: an offset beyond the descriptor's range — dropped by the hardware, no branch).
-// The stores leave at 2 per step and wave instead of in a burst, and the vector work rides in issue slots the k loop leaves empty.
-// Vector-memory instructions and LDS stores of W sit at gaps 8 s + 2 PH: no two waves of the CU issue one in the same MFMA gap.
-// Same image, same k order, same products per accumulator, the epilogue's operations per element in gemm_epilogue16's order: same bits.
-struct SnakePair { float h[2], t[2], n[2], r[2], z[2], p[2], c[2], sv[2], o[2]; int ni[2]; };
-constexpr int SNAKE_STAGES = 20;
-template <int T>
-__device__ __forceinline__ void snake_stage(SnakePair& a, const float (&al)[2], const float (&ia)[2], const float (&ga)[2], const float (&be)[2]) {
-#define L3AC_BOTH(expr) _Pragma("unroll") for (int e = 0; e < 2; ++e) { expr; }
-    if constexpr (T == 0) { L3AC_BOTH(a.t[e] = al[e] * a.h[e]) }
-    else if constexpr (T == 1) { L3AC_BOTH(a.t[e] = __builtin_amdgcn_fmed3f(a.t[e], -SIN2_ARG_MAX, SIN2_ARG_MAX)) }
-    else if constexpr (T == 2) { L3AC_BOTH(a.n[e] = a.t[e] * 0.636619772367581343f) }
-    else if constexpr (T == 3) { L3AC_BOTH(a.n[e] = __builtin_rintf(a.n[e])) }
-    else if constexpr (T == 4) { L3AC_BOTH(a.r[e] = __builtin_fmaf(a.n[e], -1.57079637050628662109375f, a.t[e])) }
-    else if constexpr (T == 5) { L3AC_BOTH(a.r[e] = __builtin_fmaf(a.n[e], 4.37113900018624283e-8f, a.r[e])) }
-    else if constexpr (T == 6) { L3AC_BOTH(a.z[e] = a.r[e] * a.r[e]) }
-    else if constexpr (T == 7) { L3AC_BOTH(a.p[e] = __builtin_fmaf(a.z[e], -1.9515295891e-4f, 8.3321608736e-3f)) }
-    else if constexpr (T == 8) { L3AC_BOTH(a.p[e] = __builtin_fmaf(a.p[e], a.z[e], -1.6666654611e-1f)) }
-    else if constexpr (T == 9) { L3AC_BOTH(a.p[e] = a.p[e] * a.z[e]) }
-    else if constexpr (T == 10) { L3AC_BOTH(a.p[e] = __builtin_fmaf(a.p[e], a.r[e], a.r[e])) }  // sin(r), |r| <= pi/4
-    else if constexpr (T == 11) { L3AC_BOTH(a.p[e] = a.p[e] * a.p[e]) }
-    else if constexpr (T == 12) { L3AC_BOTH(a.c[e] = __builtin_fmaf(a.p[e], -2.0f, 1.0f)) }  // cos(2r)
-    else if constexpr (T == 13) { L3AC_BOTH(a.ni[e] = (int)a.n[e]) }
-    else if constexpr (T == 14) { L3AC_BOTH(a.ni[e] = (int)((unsigned)a.ni[e] << 31)) }
-    else if constexpr (T == 15) { L3AC_BOTH(a.c[e] = __builtin_bit_cast(float, __builtin_bit_cast(int, a.c[e]) ^ a.ni[e])) }  // cos(2u) = (-1)^n cos(2r)
-    else if constexpr (T == 16) { L3AC_BOTH(a.c[e] = __builtin_fmaf(a.c[e], -0.5f, 0.5f)) }  // sin(u)^2
-    else if constexpr (T == 17) { L3AC_BOTH(a.sv[e] = __builtin_fmaf(ia[e], a.c[e], a.h[e])) }  // snake
-    else if constexpr (T == 18) { L3AC_BOTH(a.o[e] = __builtin_fmaf(ga[e], a.sv[e], be[e])) }  // GRN, normaliser 1 (layers.py:115)
-    else { static_assert(T == SNAKE_STAGES - 1, "stage list"); L3AC_BOTH(a.o[e] = a.o[e] + a.sv[e]) }
-#undef L3AC_BOTH
-}
-
-__global__ __launch_bounds__(THREADS, 1) void gemm_split_kernel_w256d(const GemmArgs p) {
-    constexpr int RG = 2, WM = 16 * RG, BMW = 4 * WM, NT = 16, TG = 6 * RG, GAPS = TG * NT, NST = 20 * RG, BAR_GAP = TG * (NT - 1);
-    constexpr int KT = 16;  // k tiles == half strips of a tile: the launcher sends K = 512 only
-    constexpr int EPI_SLOTS = 4 * (SNAKE_STAGES + 1), EPI_GAP0 = 14;  // stage slot e at gap EPI_GAP0 + 2 e
-    static_assert(EPI_GAP0 + 2 * (EPI_SLOTS - 1) < GAPS - 6, "epilogue slots do not fit the k tile");
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_split[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ln = lane & 15, lg = lane >> 4;
-    const int n_cb = p.n / 256;
-    const int64_t panels = (p.m + BMW - 1) / BMW;
-    const int64_t ids = ((panels + 7) / 8) * 8 * n_cb;
-    constexpr int n_tiles = KT, last = KT - 1;
-    const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.c, 0, (int)(unsigned)((uint64_t)p.m * (uint64_t)p.ldc * 4u), 0x00020000);
-    constexpr unsigned DROPPED = 0xfffffff0u;  // beyond every descriptor: the store is dropped
-
-    auto opaque = [](int v) __attribute__((always_inline)) -> int {
-        asm volatile("" : "+v"(v));
-        return v;
-    };
-    const int frag_base = opaque(tile_off(ln, lg));
-    const int store_base = opaque(16 * tid);
-    float* const hs_buf = reinterpret_cast<float*>(smem_split + 4 * W_TILE + 2048 * wave);  // this wave's half strip: 16 rows x 128 B
-    const int er = lane >> 3, eq = lane & 7;  // row-major read-back: rows er, er + 8; columns 4 eq .. + 3
-
-    float4 raw[RG][2];
-    u32x4 af[2][RG][3];
-    u32x4 w_reg[W_LOADS];
-    bf16x8 bq[2][3];
-    f32x4a acc[2][RG][8], prev[2][RG][8];
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int h = 0; h < RG; ++h)
-#pragma unroll
-            for (int t = 0; t < 8; ++t) prev[c][h][t] = f32x4a{0.f, 0.f, 0.f, 0.f};
-    auto lds_barrier = [&]() __attribute__((always_inline)) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    };
-    bool has_prev = false;
-    W256_STAMP(0);
-    int64_t prev_m0 = 0;
-    int prev_n0 = 0;
-    f4 par[5];  // bias, alpha, 1 / alpha, gamma, beta of this lane's four columns of the current column group of 32
-#pragma unroll
-    for (int i = 0; i < 5; ++i) par[i] = f4{0.f, 0.f, 0.f, 0.f};
-    float* const par_lds = reinterpret_cast<float*>(smem_split + 4 * W_TILE + 4 * 2048);  // [5][256]: the previous tile's parameter rows
-    const int par_lane = opaque(4 * W_TILE + 4 * 2048 + 16 * eq);  // (one lane base; row and column group are immediates of the ds_read:
-                                                                   // left alone hipcc keeps a register per address — 40 of them — and spills)
-    const int hs_lane = opaque(4 * W_TILE + 2048 * wave + (4 * lg * 32 + ln) * 4);
-
-    for (int64_t id = blockIdx.x; id < ids; id += gridDim.x) {  // (gridDim.x is a multiple of 8: the XCD of a workgroup's tiles does not change)
-        const unsigned xcd = (unsigned)(id & 7), j = (unsigned)(id >> 3);
-        const int64_t panel = (int64_t)(j / (unsigned)n_cb) * 8 + xcd;
-        if (panel >= panels) continue;  // (the whole workgroup)
-        const int cb = (int)(j % (unsigned)n_cb);
-        const int64_t m0 = panel * BMW;
-        const int n0 = cb * 256;
-        const float* a_row[RG];
-#pragma unroll
-        for (int h = 0; h < RG; ++h) {
-            const int64_t row = m0 + WM * wave + 16 * h + ln;
-            a_row[h] = p.a + (row < p.m ? row : 0) * p.lda + 8 * lg;  // rows past the edge: row 0, never stored
-        }
-        const unsigned char* const w_src = p.w_img + (int64_t)(2 * cb) * n_tiles * W_TILE + 16 * tid;
-        const int64_t w_phase = (int64_t)n_tiles * W_TILE;
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int h = 0; h < RG; ++h)
-#pragma unroll
-                for (int t = 0; t < 8; ++t) acc[c][h][t] = f32x4a{0.f, 0.f, 0.f, 0.f};
-        // ---- prologue: A(0) split, A(1) requested, W(0) in buffer 0 (every wave is past the previous tile's last barrier: nobody reads
-        //      W from LDS any more), fragments of column tile 0
-#pragma unroll
-        for (int h = 0; h < RG; ++h) {
-            raw[h][0] = *reinterpret_cast<const float4*>(a_row[h]);
-            raw[h][1] = *reinterpret_cast<const float4*>(a_row[h] + 4);
-        }
-#pragma unroll
-        for (int ph = 0; ph < 2; ++ph) {
-#pragma unroll
-            for (int i = 0; i < W_LOADS; ++i) w_reg[i] = *reinterpret_cast<const u32x4*>(w_src + ph * w_phase + 16 * THREADS * i);
-#pragma unroll
-            for (int i = 0; i < W_LOADS; ++i) *reinterpret_cast<u32x4*>(smem_split + store_base + ph * W_TILE + 16 * THREADS * i) = w_reg[i];
-        }
-#pragma unroll
-        for (int h = 0; h < RG; ++h) {
-            unsigned pl[3][4];
-            split2(raw[h][0].x, raw[h][0].y, pl[0][0], pl[1][0], pl[2][0]);
-            split2(raw[h][0].z, raw[h][0].w, pl[0][1], pl[1][1], pl[2][1]);
-            split2(raw[h][1].x, raw[h][1].y, pl[0][2], pl[1][2], pl[2][2]);
-            split2(raw[h][1].z, raw[h][1].w, pl[0][3], pl[1][3], pl[2][3]);
-#pragma unroll
-            for (int q = 0; q < 3; ++q) af[0][h][q] = u32x4{pl[q][0], pl[q][1], pl[q][2], pl[q][3]};
-            raw[h][0] = *reinterpret_cast<const float4*>(a_row[h] + BK);
-            raw[h][1] = *reinterpret_cast<const float4*>(a_row[h] + BK + 4);
-        }
-        if (has_prev) {  // the parameter rows of the tile that this k loop post-processes (one column per thread; read from step 0 on, behind the barrier)
-            par_lds[tid] = p.bias[prev_n0 + tid];
-            par_lds[256 + tid] = p.alpha[prev_n0 + tid];
-            par_lds[512 + tid] = p.inv_alpha[prev_n0 + tid];
-            par_lds[768 + tid] = p.gamma[prev_n0 + tid];
-            par_lds[1024 + tid] = p.beta[prev_n0 + tid];
-        }
-        lds_barrier();
-#pragma unroll
-        for (int pl = 2; pl >= 0; --pl) bq[0][pl] = *reinterpret_cast<const bf16x8*>(smem_split + frag_base + pl * W_PLANE);
-
-        // the previous tile's half strip of step E (column group hs = E / 2 of eight, row group h = E % 2): accumulators -> LDS; on even
-        // steps the parameter rows of the column group come from LDS (5 KB per tile, filled in the prologue)
-        auto pre_step = [&](auto e_) __attribute__((always_inline)) {
-            constexpr int E = decltype(e_)::value, hs = E >> 1, h = E & 1, t0 = 2 * hs;
-            if constexpr (h == 0) {
-#pragma unroll
-                for (int i = 0; i < 5; ++i) par[i] = *reinterpret_cast<const f4*>(smem_split + par_lane + (256 * i + 32 * hs) * 4);
-            }
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) *reinterpret_cast<float*>(smem_split + hs_lane + (i * 32 + 16 * tt) * 4) = prev[(t0 + tt) >> 3][h][(t0 + tt) & 7][i];
-        };
-
-        auto k_loop = [&](auto ph_) __attribute__((always_inline)) {
-            constexpr int PH = decltype(ph_)::value;
-#pragma unroll 1
-            for (int kt = 0; kt < n_tiles; ++kt) {
-                const int kt1 = kt + 1 < last ? kt + 1 : last, kt2 = kt + 2 < last ? kt + 2 : last;
-                const int buf_off = (kt & 1) * (2 * W_TILE), nxt_off = 2 * W_TILE - buf_off;  // (wave-uniform)
-                const int fb_cur = frag_base + buf_off, fb_nxt = frag_base + nxt_off, sb_nxt = store_base + nxt_off;
-                auto read_b = [&](int base, int t, int pl, bf16x8 (&b)[3]) __attribute__((always_inline)) {
-                    b[pl] = *reinterpret_cast<const bf16x8*>(smem_split + base + (t >> 3) * W_TILE + pl * W_PLANE + 1024 * (t & 7));
-                };
-                switch (kt) {  // (wave-uniform)
-#define L3AC_CASE(E) case E: pre_step(std::integral_constant<int, E>{}); break;
-                    L3AC_CASE(0) L3AC_CASE(1) L3AC_CASE(2) L3AC_CASE(3) L3AC_CASE(4) L3AC_CASE(5) L3AC_CASE(6) L3AC_CASE(7)
-                    L3AC_CASE(8) L3AC_CASE(9) L3AC_CASE(10) L3AC_CASE(11) L3AC_CASE(12) L3AC_CASE(13) L3AC_CASE(14)
-                    default: pre_step(std::integral_constant<int, 15>{}); break;
-#undef L3AC_CASE
-                }
-                // this step's two output rows of the previous tile: byte offsets into C, or the dropped offset
-                const int hs = kt >> 1, hrow = kt & 1;
-                unsigned c_off[2];
-#pragma unroll
-                for (int jr = 0; jr < 2; ++jr) {
-                    const int64_t m = prev_m0 + WM * wave + 16 * hrow + er + 8 * jr;
-                    c_off[jr] = has_prev && m < p.m ? (unsigned)((m * p.ldc + prev_n0 + 32 * hs + 4 * eq) * 4) : DROPPED;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                SplitPair sp[4];
-                unsigned planes[3][4];
-                SnakePair ep[2];
-                f4 v_in[2], v_out[2];
-                tail_for<GAPS>([&](auto g_) __attribute__((always_inline)) {
-                    constexpr int g = decltype(g_)::value, t = g / TG, r = g % TG, q = r / RG, h = r % RG, win = g / 3;
-                    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
-                    if constexpr (g == BAR_GAP) lds_barrier();  // every wave's stores of W(kt + 1) are in LDS; every wave has read the last fragments of W(kt)
-                    acc[t >> 3][h][t & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[0][h][PA[q]]), bq[t & 1][PB[q]],
-                                                                                      acc[t >> 3][h][t & 7], 0, 0, 0);
-                    // fragments of the next column tile (the last tile: column tile 0 of k tile kt + 1, behind the barrier)
-                    if constexpr (r % (2 * RG) == 0 && r / (2 * RG) < 3) {
-                        constexpr int pl = 2 - r / (2 * RG);
-                        if constexpr (t + 1 < NT) read_b(fb_cur, t + 1, pl, bq[(t + 1) & 1]);
-                        else read_b(fb_nxt, 0, pl, bq[0]);
-                    }
-                    // split of A(kt + 1): stage j = (row group, stage, pair), the four pairs of a row group interleaved
-                    if constexpr (g % 3 == 1 && win < NST) {
-                        constexpr int hh = win / 20, st = (win % 20) / 4, pr = (win % 20) % 4;
-                        if constexpr (st == 0) {
-                            const float4 v = raw[hh][pr >> 1];
-                            sp[pr].x0 = (pr & 1) ? v.z : v.x;
-                            sp[pr].x1 = (pr & 1) ? v.w : v.y;
-                        }
-                        split_stage<st>(sp[pr], planes[0][pr], planes[1][pr], planes[2][pr]);
-                        if constexpr (st == 4 && pr == 3) {
-#pragma unroll
-                            for (int u = 0; u < 3; ++u) af[1][hh][u] = u32x4{planes[u][0], planes[u][1], planes[u][2], planes[u][3]};
-                        }
-                    }
-                    // vector-memory slot s at gap 8 s + 2 PH: 0-5 W phase 0 | 6-7 A(kt + 2) row group 0 | 8-13 W phase 1 | 14-15 A(kt + 2) row group 1
-                    // | 16 the first output row's store; the second one at gap 186 + PH.  (A row group's registers are free once its pairs
-                    // have passed split stage 1: gap 22 / 82.)  A W load is stored to LDS 57 gaps (~1 k cycles) later.
-                    if constexpr (g >= 2 * PH && (g - 2 * PH) % 8 == 0 && (g - 2 * PH) / 8 < 17) {
-                        constexpr int slot = (g - 2 * PH) / 8;
-                        if constexpr (slot < 6) w_reg[slot] = *reinterpret_cast<const u32x4*>(w_src + (int64_t)kt1 * W_TILE + 16 * THREADS * slot);
-                        if constexpr (slot >= 8 && slot < 14)
-                            w_reg[slot - 8] = *reinterpret_cast<const u32x4*>(w_src + w_phase + (int64_t)kt1 * W_TILE + 16 * THREADS * (slot - 8));
-                        if constexpr (slot == 6 || slot == 7) raw[0][slot & 1] = *reinterpret_cast<const float4*>(a_row[0] + kt2 * BK + 4 * (slot & 1));
-                        if constexpr (slot == 14 || slot == 15) raw[1][slot & 1] = *reinterpret_cast<const float4*>(a_row[1] + kt2 * BK + 4 * (slot & 1));
-                        if constexpr (slot == 16) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v_out[0]), c_rsrc, c_off[0], 0, 2);
-                    }
-                    if constexpr (g == 186 + PH) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v_out[1]), c_rsrc, c_off[1], 0, 2);
-                    if constexpr (g >= 57 + 2 * PH && (g - 57 - 2 * PH) % 8 == 0 && (g - 57 - 2 * PH) / 8 < 14) {
-                        constexpr int ss = (g - 57 - 2 * PH) / 8;  // the store of vector-memory slot ss
-                        if constexpr (ss < 6) *reinterpret_cast<u32x4*>(smem_split + sb_nxt + 16 * THREADS * ss) = w_reg[ss];
-                        if constexpr (ss >= 8) *reinterpret_cast<u32x4*>(smem_split + sb_nxt + W_TILE + 16 * THREADS * (ss - 8)) = w_reg[ss - 8];
-                    }
-                    // the previous tile's half strip: back from LDS row-major, then bias + snake + GRN in stage slots, two pairs in flight
-                    if constexpr (g == 3 || g == 6) v_in[g / 3 - 1] = *reinterpret_cast<const f4*>(hs_buf + (er + 8 * (g / 3 - 1)) * 32 + 4 * eq);
-                    if constexpr (g >= EPI_GAP0 && (g - EPI_GAP0) % 2 == 0 && (g - EPI_GAP0) / 2 < EPI_SLOTS) {
-                        constexpr int e = (g - EPI_GAP0) / 2, half = e / (EPI_SLOTS / 2), ee = e % (EPI_SLOTS / 2), st = ee / 2, lo = ee % 2;
-                        // pair (half, lo): values 2 lo, 2 lo + 1 of row `half`; state ep[lo]
-                        const float al[2] = {par[1][2 * lo], par[1][2 * lo + 1]}, ia[2] = {par[2][2 * lo], par[2][2 * lo + 1]};
-                        const float ga[2] = {par[3][2 * lo], par[3][2 * lo + 1]}, be[2] = {par[4][2 * lo], par[4][2 * lo + 1]};
-                        if constexpr (st == 0) {
-                            ep[lo].h[0] = v_in[half][2 * lo] + par[0][2 * lo];
-                            ep[lo].h[1] = v_in[half][2 * lo + 1] + par[0][2 * lo + 1];
-                        } else {
-                            snake_stage<st - 1>(ep[lo], al, ia, ga, be);
-                            if constexpr (st == SNAKE_STAGES) {
-                                v_out[half][2 * lo] = ep[lo].o[0];
-                                v_out[half][2 * lo + 1] = ep[lo].o[1];
-                            }
-                        }
-                    }
-                    if constexpr (g % 3 == 2) {
-#pragma unroll
-                        for (int u = 0; u < 3; ++u) {
-                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x126, 2, 0);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                });
-#pragma unroll
-                for (int h = 0; h < RG; ++h)
-#pragma unroll
-                    for (int u = 0; u < 3; ++u) af[0][h][u] = af[1][h][u];
-            }
-        };
-        if (has_prev && prev_m0 >= 0 && id < (int64_t)blockIdx.x + 2 * (int64_t)gridDim.x) W256_STAMP(1);  // (diagnostic builds: the SECOND tile's k loop, the first one that carries an epilogue)
-        switch (wave) {  // (wave-uniform)
-            case 0: k_loop(std::integral_constant<int, 0>{}); break;
-            case 1: k_loop(std::integral_constant<int, 1>{}); break;
-            case 2: k_loop(std::integral_constant<int, 2>{}); break;
-            default: k_loop(std::integral_constant<int, 3>{}); break;
-        }
-        if (has_prev && id < (int64_t)blockIdx.x + 2 * (int64_t)gridDim.x) W256_STAMP(2);
-        // this tile's accumulators wait for the next tile's k loop
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int h = 0; h < RG; ++h)
-#pragma unroll
-                for (int t = 0; t < 8; ++t) prev[c][h][t] = acc[c][h][t];
-        has_prev = true;
-        prev_m0 = m0;
-        prev_n0 = n0;
-    }
-    // the workgroup's last tile: its epilogue has no k loop to ride in (LDS: the second W buffer, as gemm_split_kernel_w256)
-    if (has_prev) epilogue_rows<RG>(p, prev, prev_m0, prev_n0, wave, lane, reinterpret_cast<float*>(smem_split + 2 * W_TILE + 12288 * wave));
-    W256_STAMP(3);
-}
-
 }  // namespace
 
 // shapes and alignments the 256-column form takes (the dispatcher in gemm_split.hip asks; anything else stays on gemm_split_kernel)
@@ -637,26 +322,6 @@ bool gemm_split_w256_ok(const GemmArgs& g) {
     return g.taps <= 1 && g.k % BK == 0 && g.k / BK >= 2 && g.n % 256 == 0 && g.epi != EPI_GEGLU && g.ldc % 4 == 0 && al16(g.c) && al16(g.bias) &&
            (g.epi != EPI_BIAS_RES || (g.ldres % 4 == 0 && al16(g.res))) &&
            ((g.epi != EPI_SNAKE && g.epi != EPI_SNAKE_GRN) || (al16(g.alpha) && al16(g.inv_alpha))) && (g.epi != EPI_SNAKE_GRN || (al16(g.gamma) && al16(g.beta)));
-}
-
-// the deferred-epilogue form: the C = 512 stage's first product
-bool gemm_split_w256d_ok(const GemmArgs& g) {
-    return gemm_split_w256_ok(g) && g.k == 512 && g.epi == EPI_SNAKE_GRN && (uint64_t)g.m * (uint64_t)g.ldc * 4u < 0xfff00000ull && g.m >= 128 * 64;
-}
-
-int launch_gemm_split_w256d(hipStream_t s, const GemmArgs& g) {
-    L3AC_REQUIRE(gemm_split_w256d_ok(g), "split gemm (deferred-epilogue form): unsupported shape or alignment n=%d k=%d epi=%d", g.n, g.k, g.epi);
-    constexpr int LDS = 4 * W_TILE + 4 * 2048 + 5 * 256 * 4;
-    static PerDeviceOnce configured;
-    if (configured.first()) {
-        L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel_w256d), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        configured.done();
-    }
-    const int64_t ids = ceil_div64(ceil_div64(g.m, 128), 8) * 8 * (g.n / 256);
-    const int64_t grid = std::min<int64_t>(ids, (l3ac_device_cu_count() / 8) * 8);  // persistent: one workgroup per CU, a multiple of the 8 XCDs
-    hipLaunchKernelGGL(gemm_split_kernel_w256d, dim3((unsigned)grid), dim3(THREADS), LDS, s, g);
-    L3AC_LAUNCH_CHECK();
-    return L3AC_OK;
 }
 
 int launch_gemm_split_w256(hipStream_t s, const GemmArgs& g) {
