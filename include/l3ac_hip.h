@@ -285,6 +285,8 @@ int l3ac_ctx_set_gemm_split(l3ac_ctx* ctx, int32_t enable);
  * workgroup per clip.  Both forms return the same bits.  The cooperative form's six workgroups per clip wait for each other: they need
  * six CUs per clip (claimed per context in a process-wide registry; a launch that does not fit runs in the one-workgroup form);
  * failure reporting: l3ac_coop_timeout_count above.  "coop_timeout_ms" (default 250): the time limit of an arrival poll.
+ * "coop_release_claim" (any value): returns the CUs this context has claimed for cooperative launches to the per-device registry (a claim
+ * otherwise only grows until the context is destroyed); not while a graph captured from the context may still replay a cooperative launch.
  * "coop_test_fault" (test hook, default 0): j + 1 makes workgroup j of every clip withhold its first arrival.
  * "down_fused" (default 0): the encoder down layers 24 -> 48 and 48 -> 96 (Conv1d(k = stride) + ChannelNorm) in one kernel on the
  * bf16x3 route instead of an fp32-MFMA GEMM + row kernel: faster, equally accurate, a different rounding of those layers.

@@ -1046,7 +1046,7 @@ __global__ __launch_bounds__(256, 1) void wide_sliced_out_kernel(const ConvUnitW
 }
 
 // frame tiles of 16 up to which the sliced form exists (its hidden image is part of the scratch: 24 C bytes per frame) and up to which
-// it is taken by default (measured against the half-tile form: tools/wide_bench.py, profiles/r05/wide_sliced.md)
+// it is taken by default (measured against the half-tile form: tools/wide_bench.py, profiles/r05/wide_sliced_sweep.txt)
 constexpr int64_t SLICED_MAX_TILES = 256, SLICED_AUTO_TILES = 256;
 __host__ constexpr size_t wide_planes_bytes(int c, int64_t rows) { return (size_t)((rows + 31) / 32) * 32 * (size_t)c * 6; }
 __host__ constexpr int64_t sliced_tiles_pad(int64_t rows) { return ((rows + 15) / 16 + 3) / 4 * 4; }

@@ -199,7 +199,7 @@ __device__ __forceinline__ void gemm_split_body16(const GemmArgs& p, const int g
         load_a(kt + 2 < last ? kt + 2 : last, cur);  // the registers are free again: two tiles ahead
         // Keep these loads HERE.  Nothing reads them before the next iteration, so hipcc's scheduler sinks them to the end of the
         // loop body — just in front of the s_waitcnt vmcnt(0) that opens the next step's split — and every k tile then waits a full
-        // memory latency for its A operand: 3.0-3.5 k of a wave's 6.6 k cycles per k tile (tools/split_stamps.py).
+        // memory latency for its A operand: 3.0-3.5 k of a wave's 6.6 k cycles per k tile (round-3 s_memtime stamps; the tool was retired with the diagnostic build: git show 0304bc1:tools/split_stamps.py).
         __builtin_amdgcn_sched_barrier(0);
         const unsigned char* ws = smem_split + buf * W_TILE;
         if constexpr (DEEP) {

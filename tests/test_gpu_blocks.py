@@ -754,6 +754,10 @@ def test_cooperative_stacks_of_two_contexts_cannot_starve_each_other():
     for ia, ib in outs:
         assert torch.equal(ia, want) and torch.equal(ib, want)
     assert ca.coop_timeout_count() == 0 and cb.coop_timeout_count() == 0
+    # a claim only grows — unless the context gives it back (option coop_release_claim): the registry shrinks by exactly that claim
+    held = lib.l3ac_coop_claimed_cus(0)
+    ca.set_option("coop_release_claim", 1)
+    assert lib.l3ac_coop_claimed_cus(0) < held
     # the claim goes back with the context
     del a, ca, names_a, outs, ia
     gc.collect()

@@ -1,15 +1,16 @@
 #!/bin/bash
 # Run on the GPU box: kernel-trace stats + HBM traffic + MFMA/VALU counters (separate PMC passes, as the guide's
-# rocprofv3 section prescribes: --pmc never combined with a trace domain) for FOUR workloads:
+# rocprofv3 section prescribes: --pmc never combined with a trace domain) for FIVE workloads:
 #   main   bench.py --pipeline-only                 1kbps, 256 x 1 s (the headline step)
 #   3kbps  bench.py --config 3kbps --pipeline-only  BASELINE config 3
 #   b1     tools/b1_profile.py                      one 1 s clip (the streaming chunk of BASELINE config 5), eager
 #   vq     tools/vq_argmin_bench.py --quick         explicit-codebook argmin, K = 250 047, N = 42 752
+#   fsq    tools/fsq_profile.py                     the quantiser alone at 2^22 tokens (the north_star's HBM kernel) + its copy ceiling
 # usage: tools/collect_profiles.sh <outdir under gpurun_out> [workloads...]      (default: all four)
 # The program goes directly after `--` (no env / bash -c hop: the profiler has initialised the GPU by then).
 OUT=$GRAFT_REPO_ROOT/${1:-gpurun_out/prof}
 [ $# -gt 0 ] && shift
-WL=${@:-main 3kbps b1 vq}
+WL=${@:-main 3kbps b1 vq fsq}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -23,6 +24,7 @@ for w in $WL; do
         3kbps) P="$R/bench.py --config 3kbps --steps 3 --warmup 1 --pipeline-only"; PT="$R/bench.py --config 3kbps --steps 12 --warmup 3 --pipeline-only" ;;
         b1)    P="$R/tools/b1_profile.py"; PT=$P ;;
         vq)    P="$R/tools/vq_argmin_bench.py --quick"; PT=$P ;;
+        fsq)   P="$R/tools/fsq_profile.py"; PT=$P ;;
         *) echo "unknown workload $w"; continue ;;
     esac
     D=$OUT/$w

@@ -33,7 +33,8 @@ def load(pattern):
 
 
 WORKLOADS = {"main": ("", "1kbps b256 s16000 split"), "3kbps": ("3kbps_", "3kbps b256 s16000 split"),
-             "b1": ("b1_", "1kbps b1 s16000 split, eager"), "vq": ("vq_", "vq_argmin K250047 N42752 D6")}
+             "b1": ("b1_", "1kbps b1 s16000 split, eager"), "vq": ("vq_", "vq_argmin K250047 N42752 D6"),
+             "fsq": ("fsq_", "fsq forward 2^22 tokens feat128 D6 (1052 B/token algorithmic = 4.412 GB per launch)")}
 
 
 def main(src_root, dst):
@@ -73,6 +74,10 @@ def summarize(src, dst, prefix, workload, fingerprint):
         write = k["write_kb"] / max(k["wl"], 1) * 1024
         traffic[name] = dict(launches=k["launches"], fetch_size_bytes_per_launch=fetch, write_size_bytes_per_launch=write,
                              hbm_bytes_per_launch_corrected=2 * fetch + write)
+    if prefix == "fsq_":  # the north_star kernel: counter bytes against its algorithmic 1 052 B per token
+        for name, t in traffic.items():
+            t["algorithmic_bytes_per_launch"] = (1 << 22) * 1052
+            t["traffic_over_algorithmic"] = t["hbm_bytes_per_launch_corrected"] / t["algorithmic_bytes_per_launch"]
     json.dump(dict(note="FETCH_SIZE doubled (gfx950 wide-read correction), WRITE_SIZE as reported; averages per launch",
                    source_sha256=fingerprint, workload=workload, kernels=traffic), open(dst / f"{prefix}traffic.json", "w"), indent=1)
     sq = collections.defaultdict(lambda: collections.defaultdict(float))
