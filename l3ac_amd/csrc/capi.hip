@@ -173,7 +173,7 @@ int l3ac_create(const l3ac_config* cfg, const l3ac_tensor* tensors, int32_t n_te
     ctx->gemm_split = gemm_split_default();
     {
         const char* e = std::getenv("L3AC_DOWN_FUSED");
-        if (e) ctx->down_fused = std::atoi(e) != 0;
+        if (e) ctx->down_fused = std::atoi(e);
     }
     DeviceGuard guard(device);
     int rc = guard.ok ? network_build(ctx, tensors, n_tensors) : L3AC_EHIP;
@@ -627,7 +627,7 @@ int l3ac_ctx_set_option(l3ac_ctx* ctx, const char* name, int32_t value) {
         trans_coop_release(ctx->coop);
     }
     else if (n == "coop_test_fault") ctx->coop.fault_part = value - 1;  // 0 = off, j + 1 = workgroup j of every clip withholds its first arrival
-    else if (n == "down_fused") ctx->down_fused = value != 0;
+    else if (n == "down_fused") ctx->down_fused = value < 0 ? 0 : (value > 2 ? 2 : value);
     else {
         l3ac_set_error("set_option: unknown option '%s' (gemm_split, head_pretanh, narrow_ring, wide_sliced, trans_coop, coop_timeout_ms, coop_release_claim, coop_test_fault, down_fused)", name);
         return L3AC_EINVAL;

@@ -300,6 +300,154 @@ int launch_uf(hipStream_t s, const UpFusedArgs& a) {
     return launch_uf_waves<CIN, COUT, DOWN, UF_WAVES>(s, a, tiles_per_clip, tiles);
 }
 
+
+// ---- encoder down layers 24 -> 48 and 48 -> 96, EXACT form (round 6): Conv1d(k = stride) + bias + ChannelNorm in one kernel with the
+// arithmetic of the two kernels it replaces — gemm_f32_kernel (v_mfma_f32_32x32x2_f32, bias epilogue) and row_kernel<PLAIN,CN> — bit for
+// bit, so that it can be the DEFAULT (the bf16x3 DOWN form above is an equally accurate but different rounding: one token of the stress
+// weights changes sides with it).  What makes the bits equal:
+//   * products: v_mfma_f32_16x16x4_f32 is, per output element, the k-ordered chain of fused multiply-adds in lane-group order
+//     (tools/probes/mfma_f32_order_probe.hip), as 32x32x2 is in lane-half order.  gemm_f32_kernel feeds k in the order 0, 4, 1, 5, 2, 6, 3, 7
+//     inside every group of 8 (its lanes read 16 B and instruction r takes element r of both halves); here lane group g of instruction j
+//     of group q takes k = 8 q + 4 (g & 1) + (g >> 1) + 2 j: the same sequence (the scheme of gemm_f32_small_kernel), from zero;
+//   * then acc + bias (gemm_epilogue, EPI_BIAS);
+//   * ChannelNorm as row_kernel computes it for these widths: 12 lanes per row, one (C = 48) or two (C = 96) 16-B chunks per lane, a
+//     lane's partial 0 + chunk_j (+ chunk_{j + 12}), summed by the segmented shift-down tree — for 12 lanes
+//     ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7))) + ((v8 + v9) + (v10 + v11)).  In the accumulator layout chunk 4 rt + lg is lane
+//     group lg of row tile rt, so rows_sum (x[lg 0] + x[lg 1]) + (x[lg 2] + x[lg 3]) of tile rt IS the tree's node of chunks 4 rt .. 4 rt + 3,
+//     and the total is (node 0 + node 1) + node 2; the expressions of mean, variance and the affine are row_kernel's, verbatim.
+// One wave owns 16 output frames; the weights sit in LDS as fp32 in fragment order: block (rt, q) = 64 lanes x 8 B = the two values a
+// lane multiplies in group q.  The activation row of a frame is K contiguous floats: lane (frame, g) loads the 16 B it needs of every
+// group (lanes g and g ^ 2 the same 16 B: L1 serves the second) — HBM traffic is the algorithmic 4 K in + 4 Cout out per frame.
+template <int K, int COUT>
+struct DxGeo {
+    static constexpr int NQ = K / 8, RT = COUT / 16;
+    static constexpr int OFF_PAR = RT * NQ * 512;        // bias | nw | nb, COUT floats each
+    static constexpr int LDS = OFF_PAR + 3 * COUT * 4;
+    static_assert(K % 8 == 0 && COUT % 16 == 0 && (COUT == 48 || COUT == 96) && LDS <= 160 * 1024, "geometry (the norm's tree is written for 12 lanes per row)");
+};
+
+template <int K, int COUT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 1) void down_exact_kernel(const UpFusedArgs p, const int tiles_per_clip, const int n_tiles) {
+    using G = DxGeo<K, COUT>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_uf[];
+    float* const par = reinterpret_cast<float*>(smem_uf + G::OFF_PAR);
+    const int tid = threadIdx.x;
+    {
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_uf;
+        for (int blk = wv; blk < G::RT * G::NQ / 2; blk += WAVES) ring_dma_1k(p.img + 1024 * blk, 16u * (unsigned)(tid & 63), lds0 + 1024u * (unsigned)blk);
+    }
+    for (int i = tid; i < COUT; i += 64 * WAVES) {
+        par[i] = p.bias[i];
+        par[COUT + i] = p.nw[i];
+        par[2 * COUT + i] = p.nb[i];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fl = lane & 15, lg = lane >> 4;
+    const int T = p.frames;
+    const unsigned char* const wl = smem_uf + 8 * lane;
+    const bool odd = (lg >> 1) != 0;  // elements 1, 3 of the 16 B (else 0, 2)
+    for (int tile = blockIdx.x * WAVES + wave; tile < n_tiles; tile += gridDim.x * WAVES) {
+        const int b = tile / tiles_per_clip;
+        const int f = 16 * (tile - b * tiles_per_clip) + fl;  // this lane's output frame
+        const bool valid = f < T;
+        const float* const row = p.x + ((int64_t)b * T + (valid ? f : 0)) * K + 4 * (lg & 1);
+        f32x4_t acc[G::RT];
+#pragma unroll
+        for (int rt = 0; rt < G::RT; ++rt) acc[rt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < G::NQ; ++q) {
+            const f32x4_t xv = *reinterpret_cast<const f32x4_t*>(row + 8 * q);
+            const float e0 = odd ? xv[1] : xv[0], e1 = odd ? xv[3] : xv[2];
+#pragma unroll
+            for (int rt = 0; rt < G::RT; ++rt) {
+                const f32x2 wv = *reinterpret_cast<const f32x2*>(wl + (rt * G::NQ + q) * 512);
+                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, e0, acc[rt], 0, 0, 0);
+                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, e1, acc[rt], 0, 0, 0);
+            }
+        }
+        // ---- + bias, ChannelNorm (rows.hip: row_kernel<PLAIN,CN>, 12 lanes per row), store ------------------------------------------
+        // Every operation is spelled with its rounding (__fadd_rn / __fmul_rn / fmaf): hipcc contracts and packs row_kernel's expressions
+        // differently per instantiation — in the compiled row kernels a chunk's squared deviations are (dx dx + dy dy) + (dz dz + dw dw) with
+        // separate multiplies at one chunk per lane (C = 48) and fma(dx, dx, dy dy) + fma(dz, dz, dw dw) at two (C = 96); the affine is
+        // fma(w, rstd d, b) in both (ISA of rows.hip, hipcc 7.2) — and this kernel must not be reshaped on its own.
+        // tests/test_gpu_blocks.py::test_down_and_k3_layers asserts the equality with the two-kernel route bit for bit.
+        float4 v[G::RT];
+#pragma unroll
+        for (int rt = 0; rt < G::RT; ++rt) {
+            const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(par + 16 * rt + 4 * lg);
+            v[rt] = make_float4(__fadd_rn(acc[rt][0], bv[0]), __fadd_rn(acc[rt][1], bv[1]), __fadd_rn(acc[rt][2], bv[2]), __fadd_rn(acc[rt][3], bv[3]));
+        }
+        constexpr int NCH = G::RT / 3;  // chunks per lane of the row kernel: chunk j = 4 rt + lg and, at C = 96, chunk j + 12 = tile rt + 3
+        float node[3];
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const float4 c = v[n + 3 * i];
+                s = __fadd_rn(s, __fadd_rn(__fadd_rn(c.x, c.y), __fadd_rn(c.z, c.w)));
+            }
+            node[n] = rows_sum(s);
+        }
+        const float mean = __fadd_rn(__fadd_rn(node[0], node[1]), node[2]) / (float)COUT;
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const float4 c = v[n + 3 * i];
+                const float dx = __fsub_rn(c.x, mean), dy = __fsub_rn(c.y, mean), dz = __fsub_rn(c.z, mean), dw = __fsub_rn(c.w, mean);
+                const float qc = NCH == 1 ? __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fadd_rn(__fmul_rn(dz, dz), __fmul_rn(dw, dw)))
+                                          : __fadd_rn(fmaf(dx, dx, __fmul_rn(dy, dy)), fmaf(dz, dz, __fmul_rn(dw, dw)));
+                q = i == 0 ? qc : __fadd_rn(q, qc);
+            }
+            node[n] = rows_sum(q);
+        }
+        const float var = __fadd_rn(__fadd_rn(node[0], node[1]), node[2]) / (float)COUT;
+        const float rstd = 1.0f / sqrtf(__fadd_rn(var, p.eps));
+        if (valid) {
+            float* const dst = p.y + ((int64_t)b * T + f) * COUT + 4 * lg;
+#pragma unroll
+            for (int rt = 0; rt < G::RT; ++rt) {
+                const float4 w = *reinterpret_cast<const float4*>(par + COUT + 16 * rt + 4 * lg);
+                const float4 bb = *reinterpret_cast<const float4*>(par + 2 * COUT + 16 * rt + 4 * lg);
+                *reinterpret_cast<float4*>(dst + 16 * rt) =
+                    make_float4(fmaf(w.x, __fmul_rn(rstd, __fsub_rn(v[rt].x, mean)), bb.x), fmaf(w.y, __fmul_rn(rstd, __fsub_rn(v[rt].y, mean)), bb.y),
+                                fmaf(w.z, __fmul_rn(rstd, __fsub_rn(v[rt].z, mean)), bb.z), fmaf(w.w, __fmul_rn(rstd, __fsub_rn(v[rt].w, mean)), bb.w));
+            }
+        }
+    }
+}
+
+template <int K, int COUT>
+int launch_dx(hipStream_t s, const UpFusedArgs& a) {
+    using G = DxGeo<K, COUT>;
+    constexpr int WAVES = 16;
+    static PerDeviceOnce configured;
+    if (configured.first()) {
+        L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(down_exact_kernel<K, COUT, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+        configured.done();
+    }
+    const int tiles_per_clip = (a.frames + 15) / 16;
+    const int64_t tiles = (int64_t)a.batch * tiles_per_clip;
+    L3AC_REQUIRE(tiles < ((int64_t)1 << 31) - 65536, "down_exact: too many tiles");
+    const double rows = (double)a.batch * a.frames;
+    char name[64];
+    std::snprintf(name, sizeof(name), "down_exact_kernel<%d,%d>", K, COUT);
+    ProfScope prof(s, name, rows * 2.0 * K * COUT, rows * 4.0 * (K + COUT));
+    int64_t blocks = ceil_div64(tiles, WAVES);
+    const int64_t cus = l3ac_device_cu_count();
+    if (blocks > cus) blocks = cus;
+    hipLaunchKernelGGL((down_exact_kernel<K, COUT, WAVES>), dim3((unsigned)blocks), dim3(64 * WAVES), G::LDS, s, a, tiles_per_clip, (int)tiles);
+    L3AC_LAUNCH_CHECK();
+    return L3AC_OK;
+}
+
 }  // namespace
 
 bool up_fused_supported(int cin, int cout) { return (cin == 256 && cout == 96) || (cin == 96 && cout == 48) || (cin == 48 && cout == 24); }
@@ -342,5 +490,31 @@ int launch_down_fused(hipStream_t s, const DownW& w, const float* x, float* y, i
     if (k == 240 && w.cout == 96) return launch_uf<240, 96, true>(s, a);
     if (k == 192 && w.cout == 96) return launch_uf<192, 96, true>(s, a);
     l3ac_set_error("down_fused: %d x %d -> %d not supported", w.cin, w.stride, w.cout);
+    return L3AC_EINVAL;
+}
+
+// ---- the EXACT one-kernel form of the same down layers (down_exact_kernel): fp32 weights in fragment order ------------------------------
+// block (rt, q) = 64 lanes x 8 B: lane (r = lane & 15, g = lane >> 4) holds w[16 rt + r][8 q + 4 (g & 1) + (g >> 1)] and the same + 2
+std::vector<unsigned char> down_exact_image(const float* w, int k, int cout) {
+    const int nq = k / 8, rt_n = cout / 16;
+    std::vector<unsigned char> img((size_t)rt_n * nq * 512);
+    for (int rt = 0; rt < rt_n; ++rt)
+        for (int q = 0; q < nq; ++q)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int r = lane & 15, g = lane >> 4, kk = 8 * q + 4 * (g & 1) + (g >> 1);
+                const float v[2] = {w[(size_t)(16 * rt + r) * k + kk], w[(size_t)(16 * rt + r) * k + kk + 2]};
+                std::memcpy(img.data() + ((size_t)(rt * nq + q) * 64 + lane) * 8, v, 8);
+            }
+    return img;
+}
+int launch_down_exact(hipStream_t s, const DownW& w, const float* x, float* y, int batch, int frames_out) {
+    L3AC_REQUIRE(w.exact_img && w.nw && w.nb && x && y && x != y && batch > 0 && frames_out > 0, "down_exact: bad arguments");
+    UpFusedArgs a{};
+    a.x = x; a.y = y; a.batch = batch; a.frames = frames_out; a.scale = 1; a.img = w.exact_img; a.bias = w.b; a.nw = w.nw; a.nb = w.nb; a.eps = 1e-8f;
+    const int k = w.cin * w.stride;
+    if (k == 144 && w.cout == 48) return launch_dx<144, 48>(s, a);
+    if (k == 240 && w.cout == 96) return launch_dx<240, 96>(s, a);
+    if (k == 192 && w.cout == 96) return launch_dx<192, 96>(s, a);
+    l3ac_set_error("down_exact: %d x %d -> %d not supported", w.cin, w.stride, w.cout);
     return L3AC_EINVAL;
 }

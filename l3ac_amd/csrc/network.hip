@@ -412,7 +412,10 @@ int network_build(l3ac_ctx* ctx, const l3ac_tensor* tensors, int n_tensors) {
                 if (up_fused_supported(u.cin, u.cout)) b.extra_imgs.push_back({up_fused_image(b.host_of(u.w), u.cin, u.cout), &u.fused_img});
             for (DownW& d : ctx->enc_down)  // (sized before the loops above as well)
                 if (d.nw && down_fused_supported(d.cin, d.stride, d.cout))
+                {
                     b.extra_imgs.push_back({up_fused_image(b.host_of(d.w), d.cin * d.stride, d.cout), &d.fused_img});
+                    b.extra_imgs.push_back({down_exact_image(b.host_of(d.w), d.cin * d.stride, d.cout), &d.exact_img});
+                }
         }
         if (b.err.empty() && last_block_fused_supported(cl, 9)) {  // (ctx->legacy no longer reallocates: the targets stay valid)
             for (LegacyW& l : ctx->legacy) {
@@ -716,11 +719,14 @@ static int conv_unit_group(const l3ac_ctx* ctx, const ConvUnitW& w, int batch, i
 }
 
 // the one-kernel form of a down layer (up_fused_kernel<K, Cout, DOWN>): bf16x3 route, the narrow encoder stages' widths
-static bool use_down_fused(const l3ac_ctx* ctx, const DownW& w) { return ctx->down_fused && ctx->gemm_split && w.fused_img && w.nw; }
+static bool use_down_fused(const l3ac_ctx* ctx, const DownW& w) { return ctx->down_fused == 1 && ctx->gemm_split && w.fused_img && w.nw; }
+// the exact one-kernel form (down_exact_kernel): the bits of the GEMM + row kernel it replaces, on either route
+static bool use_down_exact(const l3ac_ctx* ctx, const DownW& w) { return ctx->down_fused == 2 && w.exact_img && w.nw; }
 
 int run_down(l3ac_ctx* ctx, hipStream_t s, const DownW& w, const float* x, float* y, int batch, int frames) {
     L3AC_REQUIRE(frames % w.stride == 0, "down layer: frames=%d not a multiple of stride %d", frames, w.stride);
     if (use_down_fused(ctx, w) && x != y) return launch_down_fused(s, w, x, y, batch, frames / w.stride);
+    if (use_down_exact(ctx, w) && x != y) return launch_down_exact(s, w, x, y, batch, frames / w.stride);
     const int64_t rows_out = (int64_t)batch * (frames / w.stride);
     GemmArgs g{};  // Conv1d(k = stride): non-overlapping patches are contiguous in the frame-major layout
     g.a = x; g.lda = (int64_t)w.stride * w.cin; g.w = w.w; g.w_img = ctx->img(w.w); g.ldw = (int64_t)w.stride * w.cin; g.c = y; g.ldc = w.cout;

@@ -24,6 +24,8 @@ struct DownW {  // modules.py:96-99 and local_trans.py:136: Conv1d(k = stride) [
     const float *w, *b, *nw = nullptr, *nb = nullptr;
     // the conv's weight [cout][stride * cin] as bf16x3 pieces for the DOWN form of up_fused_kernel, null when the geometry is not the kernel's
     const unsigned char* fused_img = nullptr;
+    // ... and as fp32 in fragment order for down_exact_kernel (the default one-kernel form: the unfused route's bits)
+    const unsigned char* exact_img = nullptr;
 };
 struct ConvK3W {  // modules.py:110, :150
     int cin = 0, cout = 0;
@@ -108,7 +110,9 @@ struct l3ac_ctx {
     // up_fused_kernel) instead of a small-N fp32-MFMA GEMM + row kernel: option "down_fused" / env L3AC_DOWN_FUSED.  Default 0: it is
     // 0.12 ms faster at 256 clips and as accurate, but a different rounding of the encoder's first layers, and of the tokens compared
     // with the oracle so far one (stress weights, 1.9e-6 of a rounding boundary) changes sides with it — DESIGN.md section 4.
-    int down_fused = 0;
+    // Round 6: value 2 (the DEFAULT) = down_exact_kernel, the same fusion with the unfused route's arithmetic bit for bit (exact fp32 MFMA
+    // chain in gemm_f32_kernel's k order, row_kernel's ChannelNorm tree) on BOTH GEMM routes; 1 = the bf16x3 form; 0 = GEMM + row kernel.
+    int down_fused = 2;
     const unsigned char* img(const float* w) const {  // null on the exact route: launch_gemm then takes the fp32 kernel
         if (!gemm_split) return nullptr;
         auto it = split_img.find(w);
@@ -197,6 +201,8 @@ int launch_up_fused(hipStream_t s, const EnhW& e, const UpW& w, const float* x, 
 // encoder down layer (Conv1d(k = stride) + ChannelNorm) in the same kernel's DOWN form
 bool down_fused_supported(int cin, int stride, int cout);
 int launch_down_fused(hipStream_t s, const DownW& w, const float* x, float* y, int batch, int frames_out);
+std::vector<unsigned char> down_exact_image(const float* w, int k, int cout);
+int launch_down_exact(hipStream_t s, const DownW& w, const float* x, float* y, int batch, int frames_out);
 // fused LegacyUnit / head (kernels/last_block.hip); x must not alias y
 bool last_block_fused_supported(int c, int max_dil);
 // host builders of the LegacyUnit weight images: w1 [c][7][c] (tap-major rows), w2 [c][c]

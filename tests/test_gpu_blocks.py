@@ -451,13 +451,18 @@ def test_down_and_k3_layers(tiny, full):
             ref = F.conv1d(x, w[f"{block}.0.weight"], w[f"{block}.0.bias"], stride=s)
             ref = O.channel_norm_first(ref, w[f"{block}.1.weight"], w[f"{block}.1.bias"])
             ctx = codec.network.context()
-            for fused in (0, 1):  # option "down_fused": the GEMM + row kernel (default) and the one-kernel form where it exists
+            # option "down_fused": 0 = the GEMM + row kernel, 1 = the bf16x3 one-kernel form, 2 (default, round 6) = down_exact_kernel, whose
+            # results must be those of 0 BIT FOR BIT (the exact fp32 MFMA chain in gemm_f32_kernel's k order, row_kernel's ChannelNorm tree)
+            outs = {}
+            for fused in (0, 1, 2):
                 ctx.set_option("down_fused", fused)
                 try:
                     got = G.op_block(ctx, "l3ac_op_down_layer", block, G.to_frames(x), (2, t // s, co))
                 finally:
-                    ctx.set_option("down_fused", 0)
+                    ctx.set_option("down_fused", 2)
                 _close(f"{block} T={t} down_fused={fused}", G.from_frames(got), ref)
+                outs[fused] = got.cpu()
+            assert torch.equal(outs[2], outs[0]), f"{block} T={t}: the exact one-kernel form differs from the GEMM + row kernel route"
     for (codec, mc, w), cases in ((tiny, [("encoder.blocks.6", 24, 16, 50), ("decoder.blocks.0", 16, 32, 50)]),
                                   (full, [("encoder.blocks.8", 192, 128, 180), ("decoder.blocks.0", 128, 512, 180)])):
         for block, ci, co, t in cases:

@@ -340,16 +340,18 @@ def test_parity_under_trained_weight_statistics(tag):
 
 # (round 5 needed this test to run after the stress test, which had to be the one to fill the session cache; round 6: the stress test
 # bypasses the cache for its hooked evaluation, so the order no longer matters)
-# option "down_fused" (default off): observed mismatches with the narrow encoder down layers in their one-kernel bf16x3 form
+# option "down_fused": observed mismatches with the narrow encoder down layers in their one-kernel bf16x3 form (value 1)
 OBSERVED_DOWN_FUSED_MISMATCHES = {"1kbps": 0, "stress_3kbps": 1}
 
 
 @pytest.mark.parametrize("tag", ["1kbps", "stress_3kbps"])
 def test_index_agreement_with_fused_down_layers(tag):
-    """The one-kernel form of the encoder down layers 24 -> 48 and 48 -> 96 (context option "down_fused", default off) is a different —
-    equally accurate — rounding of the encoder's first layers.  The index contract holds with it (single-level flips within TAU of a
-    rounding boundary only); what it costs is printed: on the stress weights the one decision that lies 1.9e-6 level units from its
-    boundary falls on the other side (the reason the option is off by default: without it the only difference on record is an exact tie, 9.4e-9 from its boundary)."""
+    """The encoder down layers 24 -> 48 and 48 -> 96 (Conv1d(k = stride) + ChannelNorm) have two one-kernel forms (context option
+    "down_fused").  Value 2, the DEFAULT since round 6 (down_exact_kernel), evaluates the arithmetic of the GEMM + row kernel it replaces
+    bit for bit: tokens AND q_feature of a whole encode equal those of value 0.  Value 1 (the bf16x3 form, round 4) is a different —
+    equally accurate — rounding of the encoder's first layers: the index contract holds with it (single-level flips within TAU of a
+    rounding boundary only) and what it costs is printed: on the stress weights the one decision that lies 1.9e-6 level units from its
+    boundary falls on the other side — which is why it never became the default, and what a strict gate must catch (profiles/r06/strict_gates.txt)."""
     from tests.helpers import structured_audio
     codec = _codec(tag, 0)
     mc = codec.network.mc
@@ -358,15 +360,18 @@ def test_index_agreement_with_fused_down_layers(tag):
              else seeded_audio(64, 16000))
     idx_ref, lat_ref = _oracle_indices(w, mc, audio)
     ctx = codec.network.context()
-    _, plain = codec.encode_audio(audio.cuda())
-    ctx.set_option("down_fused", 1)
+    q_default, default = codec.encode_audio(audio.cuda())  # value 2
     try:
+        ctx.set_option("down_fused", 0)
+        q_plain, plain = codec.encode_audio(audio.cuda())
+        ctx.set_option("down_fused", 1)
         _, ind = codec.encode_audio(audio.cuda())
     finally:
-        ctx.set_option("down_fused", 0)
+        ctx.set_option("down_fused", 2)
+    assert torch.equal(default["indices"], plain["indices"]) and torch.equal(q_default, q_plain), "down_exact_kernel changed the encoder's bits"
     rep = index_agreement(ind["indices"].cpu().numpy(), idx_ref.numpy(), lat_ref.numpy(), mc.levels)
     differ = int((ind["indices"] != plain["indices"]).sum())
-    print(f"[index agreement {tag} down_fused] {rep}; tokens that differ from the default form's: {differ}")
+    print(f"[index agreement {tag} down_fused=1] {rep}; tokens that differ from the default form's: {differ}")
     assert rep["single_step"] and rep["max_margin_of_mismatches"] < TAU
     assert rep["mismatches"] <= OBSERVED_DOWN_FUSED_MISMATCHES[tag] + 1
 
