@@ -359,15 +359,27 @@ __global__ __launch_bounds__(64 * WAVES, 1) void down_exact_kernel(const UpFused
         f32x4_t acc[G::RT];
 #pragma unroll
         for (int rt = 0; rt < G::RT; ++rt) acc[rt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        // the row's 16-B pieces are requested PH groups at a time, all of a phase before its first product (a wave's loads are otherwise
+        // issued one per group behind the previous group's products: too few bytes in flight for a kernel that is half HBM-bound)
+        constexpr int PH = G::NQ <= 18 ? G::NQ : (G::NQ + 1) / 2;
 #pragma unroll
-        for (int q = 0; q < G::NQ; ++q) {
-            const f32x4_t xv = *reinterpret_cast<const f32x4_t*>(row + 8 * q);
-            const float e0 = odd ? xv[1] : xv[0], e1 = odd ? xv[3] : xv[2];
+        for (int q0 = 0; q0 < G::NQ; q0 += PH) {
+            f32x4_t xv[PH];
 #pragma unroll
-            for (int rt = 0; rt < G::RT; ++rt) {
-                const f32x2 wv = *reinterpret_cast<const f32x2*>(wl + (rt * G::NQ + q) * 512);
-                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, e0, acc[rt], 0, 0, 0);
-                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, e1, acc[rt], 0, 0, 0);
+            for (int i = 0; i < PH; ++i)
+                if (q0 + i < G::NQ) xv[i] = *reinterpret_cast<const f32x4_t*>(row + 8 * (q0 + i));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < PH; ++i) {
+                if (q0 + i >= G::NQ) continue;
+                const int q = q0 + i;
+                const float e0 = odd ? xv[i][1] : xv[i][0], e1 = odd ? xv[i][3] : xv[i][2];
+#pragma unroll
+                for (int rt = 0; rt < G::RT; ++rt) {
+                    const f32x2 wv = *reinterpret_cast<const f32x2*>(wl + (rt * G::NQ + q) * 512);
+                    acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, e0, acc[rt], 0, 0, 0);
+                    acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, e1, acc[rt], 0, 0, 0);
+                }
             }
         }
         // ---- + bias, ChannelNorm (rows.hip: row_kernel<PLAIN,CN>, 12 lanes per row), store ------------------------------------------
