@@ -436,15 +436,24 @@ __global__ __launch_bounds__(64 * WAVES, 1) void down_exact_kernel(const UpFused
     }
 }
 
-template <int K, int COUT>
-int launch_dx(hipStream_t s, const UpFusedArgs& a) {
+template <int K, int COUT, int WAVES>
+int launch_dx_waves(hipStream_t s, const UpFusedArgs& a, int tiles_per_clip, int64_t tiles) {
     using G = DxGeo<K, COUT>;
-    constexpr int WAVES = 16;
     static PerDeviceOnce configured;
     if (configured.first()) {
         L3AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(down_exact_kernel<K, COUT, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
         configured.done();
     }
+    int64_t blocks = ceil_div64(tiles, WAVES);
+    const int64_t cus = l3ac_device_cu_count();
+    if (blocks > cus) blocks = cus;
+    hipLaunchKernelGGL((down_exact_kernel<K, COUT, WAVES>), dim3((unsigned)blocks), dim3(64 * WAVES), G::LDS, s, a, tiles_per_clip, (int)tiles);
+    L3AC_LAUNCH_CHECK();
+    return L3AC_OK;
+}
+
+template <int K, int COUT>
+int launch_dx(hipStream_t s, const UpFusedArgs& a) {
     const int tiles_per_clip = (a.frames + 15) / 16;
     const int64_t tiles = (int64_t)a.batch * tiles_per_clip;
     L3AC_REQUIRE(tiles < ((int64_t)1 << 31) - 65536, "down_exact: too many tiles");
@@ -452,12 +461,10 @@ int launch_dx(hipStream_t s, const UpFusedArgs& a) {
     char name[64];
     std::snprintf(name, sizeof(name), "down_exact_kernel<%d,%d>", K, COUT);
     ProfScope prof(s, name, rows * 2.0 * K * COUT, rows * 4.0 * (K + COUT));
-    int64_t blocks = ceil_div64(tiles, WAVES);
-    const int64_t cus = l3ac_device_cu_count();
-    if (blocks > cus) blocks = cus;
-    hipLaunchKernelGGL((down_exact_kernel<K, COUT, WAVES>), dim3((unsigned)blocks), dim3(64 * WAVES), G::LDS, s, a, tiles_per_clip, (int)tiles);
-    L3AC_LAUNCH_CHECK();
-    return L3AC_OK;
+    // few tiles (a single clip: 34 tiles at 48 -> 96): four-wave workgroups — one wave per SIMD, each tile's 360 fp32 MFMAs on a matrix pipe of
+    // its own instead of four tiles per pipe on three CUs (a tile's arithmetic does not depend on the form: the same bits)
+    if (2 * ceil_div64(tiles, 16) <= l3ac_device_cu_count()) return launch_dx_waves<K, COUT, 4>(s, a, tiles_per_clip, tiles);
+    return launch_dx_waves<K, COUT, 16>(s, a, tiles_per_clip, tiles);
 }
 
 }  // namespace
