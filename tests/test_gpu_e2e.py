@@ -319,7 +319,9 @@ def test_parity_under_trained_weight_statistics(tag):
             rep = index_agreement(ind["indices"].cpu().numpy(), idx_ref.numpy(), lat_ref.numpy(), mc.levels)
             print(f"[index agreement {tag} {name}] {rep}")
             assert rep["single_step"] and rep["max_margin_of_mismatches"] < TAU
-            assert rep["mismatches"] <= OBSERVED_STRESS_MISMATCHES.get((tag, name), 0) + 1
+            # strict since round 6 (the arithmetic is deterministic on this hardware: the count is a property of the build): the bf16x3 down
+            # layers (L3AC_DOWN_FUSED=1), which move ONE stress_3kbps token across its boundary, fail here — profiles/r06/strict_gates.txt
+            assert rep["mismatches"] == OBSERVED_STRESS_MISMATCHES.get((tag, name), 0)
             wave = codec.decode_audio(indices=idx_ref.cuda()).cpu()
             err = (wave - wave_ref).abs()
             print(f"[{tag} {name}] waveform given identical indices: max|err| {float(err.max()):.3e} rms {float(err.pow(2).mean().sqrt()):.3e} "
