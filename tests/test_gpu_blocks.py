@@ -2,6 +2,7 @@
 import time
 
 import numpy as np
+from pathlib import Path
 import pytest
 import torch
 
@@ -103,6 +104,25 @@ def test_gemm_split_forms_return_the_same_bits():
         for rows in (180, 60, 1, 400):
             small = G.gemm_split(a[:rows].contiguous().cuda(), w.cuda(), b.cuda()).cpu()
             assert torch.equal(small, big[:rows]), f"n={n} k={k}: {rows} rows alone differ from the same rows of a {m_big}-row call"
+
+
+def test_gemm_split_w256_returns_the_same_bits():
+    """Round 6: gemm_split_kernel_w256 (one wave per SIMD, 192 x 256 per workgroup) takes the long-K light-epilogue batch products by default
+    (L3AC_GEMM_W256=1) and every eligible shape with =2 — among them the snake + GRN epilogue of the C = 512 stage's first product, which the
+    default never sends there.  The switch is read once per process: one subprocess per value, and every digest (ragged row counts, both
+    weight shapes, a 256-column weight, the whole C = 512 ConvUnit) must equal the old kernel's (=0)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    outs = {}
+    for mode in ("0", "1", "2"):
+        env = dict(os.environ, L3AC_GEMM_W256=mode)
+        r = subprocess.run([sys.executable, str(Path(__file__).resolve().parent / "w256_digest.py")], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[mode] = json.loads(r.stdout.strip().splitlines()[-1])
+    print(f"[gemm_split_w256] digests: {outs['0']}")
+    assert outs["1"] == outs["0"] and outs["2"] == outs["0"], {k: (outs["0"][k], outs["1"][k], outs["2"][k]) for k in outs["0"] if len({outs[m][k] for m in outs}) > 1}
 
 
 def test_gemm_f32_forms_return_the_same_bits():
