@@ -288,8 +288,10 @@ int l3ac_ctx_set_gemm_split(l3ac_ctx* ctx, int32_t enable);
  * "coop_release_claim" (any value): returns the CUs this context has claimed for cooperative launches to the per-device registry (a claim
  * otherwise only grows until the context is destroyed); not while a graph captured from the context may still replay a cooperative launch.
  * "coop_test_fault" (test hook, default 0): j + 1 makes workgroup j of every clip withhold its first arrival.
- * "down_fused" (default 0): the encoder down layers 24 -> 48 and 48 -> 96 (Conv1d(k = stride) + ChannelNorm) in one kernel on the
- * bf16x3 route instead of an fp32-MFMA GEMM + row kernel: faster, equally accurate, a different rounding of those layers.
+ * "down_fused" (default 2): the encoder down layers 24 -> 48 and 48 -> 96 (Conv1d(k = stride) + ChannelNorm) in one kernel instead of an
+ * fp32-MFMA GEMM + row kernel.  2: down_exact_kernel — the arithmetic of those two kernels bit for bit, on both GEMM routes; 1: the bf16x3
+ * form of round 4 — faster, equally accurate, a DIFFERENT rounding of those layers (one token of the stress weights changes sides); 0: the
+ * two kernels.
  * "wide_sliced" (default 1): the wide ConvUnits (C = 96 .. 256) of few frames — up to 256 tiles of 16, a streaming chunk — as two
  * launches over frame tiles x channel slices instead of the fused kernel whose waves own their frames end to end; 0 never, 2 wherever
  * the form exists.  The same bits either way.
