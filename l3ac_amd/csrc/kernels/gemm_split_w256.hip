@@ -104,11 +104,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& p, f32x4a (&acc)[2
                 } else if (p.epi == EPI_BIAS_RES) {
                     v = *reinterpret_cast<const f4*>(p.res + m * p.ldres + col) + v;
                 }
-#ifdef W256_PLAIN_STORE
-                *reinterpret_cast<f4*>(p.c + m * p.ldc + col) = v;
-#else
                 __builtin_nontemporal_store(v, reinterpret_cast<f4*>(p.c + m * p.ldc + col));
-#endif
             }
         }
     }
@@ -176,9 +172,6 @@ __global__ __launch_bounds__(THREADS, 1) void gemm_split_kernel_w256(const GemmA
         raw[h][1] = *reinterpret_cast<const float4*>(a_row[h] + kt * BK + 4);
     };
     auto load_w = [&](int kt, int phase) __attribute__((always_inline)) {
-#ifdef W256_BOUND_NO_LOAD
-        if (kt > 0) return;
-#endif
 #pragma unroll
         for (int i = 0; i < W_LOADS; ++i)
             w_reg[i] = *reinterpret_cast<const u32x4*>(w_src + phase * w_phase + (int64_t)kt * W_TILE + 16 * THREADS * i);
@@ -239,9 +232,7 @@ __global__ __launch_bounds__(THREADS, 1) void gemm_split_kernel_w256(const GemmA
             tail_for<GAPS>([&](auto g_) __attribute__((always_inline)) {
                 constexpr int g = decltype(g_)::value, t = g / TG, r = g % TG, q = r / RG, h = r % RG, win = g / 3;
                 constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
-#ifndef W256_BOUND_NO_BARRIER
                 if constexpr (g == BAR_GAP) lds_barrier();  // every wave's stores of W(kt + 1) are in LDS; every wave has read the last fragments of W(kt)
-#endif
                 acc[t >> 3][h][t & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[0][h][PA[q]]), bq[t & 1][PB[q]],
                                                                                   acc[t >> 3][h][t & 7], 0, 0, 0);
                 // fragments of the next column tile (the last tile: column tile 0 of k tile kt + 1, behind the barrier)
@@ -251,7 +242,6 @@ __global__ __launch_bounds__(THREADS, 1) void gemm_split_kernel_w256(const GemmA
                     else read_b(fb_nxt, 0, pl, bq[0]);
                 }
                 // split of A(kt + 1): stage j = (row group, stage, pair), the four pairs of a row group interleaved
-#ifndef W256_BOUND_NO_SPLIT
                 if constexpr (g % 3 == 1 && win < NST) {
                     constexpr int hh = win / 20, st = (win % 20) / 4, pr = (win % 20) % 4;
                     if constexpr (st == 0) {
@@ -265,28 +255,21 @@ __global__ __launch_bounds__(THREADS, 1) void gemm_split_kernel_w256(const GemmA
                         for (int u = 0; u < 3; ++u) af[1][hh][u] = u32x4{planes[u][0], planes[u][1], planes[u][2], planes[u][3]};
                     }
                 }
-#endif
                 // this wave's vector-memory slot / LDS store of the window
                 if constexpr (g % 3 == 2) {
                     if constexpr (win >= PH && (win - PH) % 4 == 0 && (win - PH) / 4 < 18) {
                         constexpr int slot = (win - PH) / 4;
-#ifndef W256_BOUND_NO_W
                         if constexpr (slot < 6) w_reg[slot] = *reinterpret_cast<const u32x4*>(w_src + (int64_t)kt1 * W_TILE + 16 * THREADS * slot);
                         if constexpr (slot >= 10 && slot < 16)
                             w_reg[slot - 10] = *reinterpret_cast<const u32x4*>(w_src + w_phase + (int64_t)kt1 * W_TILE + 16 * THREADS * (slot - 10));
-#endif
-#ifndef W256_BOUND_NO_A
                         // (a row group's registers are free once its pairs have passed split stage 1: window 20 hh + 7)
                         if constexpr (slot >= 6 && slot < 10) raw[(slot - 6) >> 1][slot & 1] = *reinterpret_cast<const float4*>(a_row[(slot - 6) >> 1] + kt2 * BK + 4 * (slot & 1));
                         if constexpr (slot >= 16) raw[2][slot & 1] = *reinterpret_cast<const float4*>(a_row[2] + kt2 * BK + 4 * (slot & 1));
-#endif
                     }
-#ifndef W256_BOUND_NO_W
                     if constexpr (win >= 20 + PH && (win - 20 - PH) % 4 == 0 && (win - 20 - PH) / 4 < 6)
                         *reinterpret_cast<u32x4*>(smem_split + sb_nxt + 16 * THREADS * ((win - 20 - PH) / 4)) = w_reg[(win - 20 - PH) / 4];
                     if constexpr (win >= 60 + PH && (win - 60 - PH) % 4 == 0 && (win - 60 - PH) / 4 < 6)
                         *reinterpret_cast<u32x4*>(smem_split + sb_nxt + W_TILE + 16 * THREADS * ((win - 60 - PH) / 4)) = w_reg[(win - 60 - PH) / 4];
-#endif
 #pragma unroll
                     for (int u = 0; u < 3; ++u) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
