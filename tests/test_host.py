@@ -370,3 +370,26 @@ def test_bench_rank_path_runs_at_world_8_at_config_4_shape():
     assert abs(line["ms_per_step"] - max(line["per_rank_ms_per_step"])) < 1e-6
     assert abs(line["value"] - 8 * 256 * 16000 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]
     assert "summary" in line and list(line)[-1] == "summary"   # the compact summary is the LAST key of the line
+
+
+def test_bench_summary_is_compact_and_kernel_names_do_not_alias():
+    """the line's trailing `summary` object must survive a record that keeps a 2 000-character tail (< 400 characters
+    with every field filled); and the traffic summary of `gemm_split_kernel` must not be attached to `gemm_split_kernel_w256` or the
+    other way round (round 6 added a kernel whose name extends an existing one)."""
+    import json
+
+    import bench
+    out = {"ms_per_step": 13.3186, "fsq_kernel": {"frac": 0.6101, "frac_of_copy_ceiling": 0.9263, "copy_ceiling_best_residency": {"frac_of_peak": 0.6601}},
+           "configs": {"stream_1s_graph": {"ms_per_chunk": 0.8440, "pipelined_encode_decode": {"ms_per_chunk": 0.6223}}, "3kbps_b256": {"ms_per_step": 12.0881}},
+           "exact_f32_mfma_route": {"ms_per_step": 23.3478}, "cpu_baseline": {"index_agreement": {"split": {"mismatches": 0}, "exact": {"mismatches": 0}}},
+           "roofline": {"kernel": "conv_unit_wide_kernel<256>", "frac": 0.5860}, "kernels": [{"name": "gemm_split_kernel", "ms": 1.561}, {"name": "gemm_split_kernel_w256", "ms": 1.308},
+                                                                                              {"name": "gemm_split_conv_kernel", "ms": 0.109}]}
+    sm = bench.summary_of(out)
+    assert len(json.dumps(sm)) < 400
+    assert sm["chunk_ms"] == 0.844 and sm["fsq_frac"] == 0.61 and sm["index_mismatches"] == {"split": 0, "exact": 0} and sm["gemm_split_ms"] == 2.869
+    assert bench.summary_of({})["ms_per_step"] is None  # a dry run / a partial line still yields the object
+    profiled = ["gemm_split_kernel<false>", "gemm_split_kernel<true>", "gemm_split_kernel_w256<3>", "gemm_split_conv_kernel", "conv_unit_wide_kernel<256, 2>",
+                "conv_unit_wide_kernel<192, 2>"]
+    assert bench.match_traffic_kernels("gemm_split_kernel", profiled) == ["gemm_split_kernel<false>", "gemm_split_kernel<true>"]
+    assert bench.match_traffic_kernels("gemm_split_kernel_w256", profiled) == ["gemm_split_kernel_w256<3>"]
+    assert bench.match_traffic_kernels("conv_unit_wide_kernel<256>", profiled) == ["conv_unit_wide_kernel<256, 2>"]
