@@ -292,19 +292,23 @@ __device__ __forceinline__ void wide_front(const ConvUnitW& w, const float* __re
         interior = t0 >= 3 && t0 + 16 * FH + 3 <= frames;  // (inside one clip, hence inside the tensor)
     }
     if (__builtin_amdgcn_readfirstlane((int)interior)) {
+        // every row piece of the tile is requested before the first tap (round 6: the loads were issued block by block behind lane-dependent
+        // branches, three memory round trips per pass).  Of the frame groups either side only lanes 13..15 / 0..2 are used; the other lanes
+        // re-request their own row of the tile's first group (the same lines: no extra traffic, no branch).
+        f32x4_t grp[KB][FH + 2][2];
+        const float* const px0 = x + (row0 - 16 + ln) * C + 8 * lg;  // frame group -1: its lanes 13..15 are the left halo
+#pragma unroll
+        for (int b = 0; b < KB; ++b)
+#pragma unroll
+            for (int gi = 0; gi < FH + 2; ++gi) {
+                const bool wanted = gi == 0 ? ln >= 13 : gi == FH + 1 ? ln <= 2 : true;
+                const float* const q = px0 + 32 * b + (wanted ? (int64_t)gi * 16 * C : (int64_t)16 * C);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) grp[b][gi][h] = *reinterpret_cast<const f32x4_t*>(q + 4 * h);
+            }
 #pragma unroll
         for (int b = 0; b < KB; ++b) {
             const int c0 = 32 * b + 8 * lg;
-            const float* px = x + (row0 - 16 + ln) * C + c0;  // frame group -1: its lanes 13..15 are the left halo
-            f32x4_t grp[FH + 2][2];
-#pragma unroll
-            for (int gi = 0; gi < FH + 2; ++gi) {
-                // (of the groups either side only the three frames next to the tile are read — lanes 13..15 / 0..2: - 1.2 % of the kernel)
-                const bool wanted = gi == 0 ? ln >= 13 : gi == FH + 1 ? ln <= 2 : true;
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-                    grp[gi][h] = wanted ? *reinterpret_cast<const f32x4_t*>(px + (int64_t)gi * 16 * C + 4 * h) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-            }
             f32x4_t wt[7][2], bs[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -319,7 +323,7 @@ __device__ __forceinline__ void wide_front(const ConvUnitW& w, const float* __re
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float wv[7] = {wt[0][h][e], wt[1][h][e], wt[2][h][e], wt[3][h][e], wt[4][h][e], wt[5][h][e], wt[6][h][e]};
-                        cv[fh][b][4 * h + e] = dw_taps_dpp(bs[h][e], grp[fh + 1][h][e], grp[fh][h][e], grp[fh + 2][h][e], wv);
+                        cv[fh][b][4 * h + e] = dw_taps_dpp(bs[h][e], grp[b][fh + 1][h][e], grp[b][fh][h][e], grp[b][fh + 2][h][e], wv);
                     }
         }
     } else {
@@ -346,6 +350,11 @@ __device__ __forceinline__ void wide_front(const ConvUnitW& w, const float* __re
                         a1[e] = fmaf(in_clip ? x1[e] : 0.f, w1[e], a1[e]);
                     }
                 }
+                // (left alone hipcc requests the 126 row and weight pieces of all six (frame half, block) pairs first, spills them as they
+                // arrive — s_waitcnt vmcnt(0) + scratch_store after every load — and the ~1.4 % of the tiles that touch a clip boundary hold
+                // their workgroup's slot barriers for most of a pass)
+                // (the sums pass through the statement: the taps are finished, and their operands dead, before the next pair's loads)
+                asm volatile("" : "+v"(a0), "+v"(a1)::"memory");
 #pragma unroll
                 for (int e = 0; e < 4; ++e) cv[fh][b][e] = a0[e], cv[fh][b][4 + e] = a1[e];
             }
@@ -500,7 +509,12 @@ __global__ __launch_bounds__(256, WGeo<C>::WG_PER_CU) void conv_unit_wide_kernel
         // (block s = 2 b + fh of the image: k block b, frame half fh; FH = 1 keeps the blocks of its own half: ap[b])
         bf16x8 ap[G::NS1 / (3 - FH)][3];
         if constexpr (G::FRONT) {
-            wide_front<C, FH>(w, x, rows, frames, row0, tile_ok, ln, lg, ap);
+            // (the lane number made opaque per pass: what the front end derives from it — row pointers, parameter addresses — is then computed
+            // here instead of being hoisted out of the pass loop, where at 256 registers for the loop every such value was spilled and came back
+            // through scratch behind an s_waitcnt vmcnt(0), one memory round trip each)
+            int lane_f = lane;
+            asm volatile("" : "+v"(lane_f));
+            wide_front<C, FH>(w, x, rows, frames, row0, tile_ok, lane_f & 15, lane_f >> 4, ap);
         } else {
             const unsigned char* src = planes + (tile_ok ? tile32 : 0) * (int64_t)(G::NS1 * 3072) + 16 * lane + (FH == 1 ? fsel * 3072 : 0);
 #pragma unroll
@@ -687,7 +701,10 @@ __global__ __launch_bounds__(256, WGeo<C>::WG_PER_CU) void conv_unit_wide_kernel
         // ---- the residual rows of this wave's tile, all 4 C bytes per frame at once: the operand planes are dead from here on, so
         //      their registers hold the 8 x C/32 row pieces while the last second product runs (fetched tile by tile inside the
         //      store loop they cost 8 serial memory latencies: 21 k of a pass's 263 k cycles)
-        const int er = lane >> 3, es = lane & 7;  // row within a group of 8, 16-B slot
+        int lane_e = lane;
+        if constexpr (G::WG_PER_CU == 2) asm volatile("" : "+v"(lane_e));  // (as for the front end: the epilogue's addresses are computed here)
+        const int er = lane_e >> 3, es = lane_e & 7;  // row within a group of 8, 16-B slot
+        const int ln_e = G::WG_PER_CU == 2 ? lane_e & 15 : ln, lg_e = G::WG_PER_CU == 2 ? lane_e >> 4 : lg;
         float4 xres[G::CT][2 * FH];
 #pragma unroll
         for (int ct = 0; ct < G::CT; ++ct)
@@ -735,9 +752,9 @@ __global__ __launch_bounds__(256, WGeo<C>::WG_PER_CU) void conv_unit_wide_kernel
                 for (int rtl = 0; rtl < 2; ++rtl)
 #pragma unroll
                     for (int fh = 0; fh < FH; ++fh) {
-                        const int fr = 16 * fh + ln;
+                        const int fr = 16 * fh + ln_e;
                         const f32x4_t v = yacc[2 * ct + rtl][fh];
-                        *reinterpret_cast<float4*>(tb + 128 * fr + 16 * ((4 * rtl + lg) ^ ((fr ^ (fr >> 3)) & 7))) = make_float4(v.x, v.y, v.z, v.w);
+                        *reinterpret_cast<float4*>(tb + 128 * fr + 16 * ((4 * rtl + lg_e) ^ ((fr ^ (fr >> 3)) & 7))) = make_float4(v.x, v.y, v.z, v.w);
                     }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();

@@ -26,14 +26,25 @@ block = {256: "decoder.blocks.4.1.module", 192: "encoder.blocks.7.0.module", 96:
 codec = l3ac_amd.get_model("1kbps", synthetic_seed=0)
 codec.network.to(device="cuda").eval()
 ctx = codec.network.context()
-x = torch.randn(batch, frames, c, device="cuda")
-y = torch.empty_like(x)
+import os
+part = os.environ.get("STAMP_PART", "")  # experiment: run on the first / second half of an allocation twice the size
+if part:
+    xb = torch.randn(2 * batch, frames, c, device="cuda")
+    yb = torch.empty_like(xb)
+    x = xb[:batch] if part == "lo" else xb[batch:]
+    y = yb[:batch] if part == "lo" else yb[batch:]
+else:
+    x = torch.randn(batch, frames, c, device="cuda")
+    y = torch.empty_like(x)
 lib = ctx.lib
 s = torch.cuda.current_stream().cuda_stream
 for _ in range(3):
     _capi.check(lib.l3ac_op_conv_unit(ctx.handle, block.encode(), x.data_ptr(), batch, frames, y.data_ptr(), s))
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+reps = int(sys.argv[4]) if len(sys.argv) > 4 else 1  # back-to-back launches (no idle gap: clocks as inside a step); the stamps are the LAST one's
+for _ in range(reps - 1):
+    _capi.check(lib.l3ac_op_conv_unit(ctx.handle, block.encode(), x.data_ptr(), batch, frames, y.data_ptr(), s))
 e0.record()
 _capi.check(lib.l3ac_op_conv_unit(ctx.handle, block.encode(), x.data_ptr(), batch, frames, y.data_ptr(), s))
 e1.record()
@@ -63,3 +74,15 @@ print("share of a pass: " + ", ".join(f"{n_} {100 * v:.1f}%" for n_, v in zip(na
 span = np.array([st[b, :, 6].max() - st[b, 0, 0] for b in range(NB) if st[b, 0, 0] > 0])
 print(f"kernel span per block: median {np.median(span) / 1e3:.0f}k cycles, max {span.max() / 1e3:.0f}k; "
       f"ideal MFMA-only: {passes * (4 * c // 32) * (c // 16 + c // 16) * 6 * 32 / 1e3:.0f}k")
+
+if os.environ.get("STAMP_DETAIL"):
+    t00 = min(st[b, 0, 0] for b in range(NB) if st[b, 0, 0] > 0)
+    for p in range(passes):
+        blk = [b for b in range(NB) if st[b, p, 0] > 0 and st[b, p, 5] > 0]
+        loop = np.array([st[b, p, 4] - st[b, p, 3] for b in blk])
+        start = np.array([st[b, p, 0] - t00 for b in blk])
+        q = np.percentile(loop, [0, 10, 50, 90, 100]) / 1e3
+        qs = np.percentile(start, [0, 10, 50, 90, 100]) / 1e3
+        lo = np.median(loop[: len(blk) // 2]) / 1e3
+        hi = np.median(loop[len(blk) // 2:]) / 1e3
+        print(f"pass {p}: loop min/p10/p50/p90/max {q.round(1).tolist()}  blocks<half {lo:.1f}k >=half {hi:.1f}k | pass start (k ticks after the first) {qs.round(0).tolist()}")
