@@ -617,6 +617,7 @@ int l3ac_ctx_set_option(l3ac_ctx* ctx, const char* name, int32_t value) {
     if (n == "gemm_split") ctx->gemm_split = value != 0;
     else if (n == "head_pretanh") ctx->head_pretanh = value != 0;
     else if (n == "wide_sliced") ctx->wide_sliced = value < 0 ? 0 : (value > 2 ? 2 : value);
+    else if (n == "unit_counter") ctx->unit_counter = value != 0;
     else if (n == "narrow_ring") ctx->narrow_ring = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "trans_coop") ctx->coop.enabled = value != 0;
     else if (n == "coop_timeout_ms") ctx->coop.timeout_ms = value < 1 ? 1 : (value > 20000 ? 20000 : value);
@@ -629,7 +630,7 @@ int l3ac_ctx_set_option(l3ac_ctx* ctx, const char* name, int32_t value) {
     else if (n == "coop_test_fault") ctx->coop.fault_part = value - 1;  // 0 = off, j + 1 = workgroup j of every clip withholds its first arrival
     else if (n == "down_fused") ctx->down_fused = value < 0 ? 0 : (value > 2 ? 2 : value);
     else {
-        l3ac_set_error("set_option: unknown option '%s' (gemm_split, head_pretanh, narrow_ring, wide_sliced, trans_coop, coop_timeout_ms, coop_release_claim, coop_test_fault, down_fused)", name);
+        l3ac_set_error("set_option: unknown option '%s' (gemm_split, head_pretanh, narrow_ring, wide_sliced, unit_counter, trans_coop, coop_timeout_ms, coop_release_claim, coop_test_fault, down_fused)", name);
         return L3AC_EINVAL;
     }
     return L3AC_OK;

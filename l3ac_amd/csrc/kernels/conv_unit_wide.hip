@@ -68,6 +68,8 @@ struct WGeo {
     // workgroups per CU the other workgroup's loop covers its loads, and at C = 96 the separate kernel's 10 C bytes per frame through HBM
     // cost half of what the main kernel does (0.68 against 1.12 ms at 256 clips)
     static constexpr bool FRONT = WG_PER_CU == 2;
+    // units handed out by a counter instead of lock-step passes (conv_unit_wide_kernel, 'DYN')
+    static constexpr bool DYN = WG_PER_CU == 2;
     static constexpr int HALF_POS = 49152 / SLOT;  // ring positions per opaque LDS base (fragment offsets must fit 16 bits)
     static constexpr int NSTEP = 2 * NA;    // slots per hidden-tile iteration == ring size
     static constexpr int PF = NSTEP - 1;    // slots in flight
@@ -83,7 +85,8 @@ struct WGeo {
     static constexpr int OFF_B2 = OFF_B1 + H4 * 4;
     static constexpr int OFF_RING = OFF_B2 + C * 4;
     static constexpr int OFF_TB = OFF_RING + RING;            // epilogue transposition buffers: 2 x 4 KB per wave
-    static constexpr int LDS = OFF_TB + 4 * 8192;
+    static constexpr int OFF_NEXT = OFF_TB + 4 * 8192;        // (DYN) the next unit of the workgroup, written by thread 0
+    static constexpr int LDS = OFF_NEXT + (WG_PER_CU == 2 ? 16 : 0);
     static_assert(C % 32 == 0 && NS1 % KS == 0 && NS1 % 2 == 0 && SLOT % (DMA_N * 1024) == 0 && COPY_WAVES <= 4 && NSTEP <= 2 * HALF_POS, "bad geometry");
     static_assert(PF >= 3 && WAIT <= 63, "ring too small / vmcnt field too narrow");
     static_assert(LDS <= 160 * 1024, "LDS budget exceeded");
@@ -412,7 +415,7 @@ __device__ __forceinline__ void wide_front(const ConvUnitW& w, const float* __re
 template <int C, int FHK = 2>
 __global__ __launch_bounds__(256, WGeo<C>::WG_PER_CU) void conv_unit_wide_kernel(const ConvUnitW w, const unsigned char* __restrict__ planes,
                                                               const float* __restrict__ x, float* __restrict__ y, const int64_t rows,
-                                                              const int64_t tail_tiles, const int frames) {
+                                                              const int64_t tail_tiles, const int frames, int* __restrict__ counters) {
     using G = WGeo<C>;
     static_assert(FHK == 1 || FHK == 2, "one or two frame halves per wave");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_wide[];
@@ -489,7 +492,8 @@ __global__ __launch_bounds__(256, WGeo<C>::WG_PER_CU) void conv_unit_wide_kernel
                                 : tail_slack        ? (long long)((blockIdx.x >> 3) & 7) * (PASS_CYCLES * 9 / 160)
                                                     : 0;
         const long long t0 = (long long)__builtin_amdgcn_s_memtime();
-        while ((long long)__builtin_amdgcn_s_memtime() - t0 < delay) __builtin_amdgcn_s_sleep(16);
+        if (!(G::DYN && FHK == 2 && counters))
+            while ((long long)__builtin_amdgcn_s_memtime() - t0 < delay) __builtin_amdgcn_s_sleep(16);
     }
     // every wave of the block runs the same number of passes (block barriers inside)
     int pass_no = 0;
@@ -775,6 +779,46 @@ __global__ __launch_bounds__(256, WGeo<C>::WG_PER_CU) void conv_unit_wide_kernel
             __builtin_amdgcn_wave_barrier();
         }
     };
+    if constexpr (G::DYN && FHK == 2) {
+        if (counters) {
+            // DYN (round 6, two workgroups per CU): units handed out by a counter.  The two waves that share a SIMD are not served alike — the
+            // OLDER one (the workgroup dispatched first: blockIdx < gridDim / 2) issues as if it were alone (stamps: hidden-tile loop 54 k
+            // cycles, a pass 81 k) and the younger one gets what is left (loop 106 k, pass 133 k) until the older workgroup has finished,
+            // so with equal shares the first half of the grid ended after 0.7 of the kernel and the second half ran the rest alone
+            // (profiles/r06/wide96_sched/).  Unit u < G4 = a group of four 32-frame tiles; after those, groups of four half tiles of the
+            // last tail_tiles tiles (a shorter last unit per workgroup).  A workgroup's first unit is its blockIdx; thread 0 fetches the
+            // next one at the START of a unit (the answer is not needed before its end) and hands it over through LDS.  Which workgroup
+            // computes a tile does not enter the tile's arithmetic: the same bits.  counters[0] = units handed out beyond the first gridDim,
+            // counters[1] = workgroups that have left; the last one to leave zeroes both for the next launch.
+            int* const next_s = reinterpret_cast<int*>(smem_wide + G::OFF_NEXT);
+            const int64_t g4 = (n_tiles + 3) / 4, total = g4 + (2 * tail_tiles + 3) / 4;
+            int64_t u = blockIdx.x;
+            while (u < total) {
+                int nxt = 0;
+                if (tid == 0) nxt = __hip_atomic_fetch_add(counters, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + (int)gridDim.x;
+                if (u < g4)
+                    run_unit(std::integral_constant<int, 2>{}, 4 * u + wave, n_tiles);
+                else
+                    run_unit(std::integral_constant<int, 1>{}, 2 * n_tiles + 4 * (u - g4) + wave, 2 * tiles32);
+                if (tid == 0) *next_s = nxt;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                u = __builtin_amdgcn_readfirstlane(*next_s);  // (the next write is a whole unit and its barriers away)
+                ++pass_no;
+            }
+            WIDE_STAMP(6);
+            if (tid == 0) {
+                const int left = __hip_atomic_fetch_add(counters + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (left == (int)gridDim.x - 1) {
+                    __hip_atomic_store(counters, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(counters + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            return;
+        }
+    }
     for (int64_t base = (int64_t)blockIdx.x * 4; base < n_tiles; base += tile_stride, ++pass_no)
         run_unit(std::integral_constant<int, FHK>{}, base + wave, n_tiles);  // (every wave of the block runs the same number of passes)
     if constexpr (FHK == 2) {
@@ -1071,7 +1115,7 @@ __host__ constexpr bool sliced_exists(int c, int64_t rows) { return (rows + 15) 
 __host__ constexpr size_t sliced_hidden_bytes(int c, int64_t rows) { return (size_t)(4 * c / 32) * (size_t)sliced_tiles_pad(rows) * 3072; }
 
 template <int C>
-int launch_wide(hipStream_t s, const ConvUnitW& w, const float* x, float* y, unsigned char* planes, int64_t rows, int frames, int sliced_mode) {
+int launch_wide(hipStream_t s, const ConvUnitW& w, const float* x, float* y, unsigned char* planes, int64_t rows, int frames, int sliced_mode, int* counters) {
     using G = WGeo<C>;
     static PerDeviceOnce configured;
     if (configured.first()) {
@@ -1121,7 +1165,7 @@ int launch_wide(hipStream_t s, const ConvUnitW& w, const float* x, float* y, uns
     ProfScope prof(s, name, (double)rows * (16.0 * C * C + (G::FRONT ? 30.0 * C : 0.0)), (double)rows * (G::FRONT ? 8.0 : 14.0) * C);
     if (half) {
         blocks = ceil_div64(2 * tiles, 4);
-        hipLaunchKernelGGL((conv_unit_wide_kernel<C, 1>), dim3((unsigned)blocks), dim3(256), G::LDS, s, w, planes, x, y, rows, (int64_t)0, frames);
+        hipLaunchKernelGGL((conv_unit_wide_kernel<C, 1>), dim3((unsigned)blocks), dim3(256), G::LDS, s, w, planes, x, y, rows, (int64_t)0, frames, (int*)nullptr);
     } else {
         // A large grid runs its tiles in lock-step passes of 4 x 256 and the last pass may be nearly empty (256 x 900 frames at C = 256:
         // 7 200 tiles = 7 full passes + 32 tiles).  A remainder of at most half a pass is left out of the passes and run as HALF tiles
@@ -1130,7 +1174,16 @@ int launch_wide(hipStream_t s, const ConvUnitW& w, const float* x, float* y, uns
         const int64_t full = tiles / per_pass * per_pass, rest = tiles - full;
         const int64_t tail = (full > 0 && 2 * rest <= per_pass) ? rest : 0;
         if (blocks > 256 * G::WG_PER_CU) blocks = 256 * G::WG_PER_CU;
-        hipLaunchKernelGGL((conv_unit_wide_kernel<C, 2>), dim3((unsigned)blocks), dim3(256), G::LDS, s, w, planes, x, y, rows, tail, frames);
+        int64_t tail_k = tail;
+        int* ctr = nullptr;
+        if (G::DYN && counters && tiles > 4 * blocks) {
+            // units by counter (conv_unit_wide_kernel, DYN): the last tile's worth per workgroup as groups of half tiles (measured against
+            // 0, 2 and 4 per workgroup: profiles/r06/wide96_sched/dyn_ab.txt)
+            ctr = counters;
+            tail_k = blocks;
+            if (tail_k > tiles) tail_k = tiles;
+        }
+        hipLaunchKernelGGL((conv_unit_wide_kernel<C, 2>), dim3((unsigned)blocks), dim3(256), G::LDS, s, w, planes, x, y, rows, tail_k, frames, ctr);
     }
     L3AC_LAUNCH_CHECK();
     return L3AC_OK;
@@ -1149,18 +1202,20 @@ size_t conv_unit_wide_scratch_bytes(int c, int64_t rows) {
 
 // x must not alias y; `planes` = at least conv_unit_wide_scratch_bytes(c, batch * frames) bytes of scratch (checked).
 // sliced_mode (context option "wide_sliced"): 0 the fused kernel always, 1 the sliced form for few frames (default), 2 wherever it exists
+// counters: two zeroed ints of the context (the batch form at two workgroups per CU hands its units out by them and leaves them zeroed;
+// null = lock-step passes)
 int launch_conv_unit_wide(hipStream_t s, const ConvUnitW& w, const float* x, float* y, unsigned char* planes, size_t planes_bytes, int batch,
-                          int frames, int sliced_mode) {
+                          int frames, int sliced_mode, int* counters) {
     L3AC_REQUIRE(x != y && w.wide_img && planes && batch > 0 && frames > 0, "conv_unit_wide: bad arguments");
     const int64_t rows = (int64_t)batch * frames;
     L3AC_REQUIRE(planes_bytes >= conv_unit_wide_scratch_bytes(w.c, rows), "conv_unit_wide: scratch of %zu bytes, %zu needed (C=%d, %lld rows)",
                  planes_bytes, conv_unit_wide_scratch_bytes(w.c, rows), w.c, (long long)rows);
     L3AC_REQUIRE(ceil_div64(rows, 4) < ((int64_t)1 << 31), "conv_unit_wide: too many rows");
     switch (w.c) {
-        case 96: return launch_wide<96>(s, w, x, y, planes, rows, frames, sliced_mode);
-        case 128: return launch_wide<128>(s, w, x, y, planes, rows, frames, sliced_mode);
-        case 192: return launch_wide<192>(s, w, x, y, planes, rows, frames, sliced_mode);
-        case 256: return launch_wide<256>(s, w, x, y, planes, rows, frames, sliced_mode);
+        case 96: return launch_wide<96>(s, w, x, y, planes, rows, frames, sliced_mode, counters);
+        case 128: return launch_wide<128>(s, w, x, y, planes, rows, frames, sliced_mode, counters);
+        case 192: return launch_wide<192>(s, w, x, y, planes, rows, frames, sliced_mode, counters);
+        case 256: return launch_wide<256>(s, w, x, y, planes, rows, frames, sliced_mode, counters);
         default:
             l3ac_set_error("conv_unit_wide: C=%d not supported", w.c);
             return L3AC_EINVAL;

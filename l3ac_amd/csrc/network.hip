@@ -463,6 +463,8 @@ int network_build(l3ac_ctx* ctx, const l3ac_tensor* tensors, int n_tensors) {
 
     L3AC_HIP_CHECK(hipMalloc((void**)&ctx->bad_index_count, sizeof(int)));
     L3AC_HIP_CHECK(hipMemset(ctx->bad_index_count, 0, sizeof(int)));
+    L3AC_HIP_CHECK(hipMalloc((void**)&ctx->wide_counters, 64));
+    L3AC_HIP_CHECK(hipMemset(ctx->wide_counters, 0, 64));
     {  // cooperative form of the transformer stacks (few clips: the streaming chunk): its scratch, counters zeroed ONCE here —
        // every launch leaves them zeroed again
         bool any = false;
@@ -518,6 +520,8 @@ int network_build(l3ac_ctx* ctx, const l3ac_tensor* tensors, int n_tensors) {
 void network_free(l3ac_ctx* ctx) {
     if (ctx->bad_index_count) (void)hipFree(ctx->bad_index_count);
     ctx->bad_index_count = nullptr;
+    if (ctx->wide_counters) (void)hipFree(ctx->wide_counters);
+    ctx->wide_counters = nullptr;
     trans_coop_release(ctx->coop);
     if (ctx->coop.scratch) (void)hipFree(ctx->coop.scratch);
     ctx->coop.scratch = nullptr;
@@ -631,7 +635,7 @@ static bool use_wide(const l3ac_ctx* ctx, const ConvUnitW& w) {
 
 int conv_unit_step(l3ac_ctx* ctx, hipStream_t s, const ConvUnitW& w, float** cur, float** alt, int batch, int frames) {
     if (use_wide(ctx, w)) {
-        L3AC_TRY(launch_conv_unit_wide(s, w, *cur, *alt, reinterpret_cast<unsigned char*>(ctx->ws.h), ctx->ws.h_cap * sizeof(float), batch, frames, ctx->wide_sliced));
+        L3AC_TRY(launch_conv_unit_wide(s, w, *cur, *alt, reinterpret_cast<unsigned char*>(ctx->ws.h), ctx->ws.h_cap * sizeof(float), batch, frames, ctx->wide_sliced, ctx->unit_counter ? ctx->wide_counters : nullptr));
         float* t = *cur;
         *cur = *alt;
         *alt = t;
@@ -692,7 +696,7 @@ int run_conv_units(l3ac_ctx* ctx, hipStream_t s, const std::vector<ConvUnitW>& u
 
 int run_conv_unit(l3ac_ctx* ctx, hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames) {
     if (x != y && use_wide(ctx, w))
-        return launch_conv_unit_wide(s, w, x, y, reinterpret_cast<unsigned char*>(ctx->ws.h), ctx->ws.h_cap * sizeof(float), batch, frames, ctx->wide_sliced);
+        return launch_conv_unit_wide(s, w, x, y, reinterpret_cast<unsigned char*>(ctx->ws.h), ctx->ws.h_cap * sizeof(float), batch, frames, ctx->wide_sliced, ctx->unit_counter ? ctx->wide_counters : nullptr);
     if (!ctx->cfg.grn_exact && x != y && conv_unit_fused_supported(w.c)) return launch_conv_unit_fused(s, w, x, y, batch, frames, ctx->gemm_split, ctx->narrow_ring);
     const int group = conv_unit_group(ctx, w, batch, frames);
     for (int b0 = 0; b0 < batch; b0 += group) {

@@ -104,6 +104,9 @@ struct l3ac_ctx {
     // weight ring) or conv_unit_split_kernel (32 frames per wave, chunk barriers); l3ac_ctx_set_option(ctx, "narrow_ring", 0 / 1)
     // the wide ConvUnits (C = 96 .. 256) of FEW frames — a streaming chunk — as two launches over (frame tiles x channel slices) instead of
     // the fused kernel, whose waves own their frames end to end (conv_unit_wide.hip, 'the SLICED form'; the same bits)
+    // batch kernels that keep two workgroups per CU resident (conv_unit_wide_kernel<96>) hand their units out by a counter instead of equal
+    // static shares: the workgroup dispatched first is served first by every SIMD and finishes its share early (option "unit_counter")
+    int unit_counter = 1;
     int wide_sliced = 1;  // 0: never, 1: where it is faster (up to 256 frame tiles of 16: measured), 2: wherever the form exists (the same today; tests)
     int narrow_ring = 1;  // 0: conv_unit_split_kernel everywhere, 1: the ring kernel where it is faster (C = 48), 2: wherever it exists (C = 24 too)
     // encoder down layers 24 -> 48 and 48 -> 96 (Conv1d(k = stride) + ChannelNorm) in one kernel on the bf16x3 route (the DOWN form of
@@ -149,6 +152,7 @@ struct l3ac_ctx {
     // "trans_coop" (default 1) switches the form off without freeing it
     TransCoopState coop;
     int* bad_index_count = nullptr;  // device: indices outside [0, codebook size) seen by l3ac_decode since the last reset
+    int* wide_counters = nullptr;    // device, 64 B, zeroed: conv_unit_wide_kernel's unit counters (every launch leaves them zeroed)
     float* grn_min_sumsq = nullptr;  // device: smallest per-clip sum of squares any GRN of this context has seen (grn_exact only)
     hipEvent_t ws_done = nullptr;
     hipStream_t ws_stream = nullptr;
@@ -177,7 +181,7 @@ std::vector<unsigned char> conv_unit_w2_image(const float* w2, int c);  // w2 [c
 bool conv_unit_wide_supported(int c);
 size_t conv_unit_wide_scratch_bytes(int c, int64_t rows);
 int launch_conv_unit_wide(hipStream_t s, const ConvUnitW& w, const float* x, float* y, unsigned char* planes, size_t planes_bytes, int batch,
-                          int frames, int sliced_mode);
+                          int frames, int sliced_mode, int* counters);
 std::vector<unsigned char> conv_unit_wide_image(const float* w1, const float* w2, int c);  // w1 [4c][c], w2 [c][4c]
 // one LocalTrans stack per launch, one workgroup per clip (kernels/trans_stack.hip); x [batch][frames][128] in place
 bool trans_stack_supported(int dim, int dim_head, int heads, int ff_inner, int frames, int window, int n_layers);

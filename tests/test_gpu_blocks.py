@@ -427,6 +427,31 @@ def test_conv_units_wide_sliced_form_returns_the_same_bits(full):
         assert want in [e["name"] for e in prof.entries]
 
 
+def test_conv_unit_wide_unit_counter_returns_the_same_bits(full):
+    """Round 6: at two workgroups per CU (C = 96) the batch form hands its units — groups of four 32-frame tiles, then groups of four half
+    tiles — out by a device counter (option "unit_counter", default 1) instead of equal static shares.  Which workgroup computes a tile must
+    not show: the same bits as the static form, on consecutive launches (the last workgroup to leave zeroes the counters for the next
+    launch), for a ragged last tile, and for a row count just above the grid's first pass."""
+    codec, mc, w = full
+    ctx = codec.network.context()
+    for block, b, t in (("decoder.blocks.7.0.module", 31, 2700), ("decoder.blocks.7.1.module", 64, 2699), ("decoder.blocks.7.0.module", 25, 2700)):
+        xf = G.to_frames(_rand((b, 96, t), 9100 + b))
+        outs = {}
+        for mode in (1, 0, 1, 1):
+            ctx.set_option("unit_counter", mode)
+            try:
+                with _capi.profile() as prof:
+                    y = G.op_block(ctx, "l3ac_op_conv_unit", block, xf, (b, t, 96))
+            finally:
+                ctx.set_option("unit_counter", 1)
+            assert "conv_unit_wide_kernel<96>" in [e["name"] for e in prof.entries]
+            if mode in outs:
+                assert torch.equal(outs[mode], y), f"{block} B={b} T={t}: two launches with unit_counter={mode} differ"
+            outs[mode] = y
+        assert torch.equal(outs[0], outs[1]), f"{block} B={b} T={t}: units by counter differ from static shares"
+    _close("unit counter, C = 96", G.from_frames(outs[1]), O.conv_unit(w, "decoder.blocks.7.0.module", G.from_frames(xf)), atol=5e-5, rtol=5e-5)
+
+
 def test_conv_units_wide_scratch_on_a_fresh_context():
     """The wide ConvUnit's front end writes bf16x3 planes of WHOLE 32-frame tiles (conv_unit_wide_scratch_bytes) into the
     hidden scratch: more than the 4C floats per row that scratch is otherwise sized by when batch * frames < 12.  On a
