@@ -295,9 +295,11 @@ int l3ac_ctx_set_gemm_split(l3ac_ctx* ctx, int32_t enable);
  * "wide_sliced" (default 1): the wide ConvUnits (C = 96 .. 256) of few frames — up to 256 tiles of 16, a streaming chunk — as two
  * launches over frame tiles x channel slices instead of the fused kernel whose waves own their frames end to end; 0 never, 2 wherever
  * the form exists.  The same bits either way.
- * "unit_counter" (default 1): batch kernels that keep two workgroups per CU resident (the C = 96 ConvUnits) hand their units of work out
- * by a device counter instead of equal static shares (the workgroup dispatched first is served first by every SIMD and would finish
- * its share early); 0: static shares.  Which workgroup computes a tile does not enter its arithmetic: the same bits either way.
+ * "unit_counter" (default 1; its initial value can be set with the environment variable L3AC_UNIT_COUNTER): batch kernels that keep two
+ * workgroups per CU resident (the C = 96 ConvUnits, the LegacyUnits) hand their units of work out by a device counter instead of equal
+ * static shares (the workgroup dispatched first is served first by every SIMD and would finish its share early); 0: static shares;
+ * 2 / 3 (measurement): only the ConvUnits / only the LegacyUnits.  Which workgroup computes a tile does not enter its arithmetic: the
+ * same bits either way.
  * Unknown names return L3AC_EINVAL. */
 int l3ac_ctx_set_option(l3ac_ctx* ctx, const char* name, int32_t value);
 int32_t l3ac_ctx_get_gemm_split(const l3ac_ctx* ctx);

@@ -174,6 +174,8 @@ int l3ac_create(const l3ac_config* cfg, const l3ac_tensor* tensors, int32_t n_te
     {
         const char* e = std::getenv("L3AC_DOWN_FUSED");
         if (e) ctx->down_fused = std::atoi(e);
+        e = std::getenv("L3AC_UNIT_COUNTER");  // the initial value of option "unit_counter" (A/B runs of bench.py)
+        if (e) ctx->unit_counter = std::atoi(e);  // 0: static shares; 1: all; 2: conv_unit_wide only; 3: legacy units only (measurement)
     }
     DeviceGuard guard(device);
     int rc = guard.ok ? network_build(ctx, tensors, n_tensors) : L3AC_EHIP;
@@ -617,7 +619,7 @@ int l3ac_ctx_set_option(l3ac_ctx* ctx, const char* name, int32_t value) {
     if (n == "gemm_split") ctx->gemm_split = value != 0;
     else if (n == "head_pretanh") ctx->head_pretanh = value != 0;
     else if (n == "wide_sliced") ctx->wide_sliced = value < 0 ? 0 : (value > 2 ? 2 : value);
-    else if (n == "unit_counter") ctx->unit_counter = value != 0;
+    else if (n == "unit_counter") ctx->unit_counter = value < 0 ? 0 : (value > 3 ? 3 : value);
     else if (n == "narrow_ring") ctx->narrow_ring = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "trans_coop") ctx->coop.enabled = value != 0;
     else if (n == "coop_timeout_ms") ctx->coop.timeout_ms = value < 1 ? 1 : (value > 20000 ? 20000 : value);

@@ -27,7 +27,6 @@
 #include "ring_common.hpp"
 #include "split_bf16.hpp"
 
-#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -65,13 +64,14 @@ struct RGeo {
     static constexpr int OFF_B1 = OFF_P + 4 * H4 * 4;
     static constexpr int OFF_B2 = OFF_B1 + H4 * 4;
     static constexpr int OFF_DW = OFF_B2 + CP * 4;
-    static constexpr int LDS = OFF_DW + 10 * CP * 4;
+    static constexpr int OFF_TICKET = OFF_DW + 10 * CP * 4;  // (resident form) the workgroup's next tile ticket
+    static constexpr int LDS = OFF_TICKET + 16;
     static_assert(PP % SP == 0 && (RESIDENT || WAIT <= 63) && LDS * PER_CU <= 160 * 1024 && WAVES * PER_CU <= 16, "bad geometry");
 };
 
 template <class G, int C>
 __global__ __launch_bounds__(64 * G::WAVES, G::WAVES * G::PER_CU / 4) void conv_unit_ring_kernel(const ConvUnitW w, const float* __restrict__ x, float* __restrict__ y,
-                                                                             const int frames, const int tiles_per_clip, const int n_tiles) {
+                                                                             const int frames, const int tiles_per_clip, const int n_tiles, const int tickets) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_ring[];
     float* const Ps = reinterpret_cast<float*>(smem_ring + G::OFF_P);
     float* const B1s = reinterpret_cast<float*>(smem_ring + G::OFF_B1);
@@ -99,6 +99,8 @@ __global__ __launch_bounds__(64 * G::WAVES, G::WAVES * G::PER_CU / 4) void conv_
         DWs[8 * G::CP + i] = ok ? w.ln_w[i] : 0.f;
         DWs[9 * G::CP + i] = ok ? w.ln_b[i] : 0.f;
     }
+    int* const ticket_s = reinterpret_cast<int*>(smem_ring + G::OFF_TICKET);
+    if (tid == 0) *ticket_s = 0;
     __syncthreads();  // (every plain load above is drained here, before the first hand-counted LDS-DMA)
 
     // ---- the weight stream: wave p < 3 copies plane p of every piece --------------------------------------------------
@@ -156,8 +158,20 @@ __global__ __launch_bounds__(64 * G::WAVES, G::WAVES * G::PER_CU / 4) void conv_
     }
 
     const int tile_stride = (int)gridDim.x * G::WAVES;
-    for (int base = (int)blockIdx.x * G::WAVES; base < n_tiles; base += tile_stride) {
-        const int tile = base + wave;
+    // Round 6 (resident form, `tickets`): the waves of a workgroup walk their tiles independently, and a SIMD serves its oldest wave first —
+    // with equal static shares the first waves of a workgroup finish early and the last ones run the end of the kernel on a thinly
+    // occupied CU.  The workgroup keeps its tiles ((round r) gridDim + blockIdx) WAVES + j; a wave takes the next (r, j) by a ticket in LDS.
+    for (int base = (int)blockIdx.x * G::WAVES, q = 0; base < n_tiles; base += tile_stride) {
+        int tile = base + wave;
+        if (G::RESIDENT && tickets) {
+            if (lane == 0) q = __hip_atomic_fetch_add(ticket_s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            q = __builtin_amdgcn_readfirstlane(q);
+            base = ((q / G::WAVES) * (int)gridDim.x + (int)blockIdx.x) * G::WAVES;
+            if (base >= n_tiles) break;
+            tile = base + q % G::WAVES;
+            base -= tile_stride;  // (the loop statement adds it back; the next ticket replaces it anyway)
+            if (tile >= n_tiles) continue;  // the last round's missing tiles: the next ticket ends the walk
+        }
         const bool tile_ok = tile < n_tiles;
         if (G::RESIDENT && !tile_ok) break;
         const int clip = tile_ok ? tile / tiles_per_clip : 0;
@@ -358,7 +372,8 @@ int launch_ring(hipStream_t s, const ConvUnitW& w, const float* x, float* y, int
     if (blocks > places) blocks = places;
     const double rows = (double)batch * frames;
     ProfScope prof(s, name, rows * (14.0 * C + 16.0 * C * C), rows * 8.0 * C);
-    hipLaunchKernelGGL((conv_unit_ring_kernel<G, C>), dim3((unsigned)blocks), dim3(64 * G::WAVES), G::LDS, s, w, x, y, frames, tiles_per_clip, (int)tiles);
+    const int tickets = tiles >= 4 * blocks * G::WAVES;  // (C = 48 at 256 clips: 0.865 -> 0.795 ms, profiles/r06/tickets_ab.txt)
+    hipLaunchKernelGGL((conv_unit_ring_kernel<G, C>), dim3((unsigned)blocks), dim3(64 * G::WAVES), G::LDS, s, w, x, y, frames, tiles_per_clip, (int)tiles, tickets);
     L3AC_LAUNCH_CHECK();
     return L3AC_OK;
 }

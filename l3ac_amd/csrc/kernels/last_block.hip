@@ -250,7 +250,7 @@ __device__ __forceinline__ f32x4_l mfma_split16(const bf16x8 (&a)[3], const bf16
 template <int C>
 __global__ __launch_bounds__(64 * WAVES, 4) void legacy_unit_split_kernel(const LegacyW w, const float* __restrict__ x,
                                                                         float* __restrict__ y, int frames, int tiles_per_clip,
-                                                                        int total_tiles) {
+                                                                        int total_tiles, int* __restrict__ counters) {
     using G = LSGeo<C>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     unsigned char* W1b = smem_b;
@@ -266,11 +266,11 @@ __global__ __launch_bounds__(64 * WAVES, 4) void legacy_unit_split_kernel(const 
     const int dil = w.dil;
     const int rows = FRAMES + 6 * dil;
     const int splane = rows * G::PS;  // bytes between the planes of the S tile
-    const int srow = tid / (C / 4) + (tid < RPP * (C / 4) ? 0 : FRAMES + 54);
-    const int sc0 = 4 * (tid % (C / 4));
+    const int srow_o = tid / (C / 4) + (tid < RPP * (C / 4) ? 0 : FRAMES + 54);
+    const int sc0_o = 4 * (tid % (C / 4));
 
     float4 pre[PF];
-    auto prefetch = [&](int tile) __attribute__((always_inline)) {
+    auto prefetch = [&](int tile, const int srow, const int sc0) __attribute__((always_inline)) {
         const int b = tile / tiles_per_clip;
         const int t0 = (tile - b * tiles_per_clip) * FRAMES;
         const float* clip = x + (int64_t)b * frames * C;
@@ -282,8 +282,14 @@ __global__ __launch_bounds__(64 * WAVES, 4) void legacy_unit_split_kernel(const 
             if (row < rows && t >= 0 && t < frames) pre[j] = *reinterpret_cast<const float4*>(clip + (int64_t)t * C + sc0);
         }
     };
+    // Tiles by counter (round 6, `counters` non-null; conv_unit_wide.hip, 'DYN'): the two workgroups of a CU are not served alike, so equal
+    // static shares end at different times.  A workgroup's first two tiles are blockIdx and blockIdx + gridDim; thread 0 fetches the tile
+    // after next at the top of an iteration and hands it over through LDS behind the iteration's last barrier.  The last workgroup to leave
+    // zeroes the counters.  Which workgroup computes a tile does not enter its arithmetic: the same bits.
+    __shared__ int next_tile_s;
     int tile = blockIdx.x;
-    if (tile < total_tiles) prefetch(tile);
+    int next_tile = tile + (int)gridDim.x;
+    if (tile < total_tiles) prefetch(tile, srow_o, sc0_o);
 
     // weight images are copied verbatim, once per workgroup
     for (int i = tid; i < (G::W1_BYTES + G::W2_BYTES) / 16; i += NT) {
@@ -297,16 +303,17 @@ __global__ __launch_bounds__(64 * WAVES, 4) void legacy_unit_split_kernel(const 
         *reinterpret_cast<float4*>(Ps + 4 * tid) =
             make_float4(ok ? w.a1[tid] : 1.f, ok ? w.ia1[tid] : 0.f, ok ? w.b1[tid] : 0.f, ok ? w.b2[tid] : 0.f);
     }
-    const int ln = lane & 15;  // frame within a 16-frame half (B operand / accumulator column) or weight row within a 16-row tile
-    const int lg = lane >> 4;  // k group of a fragment; rows 4 lg .. 4 lg + 3 of an accumulator tile
     const int m0 = 32 * wave;
-    // per-lane offset inside a (tile hh, plane) weight block: lanes of the padding rows read the tile's last real row
-    int wl[G::NHH];
-#pragma unroll
-    for (int hh = 0; hh < G::NHH; ++hh) wl[hh] = (lg * G::rows_of(hh) + (ln < G::rows_of(hh) ? ln : G::rows_of(hh) - 1)) * 16;
     const int dps = dil * G::PS;
 
-    for (; tile < total_tiles; tile += gridDim.x) {
+    for (; tile < total_tiles;) {
+        int after_next = next_tile + (int)gridDim.x;
+        if (counters && tid == 0) after_next = __hip_atomic_fetch_add(counters, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 2 * (int)gridDim.x;
+        // (the staging thread's row and channel quad, recomputed per tile from an opaque thread number like the lane values below)
+        int tid_t = tid;
+        asm volatile("" : "+v"(tid_t));
+        const int srow = tid_t / (C / 4) + (tid_t < RPP * (C / 4) ? 0 : FRAMES + 54);
+        const int sc0 = 4 * (tid_t % (C / 4));
         const int b = tile / tiles_per_clip;
         const int t0 = (tile - b * tiles_per_clip) * FRAMES;
         const float* clip = x + (int64_t)b * frames * C;
@@ -328,12 +335,23 @@ __global__ __launch_bounds__(64 * WAVES, 4) void legacy_unit_split_kernel(const 
             }
         }
         __syncthreads();
-        if (tile + (int)gridDim.x < total_tiles) prefetch(tile + gridDim.x);  // in flight during the products
+        if (next_tile < total_tiles) prefetch(next_tile, srow, sc0);  // in flight during the products
 
         int woff = 0;  // opaque per tile: keeps the (tile-invariant) weight fragments in LDS instead of ~100 hoisted VGPRs
         asm volatile("" : "+s"(woff));
-        int lgv = lg;  // likewise opaque: the per-step S offsets (selects on the k group) are recomputed, not hoisted and spilled
-        asm volatile("" : "+v"(lgv));
+        // the lane number opaque per tile: everything derived from it — the per-step S offsets (selects on the k group), the per-lane weight
+        // and parameter offsets, the residual / store addresses — is recomputed here, not hoisted out of the tile loop and spilled (round 6:
+        // at 128 registers two to three such values came back from scratch behind an s_waitcnt vmcnt(0) right after the next tile's rows
+        // had been requested: the prefetch was waited for on the spot)
+        int lane_t = lane;
+        asm volatile("" : "+v"(lane_t));
+        const int ln = lane_t & 15;  // frame within a 16-frame half (B operand / accumulator column) or weight row within a 16-row tile
+        const int lg = lane_t >> 4;  // k group of a fragment; rows 4 lg .. 4 lg + 3 of an accumulator tile
+        const int lgv = lg, lnv = ln;
+        // per-lane offset inside a (tile hh, plane) weight block: lanes of the padding rows read the tile's last real row
+        int wl[G::NHH];
+#pragma unroll
+        for (int hh = 0; hh < G::NHH; ++hh) wl[hh] = (lgv * G::rows_of(hh) + (lnv < G::rows_of(hh) ? lnv : G::rows_of(hh) - 1)) * 16;
         const unsigned char* W1t = W1b + woff;
         const unsigned char* W2t = W2b + woff;
         const float* Pt = Ps + woff;
@@ -420,25 +438,45 @@ __global__ __launch_bounds__(64 * WAVES, 4) void legacy_unit_split_kernel(const 
                 for (int fh = 0; fh < 2; ++fh) yt[rt][fh] = mfma_split16(wf, xb[fh], yt[rt][fh]);
             }
             // ---- residual + store: lane (frame 16 fh + ln, row group lg) owns channels 16 rt + 4 lg + {0..3} ---------------
+            // (round 6: the four residual pieces are requested together, from clamped addresses by every lane, and the stores are predicated —
+            // inside `if (t < frames)` / `if (c0 < C)` each piece was load -> s_waitcnt vmcnt(0) -> add -> store: four serial round trips per tile)
+            // (the statement below: not before the first product has been issued — requested earlier the pieces are held across it and spilled)
+            asm volatile("" ::: "memory");
+            float4 xr[2][G::NHH];
 #pragma unroll
             for (int fh = 0; fh < 2; ++fh) {
                 const int t = t0 + m0 + 16 * fh + ln;
-                if (t < frames) {
-                    const float* src = clip + (int64_t)t * C;
-                    float* dst = y + ((int64_t)b * frames + t) * C;
+                const float* src = clip + (int64_t)(t < frames ? t : frames - 1) * C;
 #pragma unroll
-                    for (int rt = 0; rt < G::NHH; ++rt) {
-                        const int c0 = 16 * rt + 4 * lg;
-                        if (c0 < C) {
-                            const float4 xr = *reinterpret_cast<const float4*>(src + c0);
-                            *reinterpret_cast<float4*>(dst + c0) = make_float4(xr.x + yt[rt][fh][0], xr.y + yt[rt][fh][1],
-                                                                               xr.z + yt[rt][fh][2], xr.w + yt[rt][fh][3]);
-                        }
-                    }
+                for (int rt = 0; rt < G::NHH; ++rt) {
+                    const int c0 = 16 * rt + 4 * lg;
+                    xr[fh][rt] = *reinterpret_cast<const float4*>(src + (c0 < C ? c0 : 0));
+                }
+            }
+#pragma unroll
+            for (int fh = 0; fh < 2; ++fh) {
+                const int t = t0 + m0 + 16 * fh + ln;
+                float* dst = y + ((int64_t)b * frames + t) * C;
+#pragma unroll
+                for (int rt = 0; rt < G::NHH; ++rt) {
+                    const int c0 = 16 * rt + 4 * lg;
+                    if (t < frames && c0 < C)
+                        *reinterpret_cast<float4*>(dst + c0) = make_float4(xr[fh][rt].x + yt[rt][fh][0], xr[fh][rt].y + yt[rt][fh][1],
+                                                                           xr[fh][rt].z + yt[rt][fh][2], xr[fh][rt].w + yt[rt][fh][3]);
                 }
             }
         }
+        if (counters && tid == 0) next_tile_s = after_next;
         __syncthreads();  // every wave is done with the S tile before the next one overwrites it
+        tile = next_tile;
+        next_tile = counters ? next_tile_s : after_next;  // (rewritten only behind the next iteration's first barrier)
+    }
+    if (counters && tid == 0) {
+        const int left = __hip_atomic_fetch_add(counters + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (left == (int)gridDim.x - 1) {
+            __hip_atomic_store(counters, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(counters + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -487,7 +525,7 @@ __global__ __launch_bounds__(FRAMES) void head_fused_kernel(const HeadW w, const
 }
 
 template <int C>
-int launch_legacy_t(hipStream_t s, const LegacyW& w, const float* x, float* y, int batch, int frames, bool split_route) {
+int launch_legacy_t(hipStream_t s, const LegacyW& w, const float* x, float* y, int batch, int frames, bool split_route, int* counters) {
     L3AC_REQUIRE(w.dil >= 1 && w.dil <= 9, "legacy unit: dilation %d outside the LDS tile budget", w.dil);
     const bool split = split_route && w.w1_img && w.w2_img;
     using G = LGeo<C>;
@@ -510,7 +548,7 @@ int launch_legacy_t(hipStream_t s, const LegacyW& w, const float* x, float* y, i
                    rows * 8.0 * C);
     if (split)
         hipLaunchKernelGGL((legacy_unit_split_kernel<C>), dim3(grid), dim3(64 * WAVES), lds, s, w, x, y, frames, tiles_per_clip,
-                           (int)total);
+                           (int)total, total > 2 * (int64_t)grid ? counters : nullptr);
     else
         hipLaunchKernelGGL((legacy_unit_kernel<C>), dim3(grid), dim3(64 * WAVES), lds, s, w, x, y, frames, tiles_per_clip, (int)total);
     L3AC_LAUNCH_CHECK();
@@ -532,13 +570,14 @@ int launch_head_t(hipStream_t s, const HeadW& w, const float* x, int batch, int 
 bool last_block_fused_supported(int c, int max_dil) { return (c == 8 || c == 16 || c == 24 || c == 32) && max_dil <= 9; }
 
 // x must not alias y (neighbouring blocks read each other's halo frames)
-int launch_legacy_unit_fused(hipStream_t s, const LegacyW& w, const float* x, float* y, int batch, int frames, bool split) {
+// counters: two zeroed ints of the context (the split kernel hands its tiles out by them and leaves them zeroed; null = static shares)
+int launch_legacy_unit_fused(hipStream_t s, const LegacyW& w, const float* x, float* y, int batch, int frames, bool split, int* counters) {
     L3AC_REQUIRE(x != y && batch <= 65535, "legacy unit: bad arguments");
     switch (w.c) {
-        case 8: return launch_legacy_t<8>(s, w, x, y, batch, frames, split);
-        case 16: return launch_legacy_t<16>(s, w, x, y, batch, frames, split);
-        case 24: return launch_legacy_t<24>(s, w, x, y, batch, frames, split);
-        case 32: return launch_legacy_t<32>(s, w, x, y, batch, frames, split);
+        case 8: return launch_legacy_t<8>(s, w, x, y, batch, frames, split, counters);
+        case 16: return launch_legacy_t<16>(s, w, x, y, batch, frames, split, counters);
+        case 24: return launch_legacy_t<24>(s, w, x, y, batch, frames, split, counters);
+        case 32: return launch_legacy_t<32>(s, w, x, y, batch, frames, split, counters);
         default: l3ac_set_error("legacy unit: C=%d not supported by the fused kernel", w.c); return L3AC_EINVAL;
     }
 }

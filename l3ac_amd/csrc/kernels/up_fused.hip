@@ -55,9 +55,27 @@ struct UfGeo {
     static constexpr int OFF_W = 0;
     static constexpr int OFF_PAR = RT * K1 * 3072;       // bias | nw | nb, CP floats each (zeros beyond cout)
     static constexpr int OFF_GW = OFF_PAR + 3 * CP * 4;  // gate_w [CINP][4] | gate_b [CINP] (zeros beyond cin)
-    static constexpr int LDS = OFF_GW + CINP * 5 * 4;
+    static constexpr int OFF_TICKET = OFF_GW + CINP * 5 * 4;  // the workgroup's next tile ticket (up_fused_kernel, 'tickets')
+    static constexpr int LDS = OFF_TICKET + 16;
     static_assert(CIN % 16 == 0 && COUT % 8 == 0 && LDS <= 160 * 1024, "geometry");
 };
+
+// Tiles by ticket (round 6).  The waves of these workgroups walk their tiles independently and a SIMD serves its OLDEST wave first: with
+// equal static shares (tile = blockIdx WAVES + wave + k gridDim WAVES) the first waves of a workgroup finish early and the last ones run
+// the end of the kernel on a thinly occupied CU (conv_unit_wide.hip, 'DYN': measured there with stamps).  The workgroup keeps its tiles —
+// ((round r) gridDim + blockIdx) WAVES + j — and a wave takes the next (r, j) by a ticket in LDS; n_tiles = nothing left.  Which wave
+// computes a tile does not enter its arithmetic: the same bits.
+template <int WAVES>
+__device__ __forceinline__ int take_tile(int* ticket, const int lane, const int n_tiles) {
+    for (;;) {
+        int q = 0;
+        if (lane == 0) q = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        q = __builtin_amdgcn_readfirstlane(q);
+        const int base = ((q / WAVES) * (int)gridDim.x + (int)blockIdx.x) * WAVES;
+        if (base >= n_tiles) return n_tiles;
+        if (base + q % WAVES < n_tiles) return base + q % WAVES;  // (the last round's missing tiles are skipped)
+    }
+}
 
 // value of the lane one position down / up inside its 16-lane row (frame fl - 1 / fl + 1 of the same k group)
 __device__ __forceinline__ float row_prev(float v) {
@@ -74,7 +92,7 @@ __device__ __forceinline__ float row_next(float v) {
 // are 65 tiles = five 16-wave workgroups on five CUs, each filling 144 KB of LDS first: 31 us; as 17 workgroups of four waves ~ a third).
 // A tile's arithmetic does not depend on it: the same bits.
 template <int CIN, int COUT, bool DOWN, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void up_fused_kernel(const UpFusedArgs p, const int tiles_per_clip, const int n_tiles) {
+__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void up_fused_kernel(const UpFusedArgs p, const int tiles_per_clip, const int n_tiles, const int tickets) {
     using G = UfGeo<CIN, COUT>;
     constexpr int CORE = DOWN ? 16 : UF_CORE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_uf[];
@@ -101,6 +119,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void up_fused_kernel(const U
             gbs[i] = i < CIN ? p.gate_b[i] : 0.f;
         }
     }
+    int* const ticket_s = reinterpret_cast<int*>(smem_uf + G::OFF_TICKET);
+    if (tid == 0) *ticket_s = 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -118,6 +138,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void up_fused_kernel(const U
     // PRE (the narrow forms: at most three k steps = 24 registers): the NEXT tile's input rows and gate signals are requested before the
     // current tile's products — a wave's tile is otherwise load -> wait -> products -> s output frames with nothing of its own in flight
     // behind the loads (wait_any 0.6 of the wave cycles, 3.6-4.1 TB/s).  The same values reach the same operations: the same bits.
+    // (Round 6, measured and not kept: the 256 -> 96 layer's batch form at EIGHT waves of 256 registers with this prefetch — 0.163 against
+    // 0.167 ms at sixteen waves without spills, profiles/r06/up_fused_spills.txt — but hipcc contracts the gate's multiply-adds differently
+    // in that instantiation than in the four-wave form a single clip takes: test_full_batch_properties_1kbps, clip alone != clip in a batch.)
     constexpr bool PRE = G::K1 <= 3;
     f32x4_t xpre[PRE ? G::K1 : 1][2];
     float4 ypre = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -138,9 +161,20 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void up_fused_kernel(const U
             if constexpr (!DOWN) ypre = *reinterpret_cast<const float4*>(p.yi + r * 4);
         }
     };
-    prefetch(blockIdx.x * WAVES + wave);
+    const int tile_first = tickets ? take_tile<WAVES>(ticket_s, lane, n_tiles) : (int)blockIdx.x * WAVES + wave;
+    prefetch(tile_first);
 
-    for (int tile = blockIdx.x * WAVES + wave; tile < n_tiles; tile += gridDim.x * WAVES) {
+    const int lane_outer = lane;
+    for (int tile = tile_first, tile_next = 0; tile < n_tiles; tile = tile_next) {
+        tile_next = tickets ? take_tile<WAVES>(ticket_s, lane, n_tiles) : tile + (int)gridDim.x * WAVES;
+        // (round 6: the lane number opaque per tile — what the tile derives from it (LDS offsets of the weight fragments, of the parameters and
+        // of the gate table, row and store addresses) is computed here.  Hoisted out of the loop those values were spilled at 128 registers,
+        // and a reload from scratch waits for vmcnt(0): for the NEXT tile's rows, requested a few instructions earlier)
+        // (not at 48 -> 24, which has no spills and whose vector unit is the bound: recomputing the addresses cost it 8 %)
+        int lane_t = lane_outer;
+        if constexpr (G::K1 >= 3) asm volatile("" : "+v"(lane_t));
+        const int fl = lane_t & 15, lg = lane_t >> 4;
+        const unsigned char* const wl = smem_uf + 16 * lane_t;
         const int b = tile / tiles_per_clip;
         const int k = tile - b * tiles_per_clip;
         const int f = CORE * k - (DOWN ? 0 : 1) + fl;  // this lane's input frame
@@ -152,7 +186,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void up_fused_kernel(const U
         if constexpr (PRE) {
 #pragma unroll
             for (int s = 0; s < G::K1; ++s) xcur[s][0] = xpre[s][0], xcur[s][1] = xpre[s][1];
-            prefetch(tile + gridDim.x * WAVES);
+            prefetch(tile_next);
         }
         // ---- gate input: z = InstanceNorm(branch signals) of this frame (rows.hip, SRC_GATE) ----------------------------------------
         float z0 = 0.f, z1 = 0.f, z2 = 0.f, z3 = 0.f;
@@ -190,9 +224,16 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void up_fused_kernel(const U
                     if (valid) hi = gated(xcur[s][1], c_hi);
                 }
             } else {
-                if (valid) lo = gated(*reinterpret_cast<const f32x4_t*>(row + c_lo), c_lo);   // (32 s + 15 < CIN for every k step: CIN % 16 == 0)
+                // (round 6: loaded from the clamped row by EVERY lane and zeroed afterwards — behind `if (valid)` each k step's two loads sat in
+                // a branch of their own, between reloads of spilled registers that wait for vmcnt(0): sixteen serial round trips per tile)
+                const f32x4_t zero = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                const f32x4_t xl = *reinterpret_cast<const f32x4_t*>(row + c_lo);   // (32 s + 15 < CIN for every k step: CIN % 16 == 0)
+                lo = gated(xl, c_lo);
+                lo = valid ? lo : zero;
                 if (32 * s + 16 < CIN) {
-                    if (valid) hi = gated(*reinterpret_cast<const f32x4_t*>(row + c_hi), c_hi);
+                    const f32x4_t xh = *reinterpret_cast<const f32x4_t*>(row + c_hi);
+                    hi = gated(xh, c_hi);
+                    hi = valid ? hi : zero;
                 }
             }
             bf16x8 bp[3];
@@ -280,7 +321,10 @@ int launch_uf_waves(hipStream_t s, const UpFusedArgs& a, int tiles_per_clip, int
     int64_t blocks = ceil_div64(tiles, WAVES);
     const int64_t cus = l3ac_device_cu_count();
     if (blocks > cus) blocks = cus;
-    hipLaunchKernelGGL((up_fused_kernel<CIN, COUT, DOWN, WAVES>), dim3((unsigned)blocks), dim3(64 * WAVES), G::LDS, s, a, tiles_per_clip, (int)tiles);
+    // tiles by ticket (take_tile) where a wave has at least four of them (measured, profiles/r06/tickets_ab.txt: 48 -> 24 0.214 -> 0.193 ms,
+    // 96 -> 48 and 256 -> 96 - 2 %; with two tiles per wave — the 48 -> 96 down layer — the tickets cost 5 %)
+    const int tickets = tiles >= 4 * blocks * WAVES;
+    hipLaunchKernelGGL((up_fused_kernel<CIN, COUT, DOWN, WAVES>), dim3((unsigned)blocks), dim3(64 * WAVES), G::LDS, s, a, tiles_per_clip, (int)tiles, tickets);
     L3AC_LAUNCH_CHECK();
     return L3AC_OK;
 }
@@ -322,12 +366,13 @@ template <int K, int COUT>
 struct DxGeo {
     static constexpr int NQ = K / 8, RT = COUT / 16;
     static constexpr int OFF_PAR = RT * NQ * 512;        // bias | nw | nb, COUT floats each
-    static constexpr int LDS = OFF_PAR + 3 * COUT * 4;
+    static constexpr int OFF_TICKET = OFF_PAR + 3 * COUT * 4;
+    static constexpr int LDS = OFF_TICKET + 16;
     static_assert(K % 8 == 0 && COUT % 16 == 0 && (COUT == 48 || COUT == 96) && LDS <= 160 * 1024, "geometry (the norm's tree is written for 12 lanes per row)");
 };
 
 template <int K, int COUT, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, 1) void down_exact_kernel(const UpFusedArgs p, const int tiles_per_clip, const int n_tiles) {
+__global__ __launch_bounds__(64 * WAVES, 1) void down_exact_kernel(const UpFusedArgs p, const int tiles_per_clip, const int n_tiles, const int tickets) {
     using G = DxGeo<K, COUT>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_uf[];
     float* const par = reinterpret_cast<float*>(smem_uf + G::OFF_PAR);
@@ -342,6 +387,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void down_exact_kernel(const UpFused
         par[COUT + i] = p.nw[i];
         par[2 * COUT + i] = p.nb[i];
     }
+    int* const ticket_s = reinterpret_cast<int*>(smem_uf + G::OFF_TICKET);
+    if (tid == 0) *ticket_s = 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -351,7 +398,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void down_exact_kernel(const UpFused
     const int T = p.frames;
     const unsigned char* const wl = smem_uf + 8 * lane;
     const bool odd = (lg >> 1) != 0;  // elements 1, 3 of the 16 B (else 0, 2)
-    for (int tile = blockIdx.x * WAVES + wave; tile < n_tiles; tile += gridDim.x * WAVES) {
+    for (int tile = tickets ? take_tile<WAVES>(ticket_s, lane, n_tiles) : (int)blockIdx.x * WAVES + wave; tile < n_tiles;
+         tile = tickets ? take_tile<WAVES>(ticket_s, lane, n_tiles) : tile + (int)gridDim.x * WAVES) {
         const int b = tile / tiles_per_clip;
         const int f = 16 * (tile - b * tiles_per_clip) + fl;  // this lane's output frame
         const bool valid = f < T;
@@ -447,7 +495,8 @@ int launch_dx_waves(hipStream_t s, const UpFusedArgs& a, int tiles_per_clip, int
     int64_t blocks = ceil_div64(tiles, WAVES);
     const int64_t cus = l3ac_device_cu_count();
     if (blocks > cus) blocks = cus;
-    hipLaunchKernelGGL((down_exact_kernel<K, COUT, WAVES>), dim3((unsigned)blocks), dim3(64 * WAVES), G::LDS, s, a, tiles_per_clip, (int)tiles);
+    const int tickets = tiles >= 4 * blocks * WAVES;  // (as launch_uf_waves: 24 -> 48 0.121 -> 0.115 ms; 48 -> 96 has two tiles per wave)
+    hipLaunchKernelGGL((down_exact_kernel<K, COUT, WAVES>), dim3((unsigned)blocks), dim3(64 * WAVES), G::LDS, s, a, tiles_per_clip, (int)tiles, tickets);
     L3AC_LAUNCH_CHECK();
     return L3AC_OK;
 }

@@ -635,7 +635,7 @@ static bool use_wide(const l3ac_ctx* ctx, const ConvUnitW& w) {
 
 int conv_unit_step(l3ac_ctx* ctx, hipStream_t s, const ConvUnitW& w, float** cur, float** alt, int batch, int frames) {
     if (use_wide(ctx, w)) {
-        L3AC_TRY(launch_conv_unit_wide(s, w, *cur, *alt, reinterpret_cast<unsigned char*>(ctx->ws.h), ctx->ws.h_cap * sizeof(float), batch, frames, ctx->wide_sliced, ctx->unit_counter ? ctx->wide_counters : nullptr));
+        L3AC_TRY(launch_conv_unit_wide(s, w, *cur, *alt, reinterpret_cast<unsigned char*>(ctx->ws.h), ctx->ws.h_cap * sizeof(float), batch, frames, ctx->wide_sliced, ctx->unit_counter == 1 || ctx->unit_counter == 2 ? ctx->wide_counters : nullptr));
         float* t = *cur;
         *cur = *alt;
         *alt = t;
@@ -696,7 +696,7 @@ int run_conv_units(l3ac_ctx* ctx, hipStream_t s, const std::vector<ConvUnitW>& u
 
 int run_conv_unit(l3ac_ctx* ctx, hipStream_t s, const ConvUnitW& w, const float* x, float* y, int batch, int frames) {
     if (x != y && use_wide(ctx, w))
-        return launch_conv_unit_wide(s, w, x, y, reinterpret_cast<unsigned char*>(ctx->ws.h), ctx->ws.h_cap * sizeof(float), batch, frames, ctx->wide_sliced, ctx->unit_counter ? ctx->wide_counters : nullptr);
+        return launch_conv_unit_wide(s, w, x, y, reinterpret_cast<unsigned char*>(ctx->ws.h), ctx->ws.h_cap * sizeof(float), batch, frames, ctx->wide_sliced, ctx->unit_counter == 1 || ctx->unit_counter == 2 ? ctx->wide_counters : nullptr);
     if (!ctx->cfg.grn_exact && x != y && conv_unit_fused_supported(w.c)) return launch_conv_unit_fused(s, w, x, y, batch, frames, ctx->gemm_split, ctx->narrow_ring);
     const int group = conv_unit_group(ctx, w, batch, frames);
     for (int b0 = 0; b0 < batch; b0 += group) {
@@ -828,7 +828,7 @@ int run_last_block(l3ac_ctx* ctx, hipStream_t s, float* x, float* audio, int bat
         float* cur = x;
         float* alt = ws.a;
         for (const LegacyW& l : ctx->legacy) {
-            L3AC_TRY(launch_legacy_unit_fused(s, l, cur, alt, batch, frames, ctx->gemm_split));
+            L3AC_TRY(launch_legacy_unit_fused(s, l, cur, alt, batch, frames, ctx->gemm_split, ctx->unit_counter == 1 || ctx->unit_counter == 3 ? ctx->wide_counters + 4 : nullptr));
             float* t = cur;
             cur = alt;
             alt = t;

@@ -212,7 +212,7 @@ bool last_block_fused_supported(int c, int max_dil);
 // host builders of the LegacyUnit weight images: w1 [c][7][c] (tap-major rows), w2 [c][c]
 std::vector<unsigned char> legacy_w1_image(const float* w1, int c);
 std::vector<unsigned char> legacy_w2_image(const float* w2, int c);
-int launch_legacy_unit_fused(hipStream_t s, const LegacyW& w, const float* x, float* y, int batch, int frames, bool split);
+int launch_legacy_unit_fused(hipStream_t s, const LegacyW& w, const float* x, float* y, int batch, int frames, bool split, int* counters);
 int launch_head_fused(hipStream_t s, const HeadW& w, const float* x, int batch, int frames, float* audio, bool pretanh);
 // one ConvUnit of a stage on the ping-pong buffers: fused kernel (result in *alt, buffers swapped) or in place
 int conv_unit_step(l3ac_ctx* ctx, hipStream_t s, const ConvUnitW& w, float** cur, float** alt, int batch, int frames);

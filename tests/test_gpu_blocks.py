@@ -564,6 +564,28 @@ def test_last_block(tiny, full):
         _close("last_block", got.cpu(), r, atol=5e-5, rtol=5e-5)
 
 
+def test_last_block_tile_counter_returns_the_same_bits(full):
+    """Round 6: the LegacyUnits' persistent workgroups take their tiles from a device counter (option "unit_counter") once there are more
+    than two per workgroup — the same bits as static shares, launch after launch (three units per call, each leaving the counters zeroed),
+    with a ragged last tile per clip."""
+    codec, mc, w = full
+    ctx = codec.network.context()
+    c = mc.decoder_dims[-1]
+    for b, t in ((20, 16200), (33, 9001)):
+        xf = G.to_frames(_rand((b, c, t), 61 + b))
+        outs = {}
+        for mode in (1, 0, 1):
+            ctx.set_option("unit_counter", mode)
+            try:
+                y = G.op_plain(ctx, "l3ac_op_last_block", xf, b, t, (b, t))
+            finally:
+                ctx.set_option("unit_counter", 1)
+            if mode in outs:
+                assert torch.equal(outs[mode], y), f"B={b} T={t}: two calls with unit_counter={mode} differ"
+            outs[mode] = y
+        assert torch.equal(outs[0], outs[1]), f"B={b} T={t}: tiles by counter differ from static shares"
+
+
 def test_local_trans_single_and_multi_window(tiny, full):
     codec, mc, w = tiny
     for block, window, depth, t in (("en_encoder.down_trans.trans", 16, 1, 42), ("en_decoder.local_trans", 8, 2, 21),
