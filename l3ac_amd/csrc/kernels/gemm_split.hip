@@ -256,6 +256,27 @@ __device__ __forceinline__ void gemm_split_body16(const GemmArgs& p, const int g
         step(kt, a_pre[0], std::integral_constant<int, 0>{});
         if (kt + 1 < n_tiles) step(kt + 1, a_pre[1], std::integral_constant<int, 1>{});
     }
+    // Round 6: the epilogue of gemm_split_kernel_w256 here too — every strip of 16 rows x 64 columns through 4 KB of this wave's LDS (the W
+    // buffers are free behind the loop's last barrier: 12 KB per wave) and back row-major, 16-B stores instead of 4-B ones (a quarter of the
+    // store instructions; per element the same operations in the same order: the same bits).  A timing-only build without any epilogue ran
+    // the C = 512 ConvUnit 19 % faster: the store instructions were the largest single cost left in this kernel.  Where the 16-B accesses
+    // are not possible (GEGLU's interleaved columns, an output or parameter row that is not 16-B aligned) the permlane form stays.
+    {
+        auto al16 = [](const void* q) __attribute__((always_inline)) { return ((uintptr_t)q & 15) == 0; };
+        const bool rows_ok = p.epi != EPI_GEGLU && p.n % 4 == 0 && p.ldc % 4 == 0 && al16(p.c) && al16(p.bias) &&
+                             (p.epi != EPI_BIAS_RES || (p.ldres % 4 == 0 && al16(p.res))) &&
+                             ((p.epi != EPI_SNAKE && p.epi != EPI_SNAKE_GRN) || (al16(p.alpha) && al16(p.inv_alpha))) &&
+                             (p.epi != EPI_SNAKE_GRN || (al16(p.gamma) && al16(p.beta)));
+        if (rows_ok) {  // (wave-uniform: kernel arguments only)
+            // (the lane number made opaque HERE: everything the epilogue derives from it — LDS offsets, row and column numbers — is then
+            // computed behind the loop; hoisted above it those values cost the 168-register loop 29 spilled registers: 1.56 -> 2.27 ms)
+            int lane_e = lane;
+            asm volatile("" : "+v"(lane_e));
+            epilogue_rows<RG, 2>(p, [&](int sq, int h, int tt) __attribute__((always_inline)) -> f32x4a& { return acc[h][4 * sq + tt]; }, m0, n0, wave, lane_e,
+                                 reinterpret_cast<float*>(smem_split + 12288 * wave));
+            return;
+        }
+    }
     gemm_epilogue16<RG>(p, acc, m0, n0, wave, lane);
 }
 

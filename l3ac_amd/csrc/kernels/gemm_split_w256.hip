@@ -51,66 +51,6 @@ __device__ __forceinline__ void split_stage(SplitPair& s, unsigned& o0, unsigned
     }
 }
 
-// ---- epilogue.  The accumulator layout gives a lane four ROWS of one column; stored as it is that is one 4-B store instruction per
-// element — 192 per lane, 56 cycles each with every CU storing at once: 43 k cycles per tile against 88 k of k loop (stamps,
-// profiles/r06/gemm_w256.md), and nothing covers them at one wave per SIMD.  Instead every strip of 16 rows x 64 columns goes through
-// 4 KB of LDS of this wave (the second W buffer is free behind the last barrier of the k loop: 12 KB per wave, two strips) and comes
-// back row-major: 16 B per lane, 4 rows x 256 B per instruction, 48 non-temporal 16-B stores per lane.  LDS executes a wave's accesses in
-// order, so the write -> read -> rewrite of a strip buffer needs no wait of its own.  Written: ds_write_b32, rows 4 lg + i at a stride of
-// 256 B (2-way on the store, free); read: ds_read_b128, lane (row = lane >> 4 (+ 4 j), quad = lane & 15): conflict-free.
-// Per element the operations of gemm_epilogue16, in its order: same bits.
-template <int RG>
-__device__ __forceinline__ void epilogue_rows(const GemmArgs& p, f32x4a (&acc)[2][RG][8], int64_t m0, int n0, int wave, int lane, float* tb) {
-    {
-    const int er = lane >> 4, eq = lane & 15, ln = lane & 15, lg = lane >> 4;
-    const int64_t mw = m0 + 16 * RG * wave;
-#pragma unroll
-    for (int sq = 0; sq < 4; ++sq) {
-        const int col = n0 + 64 * sq + 4 * eq;  // this lane's four columns of the quarter
-        typedef float f4 __attribute__((ext_vector_type(4)));
-        const f4 bias = p.bias ? *reinterpret_cast<const f4*>(p.bias + col) : f4{0.f, 0.f, 0.f, 0.f};
-        f4 alpha = {0.f, 0.f, 0.f, 0.f}, inv_alpha = alpha, gamma = alpha, beta = alpha;
-        if (p.epi == EPI_SNAKE || p.epi == EPI_SNAKE_GRN) {
-            alpha = *reinterpret_cast<const f4*>(p.alpha + col);
-            inv_alpha = *reinterpret_cast<const f4*>(p.inv_alpha + col);
-        }
-        if (p.epi == EPI_SNAKE_GRN) {
-            gamma = *reinterpret_cast<const f4*>(p.gamma + col);
-            beta = *reinterpret_cast<const f4*>(p.beta + col);
-        }
-#pragma unroll
-        for (int h = 0; h < RG; ++h) {
-            float* const sb = tb + 1024 * ((sq * RG + h) & 1);
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) sb[(4 * lg + i) * 64 + 16 * tt + ln] = acc[sq >> 1][h][4 * (sq & 1) + tt][i];
-#pragma unroll
-            for (int jr = 0; jr < 4; ++jr) {
-                const int64_t m = mw + 16 * h + er + 4 * jr;
-                f4 v = *reinterpret_cast<const f4*>(sb + (er + 4 * jr) * 64 + 4 * eq);
-                if (m >= p.m) continue;
-                v = v + bias;
-                if (p.epi == EPI_SNAKE || p.epi == EPI_SNAKE_GRN) {
-                    const f32x2 s0 = snake_act2(f32x2{v.x, v.y}, f32x2{alpha.x, alpha.y}, f32x2{inv_alpha.x, inv_alpha.y});
-                    const f32x2 s1 = snake_act2(f32x2{v.z, v.w}, f32x2{alpha.z, alpha.w}, f32x2{inv_alpha.z, inv_alpha.w});
-                    if (p.epi == EPI_SNAKE_GRN) {  // layers.py:115, n_x == 1
-                        const f32x2 o0 = __builtin_elementwise_fma(f32x2{gamma.x, gamma.y}, s0, f32x2{beta.x, beta.y}) + s0;
-                        const f32x2 o1 = __builtin_elementwise_fma(f32x2{gamma.z, gamma.w}, s1, f32x2{beta.z, beta.w}) + s1;
-                        v = f4{o0.x, o0.y, o1.x, o1.y};
-                    } else {
-                        v = f4{s0.x, s0.y, s1.x, s1.y};
-                    }
-                } else if (p.epi == EPI_BIAS_RES) {
-                    v = *reinterpret_cast<const f4*>(p.res + m * p.ldres + col) + v;
-                }
-                __builtin_nontemporal_store(v, reinterpret_cast<f4*>(p.c + m * p.ldc + col));
-            }
-        }
-    }
-}
-}
-
 template <int RG>
 __global__ __launch_bounds__(THREADS, 1) void gemm_split_kernel_w256(const GemmArgs p) {
     constexpr int WM = 16 * RG, BMW = 4 * WM, NT = 16;
@@ -292,7 +232,8 @@ __global__ __launch_bounds__(THREADS, 1) void gemm_split_kernel_w256(const GemmA
         default: k_loop(std::integral_constant<int, 3>{}); break;
     }
     W256_STAMP(2);
-    epilogue_rows<RG>(p, acc, m0, n0, wave, lane, reinterpret_cast<float*>(smem_split + 2 * W_TILE + 12288 * wave));
+    epilogue_rows<RG, 4>(p, [&](int sq, int h, int tt) __attribute__((always_inline)) -> f32x4a& { return acc[sq >> 1][h][4 * (sq & 1) + tt]; }, m0, n0, wave, lane,
+                         reinterpret_cast<float*>(smem_split + 2 * W_TILE + 12288 * wave));
     W256_STAMP(3);
 }
 
