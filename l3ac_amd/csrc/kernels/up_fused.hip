@@ -24,6 +24,7 @@
 #include "../network.hpp"
 #include "device_math.hpp"
 #include "ring_common.hpp"
+#include "tickets.hpp"
 
 #include <vector>
 
@@ -59,23 +60,6 @@ struct UfGeo {
     static constexpr int LDS = OFF_TICKET + 16;
     static_assert(CIN % 16 == 0 && COUT % 8 == 0 && LDS <= 160 * 1024, "geometry");
 };
-
-// Tiles by ticket (round 6).  The waves of these workgroups walk their tiles independently and a SIMD serves its OLDEST wave first: with
-// equal static shares (tile = blockIdx WAVES + wave + k gridDim WAVES) the first waves of a workgroup finish early and the last ones run
-// the end of the kernel on a thinly occupied CU (conv_unit_wide.hip, 'DYN': measured there with stamps).  The workgroup keeps its tiles —
-// ((round r) gridDim + blockIdx) WAVES + j — and a wave takes the next (r, j) by a ticket in LDS; n_tiles = nothing left.  Which wave
-// computes a tile does not enter its arithmetic: the same bits.
-template <int WAVES>
-__device__ __forceinline__ int take_tile(int* ticket, const int lane, const int n_tiles) {
-    for (;;) {
-        int q = 0;
-        if (lane == 0) q = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        q = __builtin_amdgcn_readfirstlane(q);
-        const int base = ((q / WAVES) * (int)gridDim.x + (int)blockIdx.x) * WAVES;
-        if (base >= n_tiles) return n_tiles;
-        if (base + q % WAVES < n_tiles) return base + q % WAVES;  // (the last round's missing tiles are skipped)
-    }
-}
 
 // value of the lane one position down / up inside its 16-lane row (frame fl - 1 / fl + 1 of the same k group)
 __device__ __forceinline__ float row_prev(float v) {
