@@ -785,6 +785,36 @@ def test_streaming_chunks_and_graph_capture():
         assert torch.equal(wave_q, eager_wave_q[i])
 
 
+def test_batch_graph_replays_with_the_unit_counters():
+    """Round 6: at a batch the C = 96 ConvUnits and the LegacyUnits take their tiles from device counters that every launch leaves zeroed
+    (no memset node).  A captured graph of encode + decode of 32 clips must therefore replay — again and again, on new inputs — to the bits
+    of the eager calls, and to those of a context that uses static shares."""
+    codec = _codec("1kbps", 0)
+    ctx = codec.network.context()
+    ctx.reserve(32, 16000)
+    clips = seeded_audio(96, 16000).cuda()
+    ctx.set_option("unit_counter", 0)
+    try:
+        static_shares = [codec.decode_audio(indices=codec.encode_audio(clips[32 * i:32 * i + 32])[1]["indices"]) for i in range(3)]
+    finally:
+        ctx.set_option("unit_counter", 1)
+    eager = [codec.encode_audio(clips[32 * i:32 * i + 32]) for i in range(3)]
+    eager_wave = [codec.decode_audio(indices=e[1]["indices"]) for e in eager]
+    for i in range(3):
+        assert torch.equal(eager_wave[i], static_shares[i]), f"batch {i}: tiles by counter differ from static shares"
+    static_in = torch.zeros(32, 16000, device="cuda")
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        q, ind = codec.encode_audio(static_in)
+        wave = codec.decode_audio(indices=ind["indices"])
+    for i in (0, 1, 2, 1, 0):
+        static_in.copy_(clips[32 * i:32 * i + 32])
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(ind["indices"], eager[i][1]["indices"]), f"replay of batch {i}: tokens differ from the eager call"
+        assert torch.equal(wave, eager_wave[i]), f"replay of batch {i}: waveform differs from the eager call"
+
+
 def test_token_bit_packing_roundtrip():
     """Wire format: little-endian bit stream, ceil(log2 K) bits per token, checked against numpy."""
     for tag, bits in (("1kbps", 17), ("3kbps", 18)):
