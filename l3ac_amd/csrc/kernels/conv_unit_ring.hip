@@ -254,6 +254,9 @@ __global__ __launch_bounds__(64 * G::WAVES, G::WAVES * G::PER_CU / 4) void conv_
             for (int ft = 0; ft < G::FT; ++ft) yacc[ft][rt] = b2v;
         }
 
+        // (round 6: a wave inside its hidden-pair loop outranks the waves that are in their front end or storing — as in
+        // conv_unit_wide_kernel<96>; C = 48 at 256 clips 0.759 -> 0.748 ms; the same in legacy_unit_split_kernel measured slower)
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll 1
         for (int hp = 0; hp < G::NT; ++hp) {
             f32x4_t hx[G::FT][2];  // hidden channels 32 hp + 16 u + 4 g + i of this lane's frames, starting at the pw_conv1 bias
@@ -337,6 +340,7 @@ __global__ __launch_bounds__(64 * G::WAVES, G::WAVES * G::PER_CU / 4) void conv_
                 __builtin_amdgcn_sched_barrier(0);  // one fragment live at a time (left alone the scheduler front-loads a slot's reads: 250 spills)
             });
         }
+        __builtin_amdgcn_s_setprio(0);
         // ---- residual + store --------------------------------------------------------------------------------------------------
 #pragma unroll
         for (int ft = 0; ft < G::FT; ++ft) {

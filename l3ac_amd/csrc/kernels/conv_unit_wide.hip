@@ -661,6 +661,10 @@ __global__ __launch_bounds__(256, WGeo<C>::WG_PER_CU) void conv_unit_wide_kernel
         XTile xdummy = {};
 
         WIDE_STAMP(2);
+        // (round 6, two workgroups per CU: a wave inside its product loop outranks the other workgroup's wave while that one is in its front
+        // end or epilogue — otherwise the OLDER wave's 1 300 front-end instructions are served before the younger wave's products:
+        // 1.27 -> 1.24 ms for the three C = 96 units, profiles/r06/wide96_sched/prio_ab.txt; priority 3, or the younger workgroup only: no better)
+        if constexpr (G::WG_PER_CU == 2) __builtin_amdgcn_s_setprio(1);
         // ---- first product of hidden tile 0 (ring slots 0 .. NA-1), then frame half 0 of its activation: nothing to overlap
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) fb[0][pl] = frag1(0, 0, pl);
@@ -740,6 +744,7 @@ __global__ __launch_bounds__(256, WGeo<C>::WG_PER_CU) void conv_unit_wide_kernel
                       xdummy, tab_lane);
         });
 
+        if constexpr (G::WG_PER_CU == 2) __builtin_amdgcn_s_setprio(0);
         WIDE_STAMP(5);
         // ---- residual + store (xtract/nn/layers.py:59-62).  The accumulators hold, per lane, 4 channels of ONE frame for each of
         // the 4 C/32 (tile, group) pairs: stored directly that is 32 B per row per instruction.  Instead every 32-channel tile
