@@ -1166,6 +1166,44 @@ int launch_wide(hipStream_t s, const ConvUnitW& w, const float* x, float* y, uns
     int64_t blocks = ceil_div64(tiles, 4);
     const int cus = l3ac_device_cu_count();
     const bool half = 2 * blocks <= (int64_t)cus * G::WG_PER_CU;  // half tiles while twice the workgroups still fit one pass
+    if constexpr (!G::FRONT) {
+        // SLICED TAIL (round 6): a remainder of at most SLICED_MAX_TILES frame tiles behind the full passes (256 x 900 frames at C = 256: 7 full
+        // passes + 32 tiles) cost 0.7 of a pass as half tiles on 16 workgroups — a wave's chain of 3 072 MFMAs however few waves run
+        // (stamps: 180 k of the kernel's 1 800 k cycles, ~90 us).  The sliced form (two launches over frame tiles x channel slices, the same
+        // bits) does those frames in ~25 us: the passes run on rows [0, 32 full), the two sliced launches on the rest, from the same plane
+        // image.  One box, three interleaved rounds: the step 13.22 -> 13.11 ms (profiles/r06/sliced_tail_ab.txt).
+        const int64_t per_pass = 4LL * 256 * G::WG_PER_CU;
+        const int64_t full = tiles / per_pass * per_pass, rest = tiles - full;
+        if (!half && full > 0 && rest > 0 && 2 * rest <= SLICED_MAX_TILES) {
+            using S = SGeo<C>;
+            const int64_t rows_main = 32 * full, rows_t = rows - rows_main;
+            {
+                std::snprintf(name, sizeof(name), "conv_unit_wide_kernel<%d>", C);
+                ProfScope prof(s, name, (double)rows_main * 16.0 * C * C, (double)rows_main * 14.0 * C);
+                hipLaunchKernelGGL((conv_unit_wide_kernel<C, 2>), dim3(256 * G::WG_PER_CU), dim3(256), G::LDS, s, w, planes, x, y, rows_main, (int64_t)0, frames,
+                                   (int*)nullptr);
+                L3AC_LAUNCH_CHECK();
+            }
+            const int64_t tiles16_t = ceil_div64(rows_t, 16), tiles_pad_t = sliced_tiles_pad(rows_t);
+            const unsigned char* planes_t = planes + full * (int64_t)(G::NS1 * 3072);
+            unsigned char* hid = planes + (wide_planes_bytes(C, rows) + 255) / 256 * 256;  // (conv_unit_wide_scratch_bytes reserves it)
+            const float* x_t = x + rows_main * C;
+            float* y_t = y + rows_main * C;
+            {
+                std::snprintf(name, sizeof(name), "wide_sliced_hidden_kernel<%d>", C);
+                ProfScope p1(s, name, (double)rows_t * 8.0 * C * C, (double)rows_t * 30.0 * C);
+                hipLaunchKernelGGL((wide_sliced_hidden_kernel<C>), dim3((unsigned)(tiles_pad_t / 4 * (G::NT / S::GH))), dim3(256), S::LDS1, s, w, planes_t, hid,
+                                   tiles16_t, tiles_pad_t, x_t, rows_t, frames);
+                L3AC_LAUNCH_CHECK();
+            }
+            std::snprintf(name, sizeof(name), "wide_sliced_out_kernel<%d>", C);
+            ProfScope p2(s, name, (double)rows_t * 8.0 * C * C, (double)rows_t * 32.0 * C);
+            hipLaunchKernelGGL((wide_sliced_out_kernel<C>), dim3((unsigned)(ceil_div64(tiles16_t, 2) * (G::RT / 2))), dim3(256), S::LDS2, s, w, hid, x_t, y_t, rows_t,
+                               tiles16_t, tiles_pad_t);
+            L3AC_LAUNCH_CHECK();
+            return L3AC_OK;
+        }
+    }
     std::snprintf(name, sizeof(name), "conv_unit_wide_kernel<%d>", C);
     ProfScope prof(s, name, (double)rows * (16.0 * C * C + (G::FRONT ? 30.0 * C : 0.0)), (double)rows * (G::FRONT ? 8.0 : 14.0) * C);
     if (half) {
@@ -1179,6 +1217,7 @@ int launch_wide(hipStream_t s, const ConvUnitW& w, const float* x, float* y, uns
         const int64_t full = tiles / per_pass * per_pass, rest = tiles - full;
         const int64_t tail = (full > 0 && 2 * rest <= per_pass) ? rest : 0;
         if (blocks > 256 * G::WG_PER_CU) blocks = 256 * G::WG_PER_CU;
+
         int64_t tail_k = tail;
         int* ctr = nullptr;
         if (G::DYN && counters && tiles > 4 * blocks) {
@@ -1202,7 +1241,10 @@ bool conv_unit_wide_supported(int c) { return c == 96 || c == 128 || c == 192 ||
 // counts at which the sliced form exists — its hidden image behind it
 size_t conv_unit_wide_scratch_bytes(int c, int64_t rows) {
     const size_t planes = wide_planes_bytes(c, rows);
-    return sliced_exists(c, rows) ? (planes + 255) / 256 * 256 + sliced_hidden_bytes(c, rows) : planes;
+    // (large row counts, C >= 128: the remainder of the last pass may run in the sliced form — launch_wide, 'sliced tail' — up to
+    // SLICED_MAX_TILES frame tiles of hidden image behind the planes)
+    if (sliced_exists(c, rows)) return (planes + 255) / 256 * 256 + sliced_hidden_bytes(c, rows);
+    return c >= 128 ? (planes + 255) / 256 * 256 + sliced_hidden_bytes(c, 16 * SLICED_MAX_TILES) : planes;
 }
 
 // x must not alias y; `planes` = at least conv_unit_wide_scratch_bytes(c, batch * frames) bytes of scratch (checked).

@@ -452,6 +452,24 @@ def test_conv_unit_wide_unit_counter_returns_the_same_bits(full):
     _close("unit counter, C = 96", G.from_frames(outs[1]), O.conv_unit(w, "decoder.blocks.7.0.module", G.from_frames(xf)), atol=5e-5, rtol=5e-5)
 
 
+def test_conv_unit_wide_sliced_tail_returns_the_same_bits(full):
+    """Round 6: at C >= 128 a remainder of at most 256 frame tiles behind the full passes runs in the sliced form (two launches from the same
+    plane image) instead of as half tiles inside the fused kernel.  40 x 900 frames at C = 256 are one full pass + 101 tiles: both kernels
+    must appear, and every clip — those of the passes, those of the tail, the one the boundary falls into — must equal the clip alone."""
+    codec, mc, w = full
+    ctx = codec.network.context()
+    block, c, b, t = "decoder.blocks.4.1.module", 256, 40, 900
+    xf = G.to_frames(_rand((b, c, t), 9300))
+    with _capi.profile() as prof:
+        y = G.op_block(ctx, "l3ac_op_conv_unit", block, xf, (b, t, c))
+    names = [e["name"] for e in prof.entries]
+    assert "conv_unit_wide_kernel<256>" in names and "wide_sliced_out_kernel<256>" in names and "wide_sliced_hidden_kernel<256>" in names, names
+    for i in (0, 35, 36, 37, 39):  # rows 32 768 .. fall into clip 36
+        y1 = G.op_block(ctx, "l3ac_op_conv_unit", block, xf[i:i + 1].contiguous(), (1, t, c))
+        assert torch.equal(y1, y[i:i + 1]), f"clip {i}: differs from the clip alone"
+    _close("sliced tail, C = 256", G.from_frames(y), O.conv_unit(w, block, G.from_frames(xf)), atol=5e-5, rtol=5e-5)
+
+
 def test_conv_units_wide_scratch_on_a_fresh_context():
     """The wide ConvUnit's front end writes bf16x3 planes of WHOLE 32-frame tiles (conv_unit_wide_scratch_bytes) into the
     hidden scratch: more than the 4C floats per row that scratch is otherwise sized by when batch * frames < 12.  On a
