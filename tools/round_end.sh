@@ -13,3 +13,12 @@ python3 tools/summarize_profiles.py $OUT/raw $OUT/profiles | tail -12
 timeout 900 python bench.py --profiles-dir $OUT/profiles > $OUT/profiles/bench_default.json 2> $OUT/bench_default.err
 tail -c 600 $OUT/profiles/bench_default.json
 rm -rf $OUT/raw/*/pmc_* # per-dispatch counter dumps: tens of MB
+# same-box reference: a library kept from an earlier state of the round (l3ac_amd/libl3ac_hip_base.so, git-ignored) against the final one
+if [ -f l3ac_amd/libl3ac_hip_base.so ]; then
+  for i in 1 2 3; do for t in base -; do lib=$PWD/l3ac_amd/libl3ac_hip.so; [ $t = base ] && lib=$PWD/l3ac_amd/libl3ac_hip_base.so
+    L3AC_LIB_PATH=$lib timeout 300 python bench.py --pipeline-only --steps 60 --warmup 10 2>/dev/null | python -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$t', round(d['ms_per_step'],3), 'kernel sum', round(sum(e['ms'] for e in d['kernels']),3))
+"; done; done | tee $OUT/profiles/final_same_box_ab.txt
+fi
