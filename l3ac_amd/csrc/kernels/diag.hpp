@@ -69,55 +69,3 @@ extern "C" int l3ac_debug_w256_stamps(unsigned long long* out, int n) {
 #define W256_STAMP(slot) do { } while (0)
 #endif
 #endif
-
-// ---- legacy_unit_split_kernel: sums per phase (kept in registers, written once at the end) of wave 0 of workgroup 0 (slots 0..7) and of the
-//      last workgroup (slots 8..15) --------------------------------------------------------------------------------------------------
-#ifdef L3AC_DIAG_UNIT_LEGACY
-#ifdef L3AC_LG_STAMPS
-__device__ long long g_lg_stamps[20];  // [16], [17]: tiles taken by the two workgroups
-__device__ long long g_lg_blocks[1024][2];  // per workgroup: lifetime, tiles (summed over launches)
-#define LG_STAMP_INIT()                                          \
-    long long lg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};              \
-    long long lg_tiles = 0;                                      \
-    long long lg_last = (long long)__builtin_amdgcn_s_memtime()
-#define LG_STAMP(slot)                                                          \
-    do {                                                                        \
-        const long long now_ = (long long)__builtin_amdgcn_s_memtime();         \
-        lg_acc[slot] += now_ - lg_last;                                         \
-        lg_last = now_;                                                         \
-    } while (0)
-#define LG_STAMP_FLUSH()                                                                                 \
-    do {                                                                                                 \
-        if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) {                      \
-            for (int i_ = 0; i_ < 8; ++i_) g_lg_stamps[(blockIdx.x == 0 ? 0 : 8) + i_] += lg_acc[i_];   \
-            g_lg_stamps[blockIdx.x == 0 ? 16 : 17] += lg_tiles;                                          \
-        }                                                                                                \
-        if (threadIdx.x == 0 && blockIdx.x < 1024) {                                                     \
-            long long t_ = 0;                                                                            \
-            for (int i_ = 0; i_ < 8; ++i_) t_ += lg_acc[i_];                                             \
-            g_lg_blocks[blockIdx.x][0] += t_;                                                            \
-            g_lg_blocks[blockIdx.x][1] += lg_tiles;                                                      \
-        }                                                                                                \
-    } while (0)
-extern "C" int l3ac_debug_lg_blocks(long long* out, int reset) {
-    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lg_blocks), sizeof(long long) * 2048);
-    if (reset) {
-        static long long zero[2048] = {};
-        rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_lg_blocks), zero, sizeof(zero));
-    }
-    return rc;
-}
-extern "C" int l3ac_debug_lg_stamps(long long* out, int n, int reset) {
-    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lg_stamps), (size_t)n * sizeof(long long));
-    if (reset) {
-        long long zero[20] = {};
-        rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_lg_stamps), zero, sizeof(zero));
-    }
-    return rc;
-}
-#else
-#define LG_STAMP_INIT() do { } while (0)
-#define LG_STAMP(slot) do { } while (0)
-#define LG_STAMP_FLUSH() do { } while (0)
-#endif
-#endif

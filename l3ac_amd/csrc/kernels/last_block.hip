@@ -21,8 +21,6 @@
 #include "../network.hpp"
 #include "device_math.hpp"
 #include "split_bf16.hpp"
-#define L3AC_DIAG_UNIT_LEGACY
-#include "diag.hpp"
 
 namespace {
 
@@ -308,12 +306,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void legacy_unit_split_kernel(const 
     const int m0 = 32 * wave;
     const int dps = dil * G::PS;
 
-    LG_STAMP_INIT();
     for (; tile < total_tiles;) {
-        LG_STAMP(7);  // (loop overhead + the previous iteration's last barrier)
-#ifdef L3AC_LG_STAMPS
-        ++lg_tiles;
-#endif
         int after_next = next_tile + (int)gridDim.x;
         if (counters && tid == 0) after_next = __hip_atomic_fetch_add(counters, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 2 * (int)gridDim.x;
         // (the staging thread's row and channel quad, recomputed per tile from an opaque thread number like the lane values below)
@@ -341,11 +334,8 @@ __global__ __launch_bounds__(64 * WAVES, 4) void legacy_unit_split_kernel(const 
                 *reinterpret_cast<uint2*>(dst + 2 * splane) = make_uint2(a2, b2);
             }
         }
-        LG_STAMP(0);  // staging: snake + split of the S tile
         __syncthreads();
-        LG_STAMP(1);  // barrier A
         if (next_tile < total_tiles) prefetch(next_tile, srow, sc0);  // in flight during the products
-        LG_STAMP(2);
 
         int woff = 0;  // opaque per tile: keeps the (tile-invariant) weight fragments in LDS instead of ~100 hoisted VGPRs
         asm volatile("" : "+s"(woff));
@@ -402,7 +392,6 @@ __global__ __launch_bounds__(64 * WAVES, 4) void legacy_unit_split_kernel(const 
 #pragma unroll
                     for (int fh = 0; fh < 2; ++fh) xt[hh][fh] = mfma_split16(wf[hh], sf[fh], xt[hh][fh]);
             }
-            LG_STAMP(3);  // first product
             // ---- snake on the accumulators, split them, then Y^T[c][m] = b2[c] + sum_n W2[c][n] X^T[n][m] -----------
             // the B operand of frame half fh: word 2 hh + ip = hidden rows 16 hh + 4 lg + 2 ip, + 1 (k order sigma(lg, j) = j < 4 ?
             // 4 lg + j : 16 + 4 lg + j - 4, which the W2 image is built in); a missing second tile contributes zeros
@@ -434,7 +423,6 @@ __global__ __launch_bounds__(64 * WAVES, 4) void legacy_unit_split_kernel(const 
                     }
                 }
             }
-            LG_STAMP(4);  // activation + split
             bf16x8 xb[2][3];
 #pragma unroll
             for (int fh = 0; fh < 2; ++fh)
@@ -452,7 +440,6 @@ __global__ __launch_bounds__(64 * WAVES, 4) void legacy_unit_split_kernel(const 
             // ---- residual + store: lane (frame 16 fh + ln, row group lg) owns channels 16 rt + 4 lg + {0..3} ---------------
             // (round 6: the four residual pieces are requested together, from clamped addresses by every lane, and the stores are predicated —
             // inside `if (t < frames)` / `if (c0 < C)` each piece was load -> s_waitcnt vmcnt(0) -> add -> store: four serial round trips per tile)
-            LG_STAMP(5);  // second product
             // (the statement below: not before the first product has been issued — requested earlier the pieces are held across it and spilled)
             asm volatile("" ::: "memory");
             float4 xr[2][G::NHH];
@@ -479,13 +466,11 @@ __global__ __launch_bounds__(64 * WAVES, 4) void legacy_unit_split_kernel(const 
                 }
             }
         }
-        LG_STAMP(6);  // residual + store
         if (counters && tid == 0) next_tile_s = after_next;
         __syncthreads();  // every wave is done with the S tile before the next one overwrites it
         tile = next_tile;
         next_tile = counters ? next_tile_s : after_next;  // (rewritten only behind the next iteration's first barrier)
     }
-    LG_STAMP_FLUSH();
     if (counters && tid == 0) {
         const int left = __hip_atomic_fetch_add(counters + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (left == (int)gridDim.x - 1) {

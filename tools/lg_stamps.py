@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Where a legacy_unit_split_kernel workgroup spends its cycles: s_memtime sums per phase of thread 0 of the first and of the last workgroup
-(diagnostic build: L3AC_BUILD_TAG=lgstamps L3AC_EXTRA_HIPCC_FLAGS=-DL3AC_LG_STAMPS python -m l3ac_amd.build; L3AC_LIB_PATH=...).
+(diagnostic build: git apply tools/patches/legacy_unit_stamps.patch, then L3AC_BUILD_TAG=lgstamps L3AC_EXTRA_HIPCC_FLAGS=-DL3AC_LG_STAMPS
+python -m l3ac_amd.build; L3AC_LIB_PATH=l3ac_amd/libl3ac_hip_lgstamps.so; the stamp hooks are kept out of the product sources).
 usage: tools/lg_stamps.py [batch]"""
 import ctypes as C
 import sys
